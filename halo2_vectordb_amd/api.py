@@ -1,0 +1,205 @@
+"""numpy-facing wrappers over the C ABI (include/vdb.h).  Thin plumbing only: every function
+marshals numpy buffers into one `vdb_*` call.  Field elements are uint64 arrays (..., 4):
+little-endian limbs, Montgomery form (halo2curves layout).  G1 points are (..., 8): x then y.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import VdbError, check  # noqa: F401
+
+NTT_INVERSE_SCALE = 1
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sz(n):
+    return ctypes.c_size_t(int(n))
+
+
+def _fr(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4
+    return a
+
+
+def init(device=None):
+    return _lib.init(device)
+
+
+def shutdown():
+    _lib.load().vdb_shutdown()
+    _lib._inited = None
+
+
+def device_count():
+    return _lib.load().vdb_device_count()
+
+
+# ---------------------------------------------------------------- field helpers
+def _binop(name, a, b):
+    L = _lib.init()
+    a, b = _fr(a), _fr(b)
+    o = np.empty_like(a)
+    check(getattr(L, name)(_p(a), _p(b), _p(o), _sz(a.size // 4)))
+    return o
+
+
+def fr_mul(a, b):
+    return _binop("vdb_fr_mul", a, b)
+
+
+def fr_add(a, b):
+    return _binop("vdb_fr_add", a, b)
+
+
+def fr_sub(a, b):
+    return _binop("vdb_fr_sub", a, b)
+
+
+def _unop(name, a):
+    L = _lib.init()
+    a = _fr(a)
+    o = np.empty_like(a)
+    check(getattr(L, name)(_p(a), _p(o), _sz(a.size // 4)))
+    return o
+
+
+def fr_from_canonical(a):
+    return _unop("vdb_fr_from_canonical", a)
+
+
+def fr_to_canonical(a):
+    return _unop("vdb_fr_to_canonical", a)
+
+
+def fr_batch_invert(a):
+    return _unop("vdb_fr_batch_invert", a)
+
+
+def bench_fr_mul(threads=256 * 256 * 8, iters=2000):
+    L = _lib.init()
+    out = ctypes.c_double(0)
+    check(L.vdb_bench_fr_mul(_sz(threads), _sz(iters), ctypes.byref(out)))
+    return out.value
+
+
+def root_of_unity(k):
+    o = np.zeros(4, dtype=np.uint64)
+    check(_lib.load().vdb_fr_root_of_unity(ctypes.c_uint32(k), _p(o)))
+    return o
+
+
+# ---------------------------------------------------------------- NTT
+def _col_ptrs(cols):
+    ptrs = (ctypes.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    return ptrs
+
+
+def ntt_batch(cols, omega, flags=0):
+    """cols: (n_cols, n, 4); returns transformed copy (host-pointer entry point)."""
+    L = _lib.init()
+    cols = np.array(cols, dtype=np.uint64, copy=True)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    views = [cols[i] for i in range(n_cols)]
+    omega = _fr(omega)
+    check(L.vdb_ntt_batch(_col_ptrs(views), _sz(n_cols), ctypes.c_uint32(n.bit_length() - 1), _p(omega), ctypes.c_int(flags)))
+    return cols
+
+
+def lagrange_to_coeff(cols):
+    L = _lib.init()
+    cols = np.array(cols, dtype=np.uint64, copy=True)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    views = [cols[i] for i in range(n_cols)]
+    check(L.vdb_lagrange_to_coeff(_col_ptrs(views), _sz(n_cols), ctypes.c_uint32(n.bit_length() - 1)))
+    return cols
+
+
+def coeff_to_extended(cols, ext_k=2):
+    L = _lib.init()
+    cols = _fr(cols)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    out = np.zeros((n_cols, n << ext_k, 4), dtype=np.uint64)
+    check(L.vdb_coeff_to_extended(_col_ptrs([cols[i] for i in range(n_cols)]), _col_ptrs([out[i] for i in range(n_cols)]),
+                                  _sz(n_cols), ctypes.c_uint32(n.bit_length() - 1), ctypes.c_uint32(ext_k)))
+    return out
+
+
+# ---------------------------------------------------------------- Poseidon
+def poseidon_hash_many(msgs):
+    L = _lib.init()
+    msgs = _fr(msgs)
+    n, ln = msgs.shape[0], msgs.shape[1]
+    o = np.zeros((n, 4), dtype=np.uint64)
+    check(L.vdb_poseidon_hash_many(_p(msgs), _sz(n), _sz(ln), _p(o)))
+    return o
+
+
+def poseidon_merkle_root(vectors):
+    L = _lib.init()
+    vectors = _fr(vectors)
+    o = np.zeros(4, dtype=np.uint64)
+    check(L.vdb_poseidon_merkle_root(_p(vectors), _sz(vectors.shape[0]), _sz(vectors.shape[1]), _p(o)))
+    return o
+
+
+def poseidon_permute(states):
+    L = _lib.init()
+    s = np.array(states, dtype=np.uint64, copy=True)
+    check(L.vdb_poseidon_permute(_p(s), _sz(s.size // 12)))
+    return s
+
+
+# ---------------------------------------------------------------- device buffers
+class DeviceBuffer:
+    """A raw HBM allocation owned by the library's context."""
+
+    def __init__(self, nbytes):
+        self.L = _lib.init()
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(self.L.vdb_malloc(ctypes.byref(p), _sz(self.nbytes)))
+        self.ptr = p
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        check(self.L.vdb_memcpy_h2d(ctypes.c_void_p(self.ptr.value + offset), _p(arr), _sz(arr.nbytes)))
+
+    def download(self, shape, dtype=np.uint64, offset=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        check(self.L.vdb_memcpy_d2h(_p(out), ctypes.c_void_p(self.ptr.value + offset), _sz(out.nbytes)))
+        return out
+
+    def at(self, offset):
+        return ctypes.c_void_p(self.ptr.value + int(offset))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            check(self.L.vdb_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    check(_lib.init().vdb_sync())
+
+
+def timer_start():
+    check(_lib.init().vdb_timer_start())
+
+
+def timer_stop():
+    ms = ctypes.c_float(0)
+    check(_lib.init().vdb_timer_stop(ctypes.byref(ms)))
+    return ms.value

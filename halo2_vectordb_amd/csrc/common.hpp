@@ -1,0 +1,82 @@
+// Shared host-side plumbing of libvdb_hip: process-wide context (one GPU per process), error
+// reporting across the C ABI, scratch allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vdb.h"
+#include "field.hpp"
+
+namespace vdb {
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int cu_count = 256;
+  // twiddle tables keyed by (log_n, first limb words of omega): tw[e] = omega^e, e < n
+  struct TwKey {
+    uint32_t log_n;
+    u256 omega;
+    bool operator<(const TwKey& o) const {
+      if (log_n != o.log_n) return log_n < o.log_n;
+      return memcmp(omega.w, o.omega.w, 32) < 0;
+    }
+  };
+  std::map<TwKey, u256*> twiddles;
+  // grow-only scratch buffers
+  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[4] = {0, 0, 0, 0};
+};
+
+Context& ctx();
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+// returns nullptr (and sets error) on failure
+void* scratch_get(int slot, size_t bytes);
+
+#define VDB_HIP(expr)                                                      \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) return vdb::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define VDB_REQUIRE_INIT()                                            \
+  do {                                                                \
+    if (!vdb::ctx().ready) {                                          \
+      vdb::set_error("vdb_init() has not been called (or failed)"); \
+      return VDB_ERR_NOT_INIT;                                        \
+    }                                                                 \
+  } while (0)
+
+#define VDB_ARG(cond, msg)       \
+  do {                           \
+    if (!(cond)) {               \
+      vdb::set_error("%s", msg); \
+      return VDB_ERR_ARG;        \
+    }                            \
+  } while (0)
+
+#define VDB_LAUNCH_CHECK() VDB_HIP(hipGetLastError())
+
+static inline const u256* as_u256(const vdb_fr* p) { return reinterpret_cast<const u256*>(p); }
+static inline u256* as_u256(vdb_fr* p) { return reinterpret_cast<u256*>(p); }
+
+// Fr domain constants computed on the host with the same field code
+u256 host_root_of_unity(uint32_t k);  // ROOT_OF_UNITY^(2^(28-k)), Montgomery
+u256 host_zeta();                     // halo2curves bn256 Fr::ZETA, Montgomery
+u256 host_fr_from_u64(uint64_t v);
+
+// internal device-level entry points shared between translation units (all on ctx().stream)
+int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
+            bool coset_in, size_t in_len);
+
+}  // namespace vdb

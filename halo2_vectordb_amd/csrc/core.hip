@@ -1,0 +1,288 @@
+// libvdb_hip core: lifecycle (b0), device memory helpers, elementwise Fr kernels, batch inversion,
+// and the Montgomery-multiplication micro-benchmark used to calibrate the integer-ALU roofline.
+#include "common.hpp"
+
+namespace vdb {
+
+static Context g_ctx;
+static thread_local char g_err[512] = "";
+
+Context& ctx() { return g_ctx; }
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+  return e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP;
+}
+void* scratch_get(int slot, size_t bytes) {
+  Context& c = ctx();
+  if (c.scratch_bytes[slot] >= bytes) return c.scratch[slot];
+  if (c.scratch[slot]) (void)hipFree(c.scratch[slot]);
+  c.scratch[slot] = nullptr;
+  c.scratch_bytes[slot] = 0;
+  size_t want = bytes + bytes / 8;
+  hipError_t e = hipMalloc(&c.scratch[slot], want);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipMalloc(scratch)", __FILE__, __LINE__);
+    return nullptr;
+  }
+  c.scratch_bytes[slot] = want;
+  return c.scratch[slot];
+}
+
+u256 host_fr_from_u64(uint64_t v) { return to_mont<Fr>(u256_from_u64(v)); }
+u256 host_root_of_unity(uint32_t k) {
+  // ROOT_OF_UNITY = 7^((r-1) >> 28)  (SURVEY App. D); then square down to order 2^k
+  u256 e = mod_p<Fr>(), one = u256_from_u64(1), t;
+  u256_sub(t, e, one);
+  e = u256_shr(t, 28);
+  u256 w = mont_pow<Fr>(host_fr_from_u64(7), e);
+  for (uint32_t i = k; i < 28; i++) w = fr_mul(w, w);
+  return w;
+}
+u256 host_zeta() {
+  // halo2curves bn256 Fr::ZETA = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+  u256 z;
+  const uint32_t w[8] = {0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du, 0, 0};
+  for (int i = 0; i < 8; i++) z.w[i] = w[i];
+  return to_mont<Fr>(z);
+}
+
+// ------------------------------------------------------------------ kernels
+enum { EW_MUL = 0, EW_ADD = 1, EW_SUB = 2, EW_TO_MONT = 3, EW_FROM_MONT = 4 };
+template <int OP>
+__global__ __launch_bounds__(256) void k_elementwise(const u256* __restrict__ a, const u256* __restrict__ b, u256* __restrict__ o, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    u256 x = ld256(a + i), r;
+    if (OP == EW_MUL) r = fr_mul(x, ld256(b + i));
+    else if (OP == EW_ADD) r = fr_add(x, ld256(b + i));
+    else if (OP == EW_SUB) r = fr_sub(x, ld256(b + i));
+    else if (OP == EW_TO_MONT) r = to_mont<Fr>(x);
+    else r = from_mont<Fr>(x);
+    st256(o + i, r);
+  }
+}
+
+// Batch inversion: each thread inverts a run of CH elements with Montgomery's trick (one Fermat
+// inversion per run).  Zero entries are skipped (0 -> 0) as halo2's BatchInvert does.
+#define BINV_CH 32
+__global__ __launch_bounds__(256) void k_batch_invert(const u256* __restrict__ in, u256* __restrict__ out, size_t n) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t lo = t * BINV_CH;
+  if (lo >= n) return;
+  size_t hi = lo + BINV_CH < n ? lo + BINV_CH : n;
+  u256 acc = mont_one<Fr>();
+  for (size_t i = lo; i < hi; i++) {
+    u256 x = ld256(in + i);
+    st256(out + i, acc);  // prefix product before i
+    if (!u256_is_zero(x)) acc = fr_mul(acc, x);
+  }
+  acc = mont_inv<Fr>(acc);
+  for (size_t i = hi; i-- > lo;) {
+    u256 x = ld256(in + i);
+    u256 pre = ld256(out + i);
+    if (u256_is_zero(x)) {
+      st256(out + i, x);
+    } else {
+      st256(out + i, fr_mul(acc, pre));
+      acc = fr_mul(acc, x);
+    }
+  }
+}
+
+// 4 independent dependency chains per thread so the measurement is throughput-, not latency-bound
+__global__ __launch_bounds__(256) void k_bench_mul(u256* __restrict__ sink, size_t iters) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u256 a = to_mont<Fr>(u256_from_u64(t * 2654435761ull + 12345)), b = fr_add(a, mont_one<Fr>());
+  u256 c = fr_add(b, mont_one<Fr>()), d = fr_add(c, mont_one<Fr>());
+  for (size_t i = 0; i < iters; i++) {
+    a = fr_mul(a, b);
+    b = fr_mul(b, c);
+    c = fr_mul(c, d);
+    d = fr_mul(d, a);
+  }
+  st256(sink + t, fr_add(fr_add(a, b), fr_add(c, d)));
+}
+
+static int grid_for(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  size_t cap = (size_t)ctx().cu_count * 8;
+  return (int)(g < cap ? (g ? g : 1) : cap);
+}
+
+template <int OP>
+static int elementwise_host(const vdb_fr* a, const vdb_fr* b, vdb_fr* out, size_t n) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(a && out && (b || OP >= EW_TO_MONT), "null pointer");
+  if (n == 0) return VDB_OK;
+  Context& c = ctx();
+  size_t bytes = n * sizeof(u256);
+  u256* da = (u256*)scratch_get(0, bytes);
+  u256* db = (u256*)scratch_get(1, bytes);
+  u256* dout = (u256*)scratch_get(2, bytes);
+  if (!da || !db || !dout) return VDB_ERR_OOM;
+  VDB_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c.stream));
+  if (b) VDB_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(k_elementwise<OP>, dim3(grid_for(n)), dim3(256), 0, c.stream, da, db, dout, n);
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c.stream));
+  VDB_HIP(hipStreamSynchronize(c.stream));
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+extern "C" {
+
+int vdb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* vdb_version(void) { return "halo2-vectordb_amd 0.1 (gfx950)"; }
+const char* vdb_last_error(void) { return g_err; }
+
+int vdb_init(int device) {
+  Context& c = ctx();
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    set_error("no HIP device visible (hipGetDeviceCount: %s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return VDB_ERR_NO_DEVICE;
+  }
+  VDB_ARG(device >= 0 && device < n, "device index out of range");
+  if (c.ready && c.device == device) return VDB_OK;
+  if (c.ready) vdb_shutdown();
+  VDB_HIP(hipSetDevice(device));
+  VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  VDB_HIP(hipEventCreate(&c.ev0));
+  VDB_HIP(hipEventCreate(&c.ev1));
+  hipDeviceProp_t prop;
+  VDB_HIP(hipGetDeviceProperties(&prop, device));
+  c.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c.device = device;
+  c.ready = true;
+  return VDB_OK;
+}
+void vdb_shutdown(void) {
+  Context& c = ctx();
+  if (!c.ready) return;
+  (void)hipStreamSynchronize(c.stream);
+  for (auto& kv : c.twiddles) (void)hipFree(kv.second);
+  c.twiddles.clear();
+  for (int i = 0; i < 4; i++) {
+    if (c.scratch[i]) (void)hipFree(c.scratch[i]);
+    c.scratch[i] = nullptr;
+    c.scratch_bytes[i] = 0;
+  }
+  (void)hipEventDestroy(c.ev0);
+  (void)hipEventDestroy(c.ev1);
+  (void)hipStreamDestroy(c.stream);
+  c.ready = false;
+}
+int vdb_malloc(void** dptr, size_t bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(dptr, "null pointer");
+  VDB_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  return VDB_OK;
+}
+int vdb_free(void* dptr) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  VDB_HIP(hipFree(dptr));
+  return VDB_OK;
+}
+int vdb_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_memset_dev(void* dst, int value, size_t bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipMemsetAsync(dst, value, bytes, ctx().stream));
+  return VDB_OK;
+}
+int vdb_sync(void) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_timer_start(void) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+  return VDB_OK;
+}
+int vdb_timer_stop(float* ms) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(ms, "null pointer");
+  VDB_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+  VDB_HIP(hipEventSynchronize(ctx().ev1));
+  VDB_HIP(hipEventElapsedTime(ms, ctx().ev0, ctx().ev1));
+  return VDB_OK;
+}
+
+int vdb_fr_mul(const vdb_fr* a, const vdb_fr* b, vdb_fr* out, size_t n) { return elementwise_host<EW_MUL>(a, b, out, n); }
+int vdb_fr_add(const vdb_fr* a, const vdb_fr* b, vdb_fr* out, size_t n) { return elementwise_host<EW_ADD>(a, b, out, n); }
+int vdb_fr_sub(const vdb_fr* a, const vdb_fr* b, vdb_fr* out, size_t n) { return elementwise_host<EW_SUB>(a, b, out, n); }
+int vdb_fr_from_canonical(const vdb_fr* in, vdb_fr* out, size_t n) { return elementwise_host<EW_TO_MONT>(in, nullptr, out, n); }
+int vdb_fr_to_canonical(const vdb_fr* in, vdb_fr* out, size_t n) { return elementwise_host<EW_FROM_MONT>(in, nullptr, out, n); }
+
+int vdb_fr_batch_invert(const vdb_fr* in, vdb_fr* out, size_t n) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(in && out, "null pointer");
+  if (n == 0) return VDB_OK;
+  Context& c = ctx();
+  size_t bytes = n * sizeof(u256);
+  u256* da = (u256*)scratch_get(0, bytes);
+  u256* dout = (u256*)scratch_get(1, bytes);
+  if (!da || !dout) return VDB_ERR_OOM;
+  VDB_HIP(hipMemcpyAsync(da, in, bytes, hipMemcpyHostToDevice, c.stream));
+  size_t threads = (n + BINV_CH - 1) / BINV_CH;
+  hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, da, dout, n);
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c.stream));
+  VDB_HIP(hipStreamSynchronize(c.stream));
+  return VDB_OK;
+}
+
+int vdb_bench_fr_mul(size_t threads, size_t iters, double* mul_per_sec) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(mul_per_sec && threads >= 256 && threads % 256 == 0 && iters > 0, "threads must be a positive multiple of 256");
+  Context& c = ctx();
+  u256* sink = (u256*)scratch_get(0, threads * sizeof(u256));
+  if (!sink) return VDB_ERR_OOM;
+  hipLaunchKernelGGL(k_bench_mul, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, (size_t)8);  // warm-up
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipEventRecord(c.ev0, c.stream));
+  hipLaunchKernelGGL(k_bench_mul, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, iters);
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipEventRecord(c.ev1, c.stream));
+  VDB_HIP(hipEventSynchronize(c.ev1));
+  float ms = 0;
+  VDB_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+  *mul_per_sec = (double)threads * (double)iters * 4.0 / ((double)ms * 1e-3);
+  return VDB_OK;
+}
+
+int vdb_fr_root_of_unity(uint32_t k, vdb_fr* out) {
+  VDB_ARG(out && k <= 28, "k must be <= 28");
+  u256 w = host_root_of_unity(k);
+  memcpy(out, &w, 32);
+  return VDB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// BN254 prime-field arithmetic for gfx950 (and the host side of the same library).
+//
+// Representation: 8 x u32 little-endian limbs, Montgomery form with R = 2^256.  The byte layout is
+// identical to halo2curves' `Fr`/`Fq` ([u64; 4] little-endian, Montgomery), i.e. what the
+// reference's prover holds in memory behind `best_multiexp(&[Fr], &[G1Affine])` and `best_fft`
+// (reached from /root/reference/src/scaffold/mod.rs:296), so buffers cross the C ABI zero-copy.
+//
+// CDNA4 has no 64x64 multiplier: the inner product step is v_mad_u64_u32 (32x32+64 -> 64).  All
+// loops are fully unrolled so the 8-limb operands stay in VGPRs (one element = 8 VGPRs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HD __host__ __device__ __forceinline__
+
+namespace vdb {
+
+struct alignas(16) u256 {
+  uint32_t w[8];
+};
+
+struct FrParams {
+  // r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+  static constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t R1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+  static constexpr uint32_t INV = 0xefffffffu;  // -r^{-1} mod 2^32
+};
+struct FqParams {
+  // q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+  static constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t R1[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+  static constexpr uint32_t INV = 0xe4866389u;  // -q^{-1} mod 2^32
+};
+
+HD bool u256_is_zero(const u256& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.w[i];
+  return o == 0;
+}
+HD bool u256_eq(const u256& a, const u256& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.w[i] ^ b.w[i];
+  return o == 0;
+}
+// a >= b
+HD bool u256_geq(const u256& a, const u256& b) {
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t d = (uint64_t)a.w[i] - b.w[i] - borrow;
+    borrow = (d >> 32) & 1;
+  }
+  return borrow == 0;
+}
+// o = a + b, returns carry
+HD uint32_t u256_add(u256& o, const u256& a, const u256& b) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.w[i] + b.w[i];
+    o.w[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return (uint32_t)c;
+}
+// o = a - b, returns borrow
+HD uint32_t u256_sub(u256& o, const u256& a, const u256& b) {
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t d = (uint64_t)a.w[i] - b.w[i] - borrow;
+    o.w[i] = (uint32_t)d;
+    borrow = (d >> 32) & 1;
+  }
+  return (uint32_t)borrow;
+}
+HD u256 u256_zero() {
+  u256 z;
+#pragma unroll
+  for (int i = 0; i < 8; i++) z.w[i] = 0;
+  return z;
+}
+HD u256 u256_from_u64(uint64_t v) {
+  u256 z = u256_zero();
+  z.w[0] = (uint32_t)v;
+  z.w[1] = (uint32_t)(v >> 32);
+  return z;
+}
+// logical right shift by s in [0, 255]
+HD u256 u256_shr(const u256& a, unsigned s) {
+  u256 o;
+  unsigned ws = s >> 5, bs = s & 31;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    unsigned j = i + ws;
+    uint32_t lo = j < 8 ? a.w[j < 8 ? j : 0] : 0u;
+    uint32_t hi = j + 1 < 8 ? a.w[j + 1 < 8 ? j + 1 : 0] : 0u;
+    o.w[i] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
+  }
+  return o;
+}
+HD u256 u256_shl(const u256& a, unsigned s) {
+  u256 o;
+  unsigned ws = s >> 5, bs = s & 31;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int j = i - (int)ws;
+    uint32_t cur = j >= 0 ? a.w[j >= 0 ? j : 0] : 0u;
+    uint32_t prev = j - 1 >= 0 ? a.w[j - 1 >= 0 ? j - 1 : 0] : 0u;
+    o.w[i] = bs ? (cur << bs) | (prev >> (32 - bs)) : cur;
+  }
+  return o;
+}
+// keep the low `bits` bits
+HD u256 u256_low_bits(const u256& a, unsigned bits) {
+  u256 o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    unsigned lo = 32u * i;
+    o.w[i] = bits >= lo + 32 ? a.w[i] : (bits <= lo ? 0u : a.w[i] & ((1u << (bits - lo)) - 1u));
+  }
+  return o;
+}
+// bit length (0 for zero)
+HD unsigned u256_bits(const u256& a) {
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (a.w[i]) r = 32u * i + (32u - (unsigned)__builtin_clz(a.w[i]));
+  return r;
+}
+HD uint32_t u256_bit(const u256& a, unsigned i) { return (a.w[i >> 5] >> (i & 31)) & 1u; }
+// extract `len` (<= 32) bits starting at bit `pos`
+HD uint32_t u256_extract(const u256& a, unsigned pos, unsigned len) {
+  unsigned wi = pos >> 5, bi = pos & 31;
+  uint64_t v = wi < 8 ? a.w[wi] : 0u;
+  if (wi + 1 < 8) v |= (uint64_t)a.w[wi + 1] << 32;
+  v >>= bi;
+  return (uint32_t)(v & ((len >= 32) ? 0xffffffffull : ((1ull << len) - 1ull)));
+}
+
+template <class M>
+HD u256 mod_p() {
+  u256 p;
+#pragma unroll
+  for (int i = 0; i < 8; i++) p.w[i] = M::P[i];
+  return p;
+}
+
+// Montgomery product a*b*R^{-1} mod p, CIOS with the "no final carry word" shortcut that holds
+// because the top limb of p is < 2^31 (p < 2^254).
+template <class M>
+HD u256 mont_mul(const u256& a, const u256& b) {
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t A = (uint64_t)a.w[0] * b.w[i] + t[0];
+    uint32_t m = (uint32_t)A * M::INV;
+    uint64_t C = (uint64_t)m * M::P[0] + (uint32_t)A;
+    A >>= 32;
+    C >>= 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      A += (uint64_t)a.w[j] * b.w[i] + t[j];
+      C += (uint64_t)m * M::P[j] + (uint32_t)A;
+      t[j - 1] = (uint32_t)C;
+      A >>= 32;
+      C >>= 32;
+    }
+    t[7] = (uint32_t)(A + C);
+  }
+  u256 r, p = mod_p<M>(), s;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = t[i];
+  uint32_t borrow = u256_sub(s, r, p);
+  return borrow ? r : s;
+}
+template <class M>
+HD u256 mont_sqr(const u256& a) {
+  return mont_mul<M>(a, a);
+}
+template <class M>
+HD u256 mod_add(const u256& a, const u256& b) {
+  u256 r, s, p = mod_p<M>();
+  u256_add(r, a, b);  // no carry: a, b < p < 2^254
+  uint32_t borrow = u256_sub(s, r, p);
+  return borrow ? r : s;
+}
+template <class M>
+HD u256 mod_sub(const u256& a, const u256& b) {
+  u256 r, s, p = mod_p<M>();
+  uint32_t borrow = u256_sub(r, a, b);
+  u256_add(s, r, p);
+  return borrow ? s : r;
+}
+template <class M>
+HD u256 mod_neg(const u256& a) {
+  u256 r, p = mod_p<M>();
+  u256_sub(r, p, a);
+  return u256_is_zero(a) ? a : r;
+}
+template <class M>
+HD u256 mod_dbl(const u256& a) {
+  return mod_add<M>(a, a);
+}
+template <class M>
+HD u256 mont_one() {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = M::R1[i];
+  return r;
+}
+template <class M>
+HD u256 mont_r2() {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = M::R2[i];
+  return r;
+}
+template <class M>
+HD u256 to_mont(const u256& canonical) {
+  return mont_mul<M>(canonical, mont_r2<M>());
+}
+template <class M>
+HD u256 from_mont(const u256& a) {
+  u256 one = u256_from_u64(1);
+  return mont_mul<M>(a, one);
+}
+// a^e (e canonical integer), left-to-right; not constant time (nothing here is secret-dependent
+// beyond what the reference's own vartime code does)
+template <class M>
+HD u256 mont_pow(const u256& a, const u256& e) {
+  u256 acc = mont_one<M>();
+  int nb = (int)u256_bits(e);
+  for (int i = nb - 1; i >= 0; i--) {
+    acc = mont_sqr<M>(acc);
+    if (u256_bit(e, (unsigned)i)) acc = mont_mul<M>(acc, a);
+  }
+  return acc;
+}
+// Fermat inverse; 0 -> 0
+template <class M>
+HD u256 mont_inv(const u256& a) {
+  u256 e = mod_p<M>(), two = u256_from_u64(2), em2;
+  u256_sub(em2, e, two);
+  return mont_pow<M>(a, em2);
+}
+
+using Fr = FrParams;
+using Fq = FqParams;
+
+HD u256 fr_mul(const u256& a, const u256& b) { return mont_mul<Fr>(a, b); }
+HD u256 fr_add(const u256& a, const u256& b) { return mod_add<Fr>(a, b); }
+HD u256 fr_sub(const u256& a, const u256& b) { return mod_sub<Fr>(a, b); }
+HD u256 fr_neg(const u256& a) { return mod_neg<Fr>(a); }
+HD u256 fq_mul(const u256& a, const u256& b) { return mont_mul<Fq>(a, b); }
+HD u256 fq_sqr(const u256& a) { return mont_mul<Fq>(a, a); }
+HD u256 fq_add(const u256& a, const u256& b) { return mod_add<Fq>(a, b); }
+HD u256 fq_sub(const u256& a, const u256& b) { return mod_sub<Fq>(a, b); }
+HD u256 fq_neg(const u256& a) { return mod_neg<Fq>(a); }
+
+// 16-byte vector load/store of one element (two dwordx4 per lane)
+__device__ __forceinline__ u256 ld256(const u256* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  u256 r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st256(u256* p, const u256& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+  q[1] = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+}
+
+}  // namespace vdb

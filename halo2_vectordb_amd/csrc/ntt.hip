@@ -1,0 +1,393 @@
+// Batched radix-2 NTT over BN254 Fr for gfx950.
+//
+// Replaces halo2 `arithmetic::best_fft` and `EvaluationDomain::{lagrange_to_coeff, coeff_to_extended}`
+// (third-party halo2-axiom, reached from /root/reference/src/scaffold/mod.rs:296).
+// Semantics: X[i] = sum_j a[j] * omega^(i*j), natural order in and out.
+//
+// Structure (MI355X-first, not a port of the CPU recursion):
+//   n = m_0 * m_1 * ... * m_{L-1}, every m_l = 2^S_l <= 256.  Pass l performs, for every residue of
+//   the other digits, a size-m_l DFT along digit l inside LDS (decimation in frequency, 2 butterflies
+//   per thread per stage), multiplies by the inter-pass twiddle omega_{N_l}^(q*i) and writes back.
+//   A workgroup owns a tile of m_l x G elements (G*32 B contiguous = whole 128-B lines in HBM).
+//   The last pass reads contiguous rows and scatters to the digit-reversed natural-order position,
+//   G consecutive outputs per row group so stores are again whole lines.
+//   LDS holds the tile as two 16-byte planes with a one-element row pad: conflict-free ds_read_b128 /
+//   ds_write_b128 both along rows and along columns.
+// Roofline: 64 B/element algorithmic HBM traffic per transform; the kernel is integer-ALU bound
+// (one 254-bit Montgomery product per butterfly), see DESIGN.md.
+#include "common.hpp"
+
+namespace vdb {
+
+#define NTT_THREADS 256
+#define NTT_TILE 1024
+#define NTT_MAX_PASSES 4
+
+struct NttPass {
+  uint32_t log_n, S, log_inner, logG;
+  uint32_t nprev;                 // last pass: number of previous passes
+  uint32_t prevS[NTT_MAX_PASSES]; // their sizes (S_0 .. S_{L-2})
+  uint32_t first;                 // this is pass 0 (input staging rules apply)
+  uint32_t coset;                 // multiply input element e by zeta^(e mod 3)
+  uint32_t scale;                 // multiply output by n^{-1}
+  uint64_t in_len;                // elements >= in_len of the input column read as zero
+  uint64_t in_stride, out_stride; // column strides (elements)
+  u256 zeta1, zeta2, ninv;
+};
+
+__device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+__device__ __forceinline__ u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
+  uint4 a = lo[idx], b = hi[idx];
+  u256 r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t idx, const u256& v) {
+  lo[idx] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+  hi[idx] = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict__ in, u256* __restrict__ out,
+                                                         const u256* __restrict__ tw, NttPass p, uint32_t tiles_per_col) {
+  extern __shared__ uint4 smem[];
+  const uint32_t S = p.S, m = 1u << S, G = 1u << p.logG, T = m * G;
+  const uint32_t row = m + 1;
+  uint4* lo = smem;
+  uint4* hi = smem + G * row;
+  uint4* twlo = hi + G * row;
+  uint4* twhi = twlo + (m / 2 ? m / 2 : 1);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t col = blockIdx.x / tiles_per_col, tile = blockIdx.x % tiles_per_col;
+  const u256* cin = in + (size_t)col * p.in_stride;
+  u256* cout = out + (size_t)col * p.out_stride;
+
+  // tile geometry
+  uint64_t base;      // element index of (j=0, g=0)
+  uint64_t jstride;   // index step along j
+  uint64_t gstride;   // index step along g
+  uint32_t i0 = 0, q0_base = 0, rdig = 0, rest = 1;
+  if (!LAST) {
+    uint32_t tiles_inner = (1u << p.log_inner) >> p.logG;
+    uint32_t o = tile / tiles_inner;
+    i0 = (tile % tiles_inner) << p.logG;
+    base = ((uint64_t)o << (S + p.log_inner)) + i0;
+    jstride = 1ull << p.log_inner;
+    gstride = 1;
+  } else {
+    if (p.nprev == 0) {
+      base = 0;
+      jstride = 1;
+      gstride = 0;
+    } else {
+      rest = 1u << (p.log_n - S - p.prevS[0]);
+      q0_base = (tile / rest) << p.logG;
+      rdig = tile % rest;
+      base = ((uint64_t)q0_base * rest + rdig) << S;
+      jstride = 1;
+      gstride = (uint64_t)rest << S;
+    }
+  }
+
+  // stage twiddles omega_m^e = tw[e * n/m]
+  for (uint32_t e = tid; e < m / 2; e += NTT_THREADS) {
+    u256 w = ld256(tw + ((size_t)e << (p.log_n - S)));
+    lds_put(twlo, twhi, e, w);
+  }
+  // load tile
+  for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+    uint32_t j, g;
+    if (!LAST) {
+      g = e & (G - 1);
+      j = e >> p.logG;
+    } else {
+      j = e & (m - 1);
+      g = e >> S;
+    }
+    uint64_t idx = base + j * jstride + g * gstride;
+    u256 v;
+    if (p.first) {
+      if (idx < p.in_len) {
+        v = ld256(cin + idx);
+        if (p.coset) {
+          uint32_t r3 = (uint32_t)(idx % 3);
+          if (r3 == 1) v = fr_mul(v, p.zeta1);
+          else if (r3 == 2) v = fr_mul(v, p.zeta2);
+        }
+      } else {
+        v = u256_zero();
+      }
+    } else {
+      v = ld256(cin + idx);
+    }
+    lds_put(lo, hi, g * row + j, v);
+  }
+  __syncthreads();
+  // DIF stages: natural order in, bit-reversed order out
+  for (uint32_t s = 0; s < S; s++) {
+    uint32_t logh = S - 1 - s, h = 1u << logh;
+    for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
+      uint32_t g = b >> (S - 1), pj = b & ((m >> 1) - 1);
+      uint32_t r = pj & (h - 1), j0 = ((pj >> logh) << (logh + 1)) + r;
+      uint32_t a0 = g * row + j0, a1 = a0 + h;
+      u256 u = lds_get(lo, hi, a0), v = lds_get(lo, hi, a1);
+      u256 d = fr_sub(u, v);
+      if (h > 1) d = fr_mul(d, lds_get(twlo, twhi, r << s));
+      lds_put(lo, hi, a0, fr_add(u, v));
+      lds_put(lo, hi, a1, d);
+    }
+    __syncthreads();
+  }
+  // write out
+  for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+    uint32_t g = e & (G - 1), q = e >> p.logG;
+    u256 v = lds_get(lo, hi, g * row + bitrev_s(q, S));
+    if (!LAST) {
+      uint64_t i = (uint64_t)i0 + g;
+      uint64_t ex = ((uint64_t)q * i) << (p.log_n - S - p.log_inner);
+      if (ex) v = fr_mul(v, ld256(tw + ex));
+      st256(cout + base + (uint64_t)q * jstride + g, v);
+    } else {
+      uint64_t pos;
+      if (p.nprev == 0) {
+        pos = q;
+      } else {
+        pos = (uint64_t)q0_base + g;
+        uint32_t r = rdig;
+        uint32_t shift = 0;
+        for (uint32_t l = 0; l < p.nprev; l++) shift += p.prevS[l];
+        // peel digits q_{L-2} .. q_1 (least significant first)
+        for (int l = (int)p.nprev - 1; l >= 1; l--) {
+          shift -= p.prevS[l];
+          uint32_t ql = r & ((1u << p.prevS[l]) - 1);
+          r >>= p.prevS[l];
+          pos += (uint64_t)ql << shift;
+        }
+        pos += (uint64_t)q << (p.log_n - S);
+      }
+      if (p.scale) v = fr_mul(v, p.ninv);
+      st256(cout + pos, v);
+    }
+  }
+}
+
+// tw[e] = omega^e for e < n
+__global__ __launch_bounds__(256) void k_twiddles(u256* __restrict__ tw, u256 omega, uint64_t n, uint32_t chunk) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t lo = t * chunk;
+  if (lo >= n) return;
+  u256 w = mont_pow<Fr>(omega, u256_from_u64(lo));
+  for (uint32_t i = 0; i < chunk && lo + i < n; i++) {
+    st256(tw + lo + i, w);
+    w = fr_mul(w, omega);
+  }
+}
+
+static const u256* get_twiddles(uint32_t log_n, const u256& omega, int* err) {
+  Context& c = ctx();
+  Context::TwKey key{log_n, omega};
+  auto it = c.twiddles.find(key);
+  if (it != c.twiddles.end()) return it->second;
+  uint64_t n = 1ull << log_n;
+  u256* tw = nullptr;
+  hipError_t e = hipMalloc(&tw, n * sizeof(u256));
+  if (e != hipSuccess) {
+    *err = hip_fail(e, "hipMalloc(twiddles)", __FILE__, __LINE__);
+    return nullptr;
+  }
+  uint32_t chunk = 16;
+  uint64_t threads = (n + chunk - 1) / chunk;
+  hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, n, chunk);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    *err = hip_fail(e, "k_twiddles", __FILE__, __LINE__);
+    (void)hipFree(tw);
+    return nullptr;
+  }
+  c.twiddles[key] = tw;
+  return tw;
+}
+
+// Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
+// result goes to out (stride n) or back into data when out == nullptr.
+int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
+            bool coset_in, size_t in_len) {
+  Context& c = ctx();
+  if (n_cols == 0) return VDB_OK;
+  if (log_n > 26) {
+    set_error("ntt: log_n > 26 unsupported");
+    return VDB_ERR_ARG;
+  }
+  const uint64_t n = 1ull << log_n;
+  const uint64_t in_stride = in_len ? in_len : n;
+  if (!in_len) in_len = n;
+  u256* dst = out_or_null ? out_or_null : data;
+  if (!out_or_null && in_stride != n) {
+    set_error("ntt: in-place transform needs in_len == n");
+    return VDB_ERR_ARG;
+  }
+  int err = VDB_OK;
+  const u256* tw = get_twiddles(log_n, omega, &err);
+  if (!tw) return err;
+
+  // pass sizes
+  uint32_t L, S[NTT_MAX_PASSES];
+  if (log_n <= 10) {
+    L = 1;
+    S[0] = log_n;
+  } else {
+    L = (log_n + 7) / 8;
+    for (uint32_t l = 0; l < L; l++) S[l] = log_n / L + (l < log_n % L ? 1 : 0);
+  }
+  u256 ninv = mont_inv<Fr>(host_fr_from_u64(n));
+  u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
+
+  // column chunking bounds the scratch buffer (<= ~2 GiB)
+  size_t chunk_cols = n_cols;
+  u256* scratch = nullptr;
+  if (L > 1) {
+    size_t max_cols = ((size_t)2 << 30) / (n * sizeof(u256));
+    if (max_cols < 1) max_cols = 1;
+    if (chunk_cols > max_cols) chunk_cols = max_cols;
+    scratch = (u256*)scratch_get(3, chunk_cols * n * sizeof(u256));
+    if (!scratch) return VDB_ERR_OOM;
+  }
+  for (size_t c0 = 0; c0 < n_cols; c0 += chunk_cols) {
+    size_t nc = n_cols - c0 < chunk_cols ? n_cols - c0 : chunk_cols;
+    uint32_t done_bits = 0;
+    for (uint32_t l = 0; l < L; l++) {
+      NttPass p;
+      memset(&p, 0, sizeof(p));
+      p.log_n = log_n;
+      p.S = S[l];
+      p.log_inner = log_n - done_bits - S[l];
+      p.first = (l == 0);
+      p.coset = (l == 0 && coset_in);
+      p.in_len = in_len;
+      p.zeta1 = z1;
+      p.zeta2 = z2;
+      p.ninv = ninv;
+      bool last = (l == L - 1);
+      p.scale = last && scale_ninv;
+      const u256* src;
+      u256* out;
+      if (l == 0) {
+        src = data + c0 * in_stride;
+        p.in_stride = in_stride;
+      } else {
+        src = scratch;
+        p.in_stride = n;
+      }
+      if (last) {
+        out = dst + c0 * n;
+        p.out_stride = n;
+      } else {
+        out = scratch;
+        p.out_stride = n;
+      }
+      uint32_t m = 1u << S[l];
+      if (L == 1) {
+        p.logG = 0;
+        p.nprev = 0;
+      } else {
+        p.logG = 10 - S[l];
+        p.nprev = l;  // only read when last
+        for (uint32_t q = 0; q < l && q < NTT_MAX_PASSES; q++) p.prevS[q] = S[q];
+      }
+      uint32_t G = 1u << p.logG;
+      uint32_t tiles = (uint32_t)(n / ((uint64_t)m * G));
+      size_t lds = (size_t)(2 * G * (m + 1) + 2 * (m / 2 ? m / 2 : 1)) * sizeof(uint4);
+      dim3 grid((unsigned)(nc * tiles));
+      if (last) {
+        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+      } else {
+        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+      }
+      VDB_LAUNCH_CHECK();
+      done_bits += S[l];
+    }
+  }
+  return VDB_OK;
+}
+
+static int host_cols_roundtrip(vdb_fr* const* cols, size_t n_cols, size_t n, u256** dbuf, bool upload) {
+  Context& c = ctx();
+  size_t bytes = n * sizeof(u256);
+  if (upload) {
+    *dbuf = (u256*)scratch_get(0, n_cols * bytes);
+    if (!*dbuf) return VDB_ERR_OOM;
+    for (size_t i = 0; i < n_cols; i++) VDB_HIP(hipMemcpyAsync(*dbuf + i * n, cols[i], bytes, hipMemcpyHostToDevice, c.stream));
+  } else {
+    for (size_t i = 0; i < n_cols; i++) VDB_HIP(hipMemcpyAsync(cols[i], *dbuf + i * n, bytes, hipMemcpyDeviceToHost, c.stream));
+    VDB_HIP(hipStreamSynchronize(c.stream));
+  }
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+extern "C" {
+
+int vdb_ntt_batch_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t log_n, const vdb_fr* omega, int flags) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols_dev && omega, "null pointer");
+  u256 w;
+  memcpy(&w, omega, 32);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0);
+}
+int vdb_ntt_batch(vdb_fr* const* cols, size_t n_cols, uint32_t log_n, const vdb_fr* omega, int flags) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols && omega, "null pointer");
+  if (n_cols == 0) return VDB_OK;
+  u256* d = nullptr;
+  int rc = host_cols_roundtrip(cols, n_cols, (size_t)1 << log_n, &d, true);
+  if (rc) return rc;
+  rc = vdb_ntt_batch_dev(reinterpret_cast<vdb_fr*>(d), n_cols, log_n, omega, flags);
+  if (rc) return rc;
+  return host_cols_roundtrip(cols, n_cols, (size_t)1 << log_n, &d, false);
+}
+int vdb_lagrange_to_coeff_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols_dev && k <= 26, "bad argument");
+  u256 w = mont_inv<Fr>(host_root_of_unity(k));
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0);
+}
+int vdb_lagrange_to_coeff(vdb_fr* const* cols, size_t n_cols, uint32_t k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols, "null pointer");
+  if (n_cols == 0) return VDB_OK;
+  u256* d = nullptr;
+  int rc = host_cols_roundtrip(cols, n_cols, (size_t)1 << k, &d, true);
+  if (rc) return rc;
+  rc = vdb_lagrange_to_coeff_dev(reinterpret_cast<vdb_fr*>(d), n_cols, k);
+  if (rc) return rc;
+  return host_cols_roundtrip(cols, n_cols, (size_t)1 << k, &d, false);
+}
+int vdb_coeff_to_extended_dev(const vdb_fr* coeff_dev, vdb_fr* ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && ext_dev && k + ext_k <= 26, "bad argument");
+  u256 w = host_root_of_unity(k + ext_k);
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k);
+}
+int vdb_coeff_to_extended(const vdb_fr* const* coeff_cols, vdb_fr* const* ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_cols && ext_cols, "null pointer");
+  if (n_cols == 0) return VDB_OK;
+  Context& c = ctx();
+  size_t n = (size_t)1 << k, ne = (size_t)1 << (k + ext_k);
+  u256* din = (u256*)scratch_get(0, n_cols * n * sizeof(u256));
+  u256* dout = (u256*)scratch_get(1, n_cols * ne * sizeof(u256));
+  if (!din || !dout) return VDB_ERR_OOM;
+  for (size_t i = 0; i < n_cols; i++) VDB_HIP(hipMemcpyAsync(din + i * n, coeff_cols[i], n * sizeof(u256), hipMemcpyHostToDevice, c.stream));
+  int rc = vdb_coeff_to_extended_dev(reinterpret_cast<vdb_fr*>(din), reinterpret_cast<vdb_fr*>(dout), n_cols, k, ext_k);
+  if (rc) return rc;
+  for (size_t i = 0; i < n_cols; i++) VDB_HIP(hipMemcpyAsync(ext_cols[i], dout + i * ne, ne * sizeof(u256), hipMemcpyDeviceToHost, c.stream));
+  VDB_HIP(hipStreamSynchronize(c.stream));
+  return VDB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Poseidon (x^5, BN254 Fr, T=3, RATE=2) shared definitions: the optimized-schedule constant table
+// that lives in HBM and the device permutation used both by the hash-only kernels (b6) and by the
+// witness-trace kernels (b5).  Parameters as the reference's call sites use them:
+// T=3, RATE=2, R_F=8, R_P=57 (/root/reference/examples/merkle.rs:15-18, tests/vectordb/mod.rs:7-10).
+#pragma once
+#include "field.hpp"
+
+namespace vdb {
+
+constexpr int PSD_T = 3;
+constexpr int PSD_RATE = 2;
+constexpr int PSD_RF = 8;
+constexpr int PSD_RP = 57;
+constexpr int PSD_HALF = PSD_RF / 2;
+
+// optimized schedule of the PSE `poseidon` Spec (constants folded through the MDS, sparse partial rounds)
+struct PoseidonSpec {
+  u256 start[PSD_HALF + 1][PSD_T];  // start[0] = pre-constants added in the absorb step
+  u256 partial[PSD_RP];
+  u256 end[PSD_HALF - 1][PSD_T];
+  u256 mds[PSD_T][PSD_T];
+  u256 pre_sparse[PSD_T][PSD_T];
+  u256 sparse_row[PSD_RP][PSD_T];
+  u256 sparse_col[PSD_RP][PSD_T - 1];
+  u256 cap;  // initial state word 0: 2^64 (Montgomery)
+  u256 one;
+};
+
+// host: Grain-LFSR parameter generation + optimisation (poseidon_spec.cpp)
+void poseidon_build_spec(PoseidonSpec* out);
+// device-resident copy (created on first use)
+int poseidon_spec_dev(const PoseidonSpec** dev_out, const PoseidonSpec** host_out);
+
+__device__ __forceinline__ u256 psd_pow5(const u256& x) {
+  u256 x2 = fr_mul(x, x);
+  u256 x4 = fr_mul(x2, x2);
+  return fr_mul(x4, x);
+}
+__device__ __forceinline__ void psd_dense(u256 st[PSD_T], const u256 m[PSD_T][PSD_T]) {
+  u256 r[PSD_T];
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) {
+    u256 acc = fr_mul(m[i][0], st[0]);
+#pragma unroll
+    for (int j = 1; j < PSD_T; j++) acc = fr_add(acc, fr_mul(m[i][j], st[j]));
+    r[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st[i] = r[i];
+}
+// PoseidonChip::permutation value semantics: absorb n_in (<= RATE) inputs with the pre-constants and
+// the +1 padding marker, then the optimized rounds
+__device__ __forceinline__ void psd_permute_absorb(const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
+  st[0] = fr_add(st[0], sp->start[0][0]);
+#pragma unroll
+  for (int i = 0; i < PSD_RATE; i++) {
+    if (i < n_in) st[1 + i] = fr_add(fr_add(st[1 + i], in[i]), sp->start[0][1 + i]);
+    else if (i == n_in) st[1 + i] = fr_add(st[1 + i], fr_add(sp->start[0][1 + i], sp->one));
+    else st[1 + i] = fr_add(st[1 + i], sp->start[0][1 + i]);
+  }
+  for (int r = 1; r < PSD_HALF; r++) {
+#pragma unroll
+    for (int i = 0; i < PSD_T; i++) st[i] = fr_add(psd_pow5(st[i]), sp->start[r][i]);
+    psd_dense(st, sp->mds);
+  }
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st[i] = fr_add(psd_pow5(st[i]), sp->start[PSD_HALF][i]);
+  psd_dense(st, sp->pre_sparse);
+  for (int p = 0; p < PSD_RP; p++) {
+    st[0] = fr_add(psd_pow5(st[0]), sp->partial[p]);
+    u256 n0 = fr_mul(sp->sparse_row[p][0], st[0]);
+#pragma unroll
+    for (int j = 1; j < PSD_T; j++) n0 = fr_add(n0, fr_mul(sp->sparse_row[p][j], st[j]));
+#pragma unroll
+    for (int i = 1; i < PSD_T; i++) st[i] = fr_add(fr_mul(st[0], sp->sparse_col[p][i - 1]), st[i]);
+    st[0] = n0;
+  }
+  for (int r = 0; r < PSD_HALF - 1; r++) {
+#pragma unroll
+    for (int i = 0; i < PSD_T; i++) st[i] = fr_add(psd_pow5(st[i]), sp->end[r][i]);
+    psd_dense(st, sp->mds);
+  }
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st[i] = psd_pow5(st[i]);
+  psd_dense(st, sp->mds);
+}
+// sponge: clear(); update(msg[0..len)); squeeze()  (elements `stride` apart)
+__device__ __forceinline__ u256 psd_hash(const PoseidonSpec* __restrict__ sp, const u256* msg, size_t len, size_t stride) {
+  u256 st[PSD_T];
+  st[0] = sp->cap;
+  st[1] = u256_zero();
+  st[2] = u256_zero();
+  size_t off = 0;
+  int pad = 0;
+  while (off < len) {
+    int c = (len - off) < (size_t)PSD_RATE ? (int)(len - off) : PSD_RATE;
+    u256 in[PSD_RATE];
+    in[0] = ld256(msg + off * stride);
+    in[1] = c > 1 ? ld256(msg + (off + 1) * stride) : u256_zero();
+    pad = PSD_RATE - c;
+    psd_permute_absorb(sp, st, in, c);
+    off += (size_t)c;
+  }
+  if (pad == 0) psd_permute_absorb(sp, st, nullptr, 0);
+  return st[1];
+}
+
+}  // namespace vdb

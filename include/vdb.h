@@ -1,0 +1,103 @@
+/*
+ * vdb.h — C ABI of the MI355X-native proving hot path for halo2-vectordb circuits.
+ *
+ * This is the drop-in boundary.  The reference (Rust) has no FFI of its own: the seam
+ * is the set of upstream Rust functions its prover reaches through
+ *   /root/reference/src/scaffold/mod.rs:296  gen_snark_shplonk -> create_proof   (MSM, NTT)
+ *   /root/reference/src/scaffold/mod.rs:273  create_pk                            (MSM, NTT, keygen)
+ *   /root/reference/src/scaffold/mod.rs:378-396  closure + RangeCircuitBuilder::prover (witness, layout)
+ * A patched halo2-axiom / halo2-base (Cargo `[patch]`) forwards those calls here; INTEGRATION.md shows
+ * the Rust `extern "C"` stubs.  Each entry point below names the interface it replaces.
+ *
+ * Conventions
+ *  - vdb_fr  : BN254 scalar, 4 x u64 little-endian limbs, MONTGOMERY form (R = 2^256) — the in-memory
+ *              layout of halo2curves::bn256::Fr, so `&[Fr]` crosses zero-copy.
+ *  - vdb_g1  : affine point {x, y}, each a Montgomery Fq; identity = (0, 0) as halo2curves.
+ *  - Every function returns 0 on success or a negative VDB_ERR_*; nothing aborts or throws across
+ *    the ABI.  vdb_last_error() returns a thread-local message for the last failure.
+ *  - Host pointers unless the name ends in _dev (then: device pointers in HBM of the bound GPU).
+ *  - One process binds one GPU (vdb_init(device)); calls are blocking and not re-entrant per process,
+ *    matching the reference's single prover thread.
+ */
+#ifndef VDB_H
+#define VDB_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } vdb_fr;
+typedef struct { uint64_t l[4]; } vdb_fq;
+typedef struct { vdb_fq x, y; } vdb_g1;
+typedef struct vdb_srs vdb_srs;
+
+enum {
+  VDB_OK = 0,
+  VDB_ERR_NOT_INIT = -1,
+  VDB_ERR_HIP = -2,       /* HIP runtime failure (message has the hipError string) */
+  VDB_ERR_ARG = -3,       /* bad argument (size mismatch, null pointer, unsupported parameter) */
+  VDB_ERR_OOM = -4,
+  VDB_ERR_DOMAIN = -5,    /* data-dependent failure the reference turns into a panic (div by zero, K >= N) */
+  VDB_ERR_NO_DEVICE = -6
+};
+
+/* ---- b0 lifecycle -------------------------------------------------------------------------- */
+/* Binds this process to HIP device `device` and creates streams/workspaces.  Fails loudly with
+ * VDB_ERR_NO_DEVICE when no GPU is visible: there is NO CPU fallback in this library. */
+int vdb_init(int device);
+void vdb_shutdown(void);
+const char *vdb_last_error(void);
+int vdb_device_count(void);
+const char *vdb_version(void);
+
+/* device memory helpers for HBM-resident pipelines */
+int vdb_malloc(void **dptr, size_t bytes);
+int vdb_free(void *dptr);
+int vdb_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int vdb_memset_dev(void *dst_dev, int value, size_t bytes);
+int vdb_sync(void);
+/* HIP-event timing on the library's own stream (bench.py: torch.cuda.Event does not see it) */
+int vdb_timer_start(void);
+int vdb_timer_stop(float *ms_out);
+
+/* ---- field helpers (tests / staging) -------------------------------------------------------- */
+int vdb_fr_from_canonical(const vdb_fr *in, vdb_fr *out, size_t n);
+int vdb_fr_to_canonical(const vdb_fr *in, vdb_fr *out, size_t n);
+int vdb_fr_mul(const vdb_fr *a, const vdb_fr *b, vdb_fr *out, size_t n);
+int vdb_fr_add(const vdb_fr *a, const vdb_fr *b, vdb_fr *out, size_t n);
+int vdb_fr_sub(const vdb_fr *a, const vdb_fr *b, vdb_fr *out, size_t n);
+/* replaces halo2 `BatchInvert` over `Assigned::Rational` denominators (poly::batch_invert_assigned);
+ * 0 maps to 0 */
+int vdb_fr_batch_invert(const vdb_fr *in, vdb_fr *out, size_t n);
+/* micro-benchmark: `iters` dependent Montgomery multiplications in each of `threads` GPU threads;
+ * reports Fr multiplications per second (kernel time only) */
+int vdb_bench_fr_mul(size_t threads, size_t iters, double *mul_per_sec);
+
+/* ---- b3 NTT: replaces halo2 arithmetic::best_fft / EvaluationDomain::{lagrange_to_coeff,
+ *      coeff_to_extended} (reached from src/scaffold/mod.rs:296) ------------------------------ */
+#define VDB_NTT_INVERSE_SCALE 1 /* multiply the result by n^{-1} (EvaluationDomain::ifft) */
+/* In place on each column; natural order in, natural order out; X[i] = sum_j a[j] omega^(ij). */
+int vdb_ntt_batch(vdb_fr *const *cols, size_t n_cols, uint32_t log_n, const vdb_fr *omega, int flags);
+/* contiguous device buffer of n_cols columns of 2^log_n elements */
+int vdb_ntt_batch_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t log_n, const vdb_fr *omega, int flags);
+/* lagrange_to_coeff for the 2^k domain (omega = ROOT_OF_UNITY^(2^(28-k))) */
+int vdb_lagrange_to_coeff(vdb_fr *const *cols, size_t n_cols, uint32_t k);
+int vdb_lagrange_to_coeff_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t k);
+/* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
+int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
+int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);
+int vdb_fr_root_of_unity(uint32_t k, vdb_fr *out);
+
+/* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,
+ *      R_P=57 as examples/merkle.rs:15-18; call sites src/gadget/vectordb.rs:180-182, 213-215) --- */
+int vdb_poseidon_hash_many(const vdb_fr *inputs, size_t n_msgs, size_t msg_len, vdb_fr *digests);
+int vdb_poseidon_merkle_root(const vdb_fr *vectors, size_t n, size_t dim, vdb_fr *root);
+int vdb_poseidon_permute(vdb_fr *states /* n x 3 */, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""GPU parity (through the C ABI) of the field helpers, the NTT family and Poseidon against the CPU
+oracle on the same seeded inputs.  Bit-exact: integer arithmetic."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init()
+    return a
+
+
+def test_native_library_is_loaded(api):
+    from halo2_vectordb_amd import _lib
+    assert _lib.load().vdb_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libvdb_hip.so" in maps
+
+
+def test_field_ops(api, O):
+    rng = np.random.default_rng(21)
+    a, b = O.random_fr(rng, 5000), O.random_fr(rng, 5000)
+    edge = O.fr_from_ints([0, 1, R - 1, R - 2, 1 << 48, R - (1 << 97), 1 << 253, 2])
+    a[:8], b[:8] = edge, edge[::-1]
+    assert np.array_equal(api.fr_mul(a, b), O.fr_mul(a, b))
+    assert np.array_equal(api.fr_add(a, b), O.fr_add(a, b))
+    assert np.array_equal(api.fr_sub(a, b), O.fr_sub(a, b))
+    assert np.array_equal(api.fr_to_canonical(a), O.fr_to_canonical(a))
+    can = O.fr_to_canonical(a)
+    assert np.array_equal(api.fr_from_canonical(can), a)
+    assert np.array_equal(api.fr_mul(a[:0], b[:0]), a[:0])  # empty input
+
+
+def test_batch_invert(api, O):
+    rng = np.random.default_rng(22)
+    a = O.random_fr(rng, 1000)
+    a[[0, 5, 31, 32, 999]] = 0
+    got = api.fr_batch_invert(a)
+    assert np.array_equal(got, O.fr_inv(a))  # oracle maps 0 -> 0 as well
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 5, 8, 10, 11, 12, 14, 16, 17])
+def test_ntt_forward(api, O, k):
+    rng = np.random.default_rng(30 + k)
+    n_cols = 3 if k <= 14 else 2
+    cols = O.random_fr(rng, n_cols * (1 << k)).reshape(n_cols, 1 << k, 4)
+    w = O.root_of_unity(k)
+    assert np.array_equal(api.root_of_unity(k), w)
+    got = api.ntt_batch(cols, w)
+    want = O.ntt_batch(cols, w, threads=4)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [3, 10, 13, 16])
+def test_lagrange_to_coeff_and_extended(api, O, k):
+    rng = np.random.default_rng(50 + k)
+    cols = O.random_fr(rng, 2 << k).reshape(2, 1 << k, 4)
+    want_c, want_e = O.lde_batch(cols, ext=2, threads=4)
+    got_c = api.lagrange_to_coeff(cols)
+    assert np.array_equal(got_c, want_c)
+    got_e = api.coeff_to_extended(got_c, 2)
+    assert np.array_equal(got_e, want_e)
+
+
+def test_ntt_roundtrip_full_size(api, O):
+    # size-independent property at the bench size (k=16 -> extended 2^18): iNTT(NTT(x)) == x
+    rng = np.random.default_rng(60)
+    k = 18
+    cols = O.random_fr(rng, 1 << k).reshape(1, 1 << k, 4)
+    w = O.root_of_unity(k)
+    winv = O.fr_inv(w.reshape(1, 4))[0]
+    f = api.ntt_batch(cols, w)
+    back = api.ntt_batch(f, winv, api.NTT_INVERSE_SCALE)
+    assert np.array_equal(back, cols)
+    # linearity spot check against the oracle on a single output coefficient set
+    assert np.array_equal(f[0, :4], O.ntt(cols[0], w)[:4])
+
+
+def test_poseidon(api, O):
+    rng = np.random.default_rng(70)
+    st = O.fr_from_ints([0, 1, 2]).reshape(1, 3, 4)
+    kat = [0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A,
+           0x0FCA49B798923AB0239DE1C9E7A4A9A2210312B6A2F616D18B5A87F9B628AE29,
+           0x0E7AE82E40091E63CBD4F16A6D16310B3729D4B6E138FCF54110E2867045A30C]
+    assert O.fr_to_ints(api.poseidon_permute(st).reshape(3, 4)) == kat
+    for ln in (0, 1, 2, 3, 7, 128):
+        msgs = O.random_fr(rng, 40 * max(ln, 1)).reshape(40, max(ln, 1), 4)[:, :ln]
+        assert np.array_equal(api.poseidon_hash_many(msgs), O.poseidon_hash_many(msgs))
+    for n, dim in ((1, 3), (2, 4), (3, 5), (37, 16), (64, 128)):
+        v = O.random_fr(rng, n * dim).reshape(n, dim, 4)
+        assert np.array_equal(api.poseidon_merkle_root(v), O.poseidon_merkle_root(v))
+
+
+def test_fr_mul_throughput_report(api):
+    rate = api.bench_fr_mul()
+    print(f"\nFr Montgomery mul throughput: {rate / 1e9:.1f} G mul/s")
+    assert rate > 1e9

@@ -129,6 +129,58 @@ def coeff_to_extended(cols, ext_k=2):
     return out
 
 
+# ---------------------------------------------------------------- SRS / MSM
+class Srs:
+    """Device-resident KZG bases + fixed-base window tables (vdb_srs_load)."""
+
+    def __init__(self, k, g=None, g_lagrange=None):
+        self.L = _lib.init()
+        self.k = k
+        h = ctypes.c_void_p()
+        ga = np.ascontiguousarray(g, dtype=np.uint64) if g is not None else None
+        gl = np.ascontiguousarray(g_lagrange, dtype=np.uint64) if g_lagrange is not None else None
+        check(self.L.vdb_srs_load(ctypes.c_uint32(k), _p(ga) if ga is not None else None, _p(gl) if gl is not None else None, ctypes.byref(h)))
+        self.h = h
+
+    def info(self):
+        k, c, w = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        check(self.L.vdb_srs_info(self.h, ctypes.byref(k), ctypes.byref(c), ctypes.byref(w)))
+        return k.value, c.value, w.value
+
+    def free(self):
+        if self.h is not None:
+            self.L.vdb_srs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_batch(srs, cols, basis=1):
+    """cols: (n_cols, n, 4) Montgomery scalars (host) -> (n_cols, 8) affine points."""
+    cols = _fr(cols)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    out = np.zeros((n_cols, 8), dtype=np.uint64)
+    check(srs.L.vdb_msm_batch(srs.h, ctypes.c_int(basis), _col_ptrs([cols[i] for i in range(n_cols)]), _sz(n_cols), _sz(n), _p(out)))
+    return out
+
+
+def msm(srs, scalars, basis=1):
+    scalars = _fr(scalars)
+    out = np.zeros(8, dtype=np.uint64)
+    check(srs.L.vdb_msm(srs.h, ctypes.c_int(basis), _p(scalars), _sz(scalars.size // 4), _p(out)))
+    return out
+
+
+def msm_batch_dev(srs, dev_ptr, n_cols, n, basis=1):
+    out = np.zeros((n_cols, 8), dtype=np.uint64)
+    check(srs.L.vdb_msm_batch_dev(srs.h, ctypes.c_int(basis), dev_ptr, _sz(n_cols), _sz(n), _p(out)))
+    return out
+
+
 # ---------------------------------------------------------------- Poseidon
 def poseidon_hash_many(msgs):
     L = _lib.init()

@@ -1,0 +1,428 @@
+// Batched multi-scalar multiplication over BN254 G1 for gfx950.
+//
+// Replaces halo2 `arithmetic::best_multiexp` / `ParamsKZG::commit_lagrange` (third-party halo2-axiom,
+// reached from /root/reference/src/scaffold/mod.rs:296 and :273): one exact
+// group element per column, returned as canonical affine (identity = (0,0)).
+//
+// MI355X-first design (not the CPU's per-thread chunked Pippenger):
+//  * The bases are fixed per circuit size, so vdb_srs_load precomputes T[j][i] = 2^(c*j) * G_i for every
+//    c-bit window j (tens of MB in 288 GB of HBM, L2 / Infinity-Cache resident).  All windows of a column
+//    then share ONE bucket set: a signed digit d of window j of scalar i adds +-T[j][i] to bucket |d|.
+//    No per-window doubling chain, one bucket reduction per column.
+//  * Scalars are sign-folded (s > r/2 -> r - s with the point negated) so the many "negative" witness
+//    values become short; zero digits cost nothing.
+//  * k_msm_sort: one workgroup per column does a counting sort of the (digit -> table index) pairs
+//    entirely in LDS (histogram, scan, scatter) and cuts every bucket into tasks of <= LCAP points, which
+//    removes the skew of witness columns (e.g. ~10 % of all cells are the constant 1).
+//  * k_msm_accum: one thread per task, XYZZ accumulator in VGPRs, mixed additions from the table.
+//  * k_msm_reduce: one wavefront per column; each lane folds its slice of buckets with the running-sum
+//    trick, lanes are combined with wavefront shuffles, lane 0 normalises to affine.
+// Roofline: algorithmic HBM traffic is 32 B per scalar (+ bases once); the kernels are bound by 32-bit
+// integer multiply-add throughput (v_mad_u64_u32), see DESIGN.md.
+#include "common.hpp"
+#include "ec.hpp"
+
+struct vdb_srs {
+  uint32_t k;
+  size_t n;
+  uint32_t c, W, B;
+  vdb::Affine* table[2];  // [0] monomial, [1] lagrange; each W * n points
+};
+
+namespace vdb {
+
+#define MSM_SORT_THREADS 1024
+#define MSM_LCAP 32
+
+struct MsmTask {
+  uint32_t col, bucket, start, len;
+};
+
+// ---------------------------------------------------------------- table precompute
+__global__ __launch_bounds__(256) void k_srs_table(const Affine* __restrict__ bases, Affine* __restrict__ table, size_t n, uint32_t c, uint32_t W) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine p = ld_affine(bases + i);
+  for (uint32_t j = 0; j < W; j++) {
+    st_affine(table + (size_t)j * n + i, p);
+    if (j + 1 < W) {
+      XYZZ q = xyzz_double_affine(p);
+      for (uint32_t d = 1; d < c; d++) q = xyzz_double(q);
+      p = xyzz_to_affine(q);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- digit decomposition
+// canonical scalar -> (folded magnitude, sign)
+__device__ __forceinline__ bool fold_scalar(u256& s) {
+  // (r-1)/2
+  const uint32_t H[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+  u256 half;
+#pragma unroll
+  for (int i = 0; i < 8; i++) half.w[i] = H[i];
+  // s > half  <=>  !(half >= s)
+  if (!u256_geq(half, s)) {
+    u256 r = mod_p<Fr>(), t;
+    u256_sub(t, r, s);
+    s = t;
+    return true;
+  }
+  return false;
+}
+
+template <class F>
+__device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t c, uint32_t W, F&& f) {
+  u256 s = from_mont<Fr>(mont_scalar);
+  if (u256_is_zero(s)) return;
+  bool neg = fold_scalar(s);
+  uint32_t carry = 0;
+  const uint32_t half = 1u << (c - 1), full = 1u << c;
+  for (uint32_t j = 0; j < W; j++) {
+    uint32_t d = u256_extract(s, c * j, c) + carry;
+    bool dneg = false;
+    if (d > half) {
+      d = full - d;
+      dneg = true;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    if (d) f(j, d, neg != dneg);
+  }
+}
+
+// block-wide exclusive scan of one value per thread (blockDim.x = MSM_SORT_THREADS); returns the
+// exclusive prefix, *total gets the block sum
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(inc, o, 64);
+    if ((int)lane >= o) inc += t;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t ws = lane < (MSM_SORT_THREADS / 64) ? wave_sums[lane] : 0;
+    uint32_t winc = ws;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(winc, o, 64);
+      if ((int)lane >= o) winc += t;
+    }
+    if (lane < (MSM_SORT_THREADS / 64)) wave_sums[lane] = winc - ws;  // exclusive wave offsets
+    if (lane == (MSM_SORT_THREADS / 64) - 1) wave_sums[MSM_SORT_THREADS / 64] = winc;
+  }
+  __syncthreads();
+  uint32_t res = wave_sums[wave] + inc - v;
+  *total = wave_sums[MSM_SORT_THREADS / 64];
+  __syncthreads();
+  return res;
+}
+
+// One workgroup per column: counting sort of (bucket -> table index|sign) and task cutting.
+__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, size_t n, size_t table_n, uint32_t c, uint32_t W,
+                                                               uint32_t* __restrict__ entries, size_t ent_cap,
+                                                               uint32_t* __restrict__ task_off, MsmTask* __restrict__ tasks,
+                                                               uint32_t* __restrict__ counters /* [0]=tasks, [1]=overflow */, uint32_t task_cap) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t B = 1u << (c - 1);
+  uint32_t* hist = sh;            // B
+  uint32_t* cursor = sh + B;      // B
+  uint32_t* wave_sums = sh + 2 * B;  // 18
+  __shared__ uint32_t s_base;
+  const uint32_t col = blockIdx.x, tid = threadIdx.x;
+  const u256* sc = scalars + (size_t)col * n;
+  for (uint32_t b = tid; b < B; b += MSM_SORT_THREADS) hist[b] = 0;
+  __syncthreads();
+  for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
+    for_each_digit(ld256(sc + i), c, W, [&](uint32_t, uint32_t d, bool) { atomicAdd(&hist[d - 1], 1u); });
+  }
+  __syncthreads();
+  // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
+  const uint32_t ipt = (B + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS;
+  uint32_t cnt_local = 0, task_local = 0;
+  for (uint32_t q = 0; q < ipt; q++) {
+    uint32_t b = tid * ipt + q;
+    if (b < B) {
+      cnt_local += hist[b];
+      task_local += (hist[b] + MSM_LCAP - 1) / MSM_LCAP;
+    }
+  }
+  uint32_t total_cnt, total_tasks;
+  uint32_t cnt_pre = block_exclusive_scan(cnt_local, wave_sums, &total_cnt);
+  uint32_t task_pre = block_exclusive_scan(task_local, wave_sums, &total_tasks);
+  if (tid == 0) {
+    uint32_t base = atomicAdd(&counters[0], total_tasks);
+    if (base + total_tasks > task_cap || total_cnt > ent_cap) {
+      atomicExch(&counters[1], 1u);
+      base = 0xffffffffu;
+    }
+    s_base = base;
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  uint32_t* toff = task_off + (size_t)col * (B + 1);
+  if (base == 0xffffffffu) {  // overflow: publish an empty column so later kernels stay in bounds
+    for (uint32_t b = tid; b <= B; b += MSM_SORT_THREADS) toff[b] = 0;
+    return;
+  }
+  for (uint32_t q = 0; q < ipt; q++) {
+    uint32_t b = tid * ipt + q;
+    if (b < B) {
+      uint32_t cnt = hist[b];
+      cursor[b] = cnt_pre;
+      toff[b] = base + task_pre;
+      uint32_t nt = (cnt + MSM_LCAP - 1) / MSM_LCAP;
+      for (uint32_t t = 0; t < nt; t++) {
+        MsmTask tk;
+        tk.col = col;
+        tk.bucket = b + 1;
+        tk.start = cnt_pre + t * MSM_LCAP;
+        uint32_t rem = cnt - t * MSM_LCAP;
+        tk.len = rem < MSM_LCAP ? rem : MSM_LCAP;
+        tasks[base + task_pre + t] = tk;
+      }
+      cnt_pre += cnt;
+      task_pre += nt;
+    }
+  }
+  if (tid == 0) toff[B] = base + total_tasks;
+  __syncthreads();
+  uint32_t* ent = entries + (size_t)col * ent_cap;
+  for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
+    for_each_digit(ld256(sc + i), c, W, [&](uint32_t j, uint32_t d, bool neg) {
+      uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
+      ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
+    });
+  }
+}
+
+// One thread per task: sum of <= LCAP table points
+__global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ table, const uint32_t* __restrict__ entries, size_t ent_cap,
+                                                   const MsmTask* __restrict__ tasks, const uint32_t* __restrict__ counters,
+                                                   XYZZ* __restrict__ partials, uint32_t task_cap) {
+  if (counters[1]) return;  // sort overflowed (never expected: capacities are worst-case)
+  const uint32_t total = counters[0] < task_cap ? counters[0] : task_cap;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    MsmTask tk = tasks[t];
+    const uint32_t* e = entries + (size_t)tk.col * ent_cap + tk.start;
+    XYZZ acc = xyzz_identity();
+    for (uint32_t q = 0; q < tk.len; q++) {
+      uint32_t v = e[q];
+      Affine p = ld_affine(table + (v & 0x7fffffffu));
+      xyzz_add_mixed(acc, p, (v >> 31) != 0);
+    }
+    st_xyzz(partials + t, acc);
+  }
+}
+
+__device__ __forceinline__ u256 shfl_u256(const u256& v, int src) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = (uint32_t)__shfl((int)v.w[i], src, 64);
+  return r;
+}
+__device__ __forceinline__ XYZZ shfl_xyzz(const XYZZ& p, int src) {
+  XYZZ r;
+  r.x = shfl_u256(p.x, src);
+  r.y = shfl_u256(p.y, src);
+  r.zz = shfl_u256(p.zz, src);
+  r.zzz = shfl_u256(p.zzz, src);
+  return r;
+}
+
+// One wavefront per column: result = sum_b b * B_b with B_b = sum of the partials of bucket b.
+__global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ partials, const uint32_t* __restrict__ task_off, uint32_t c,
+                                                   const uint32_t* __restrict__ counters, Affine* __restrict__ out) {
+  if (counters[1]) return;
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t col = blockIdx.x, lane = threadIdx.x;
+  const uint32_t log_per = c - 1 >= 6 ? c - 7 : 0, per = 1u << log_per;
+  const uint32_t* toff = task_off + (size_t)col * (B + 1);
+  XYZZ running = xyzz_identity(), total = xyzz_identity();
+  const uint32_t lo = lane * per;  // bucket indices [lo, lo+per) <-> bucket ids lo+1 .. lo+per
+  if (lo < B) {
+    for (int b = (int)(lo + per) - 1; b >= (int)lo; b--) {
+      uint32_t t0 = toff[b], t1 = toff[b + 1];
+      for (uint32_t t = t0; t < t1; t++) {
+        XYZZ p = ld_xyzz(partials + t);
+        xyzz_add(running, p);
+      }
+      xyzz_add(total, running);
+    }
+  }
+  // total_L = sum (b - lo) * B_b over the lane's ids; running_L = sum B_b.
+  // result = sum_L total_L + per * sum_L L * running_L
+  // suffix scan of running over lanes: suf_L = sum_{L' >= L} running_L'
+  XYZZ suf = running;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    XYZZ other = shfl_xyzz(suf, (int)lane + o < 64 ? (int)lane + o : (int)lane);
+    if ((int)lane + o < 64) xyzz_add(suf, other);
+  }
+  // sum_{L>=1} suf_L = sum_L L * running_L
+  XYZZ t2 = lane >= 1 ? suf : xyzz_identity();
+  XYZZ t1 = total;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    XYZZ a = shfl_xyzz(t1, (int)lane + o < 64 ? (int)lane + o : (int)lane);
+    XYZZ b = shfl_xyzz(t2, (int)lane + o < 64 ? (int)lane + o : (int)lane);
+    if ((int)lane < o) {
+      xyzz_add(t1, a);
+      xyzz_add(t2, b);
+    }
+  }
+  if (lane == 0) {
+    for (uint32_t d = 0; d < log_per; d++) t2 = xyzz_double(t2);
+    xyzz_add(t1, t2);
+    st_affine(out + col, xyzz_to_affine(t1));
+  }
+}
+
+static uint32_t pick_window(uint32_t k) {
+  const char* env = getenv("VDB_MSM_C");
+  if (env) {
+    int v = atoi(env);
+    if (v >= 2 && v <= 16) return (uint32_t)v;
+  }
+  if (k <= 8) return 8;
+  if (k <= 12) return 11;
+  return 13;
+}
+
+// device-level batched MSM: scalars_dev = n_cols x n (contiguous), out_dev = n_cols affine points
+int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev) {
+  Context& cx = ctx();
+  if (n_cols == 0) return VDB_OK;
+  const Affine* table = srs->table[basis];
+  const uint32_t c = srs->c, W = srs->W, B = srs->B;
+  const size_t ent_cap = n * W;
+  const size_t task_cap_col = B + (ent_cap + MSM_LCAP - 1) / MSM_LCAP;
+  // batch so that the worst-case scratch stays below ~6 GiB
+  size_t per_col = ent_cap * 4 + task_cap_col * (sizeof(MsmTask) + sizeof(XYZZ)) + (B + 1) * 4;
+  size_t nb = ((size_t)6 << 30) / per_col;
+  if (nb < 1) nb = 1;
+  if (nb > n_cols) nb = n_cols;
+  if (nb > 1024) nb = 1024;
+  if (nb * task_cap_col > 0x7fffffffull) nb = 0x7fffffffull / task_cap_col;
+  uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 256);
+  if (!buf) return VDB_ERR_OOM;
+  uint32_t* entries = (uint32_t*)buf;
+  MsmTask* tasks = (MsmTask*)(buf + nb * ent_cap * 4);
+  XYZZ* partials = (XYZZ*)((uint8_t*)tasks + nb * task_cap_col * sizeof(MsmTask));
+  uint32_t* task_off = (uint32_t*)((uint8_t*)partials + nb * task_cap_col * sizeof(XYZZ));
+  uint32_t* counters = task_off + nb * (B + 1);
+  const uint32_t task_cap = (uint32_t)(nb * task_cap_col);
+  size_t lds = (2 * (size_t)B + 32) * sizeof(uint32_t);
+  for (size_t c0 = 0; c0 < n_cols; c0 += nb) {
+    size_t nc = n_cols - c0 < nb ? n_cols - c0 : nb;
+    VDB_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), cx.stream));
+    hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
+                       ent_cap, task_off, tasks, counters, task_cap);
+    VDB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, tasks, counters,
+                       partials, task_cap);
+    VDB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, out_dev + c0);
+    VDB_LAUNCH_CHECK();
+  }
+  uint32_t h_counters[2] = {0, 0};
+  VDB_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  if (h_counters[1]) {
+    set_error("msm: internal task buffer overflow");
+    return VDB_ERR_HIP;
+  }
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+extern "C" {
+
+int vdb_srs_load(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, vdb_srs** out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(out && (g || g_lagrange) && k >= 1 && k <= 24, "bad argument");
+  Context& cx = ctx();
+  vdb_srs* s = new vdb_srs();
+  s->k = k;
+  s->n = (size_t)1 << k;
+  s->c = pick_window(k);
+  s->W = (254 + s->c - 1) / s->c;
+  s->B = 1u << (s->c - 1);
+  s->table[0] = s->table[1] = nullptr;
+  if ((size_t)s->W * s->n > 0x7fffffffull) {
+    delete s;
+    set_error("srs: table index does not fit 31 bits");
+    return VDB_ERR_ARG;
+  }
+  const vdb_g1* src[2] = {g, g_lagrange};
+  for (int b = 0; b < 2; b++) {
+    if (!src[b]) continue;
+    Affine* bases = (Affine*)scratch_get(0, s->n * sizeof(Affine));
+    if (!bases) {
+      vdb_srs_free(s);
+      return VDB_ERR_OOM;
+    }
+    hipError_t e = hipMalloc(&s->table[b], (size_t)s->W * s->n * sizeof(Affine));
+    if (e != hipSuccess) {
+      vdb_srs_free(s);
+      return hip_fail(e, "hipMalloc(srs table)", __FILE__, __LINE__);
+    }
+    VDB_HIP(hipMemcpyAsync(bases, src[b], s->n * sizeof(Affine), hipMemcpyHostToDevice, cx.stream));
+    hipLaunchKernelGGL(k_srs_table, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, cx.stream, bases, s->table[b], s->n, s->c, s->W);
+    VDB_LAUNCH_CHECK();
+    VDB_HIP(hipStreamSynchronize(cx.stream));
+  }
+  *out = s;
+  return VDB_OK;
+}
+void vdb_srs_free(vdb_srs* s) {
+  if (!s) return;
+  for (int b = 0; b < 2; b++)
+    if (s->table[b]) (void)hipFree(s->table[b]);
+  delete s;
+}
+int vdb_srs_info(const vdb_srs* s, uint32_t* k, uint32_t* window_bits, uint32_t* windows) {
+  VDB_ARG(s, "null srs");
+  if (k) *k = s->k;
+  if (window_bits) *window_bits = s->c;
+  if (windows) *windows = s->W;
+  return VDB_OK;
+}
+
+int vdb_msm_batch_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, vdb_g1* out_host) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && scalars_dev && out_host && (basis == 0 || basis == 1), "bad argument");
+  VDB_ARG(srs->table[basis], "srs was loaded without this basis");
+  VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size (shorter columns are allowed)");
+  if (n_cols == 0) return VDB_OK;
+  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  if (!dout) return VDB_ERR_OOM;
+  int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout);
+  if (rc) return rc;
+  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_msm_batch(const vdb_srs* srs, int basis, const vdb_fr* const* cols, size_t n_cols, size_t n, vdb_g1* out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && cols && out, "null pointer");
+  if (n_cols == 0) return VDB_OK;
+  u256* d = (u256*)scratch_get(0, n_cols * n * sizeof(u256));
+  if (!d) return VDB_ERR_OOM;
+  for (size_t i = 0; i < n_cols; i++) VDB_HIP(hipMemcpyAsync(d + i * n, cols[i], n * sizeof(u256), hipMemcpyHostToDevice, ctx().stream));
+  return vdb_msm_batch_dev(srs, basis, reinterpret_cast<const vdb_fr*>(d), n_cols, n, out);
+}
+int vdb_msm(const vdb_srs* srs, int basis, const vdb_fr* scalars, size_t n, vdb_g1* out) {
+  const vdb_fr* cols[1] = {scalars};
+  return vdb_msm_batch(srs, basis, cols, 1, n, out);
+}
+
+}  // extern "C"

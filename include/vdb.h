@@ -76,6 +76,23 @@ int vdb_fr_batch_invert(const vdb_fr *in, vdb_fr *out, size_t n);
  * reports Fr multiplications per second (kernel time only) */
 int vdb_bench_fr_mul(size_t threads, size_t iters, double *mul_per_sec);
 
+/* ---- b1 SRS: replaces halo2 ParamsKZG::{get_g, g_lagrange} as consumed by commit / commit_lagrange;
+ *      the reference obtains the params with gen_srs(k) (src/scaffold/mod.rs:260) ------------------ */
+/* Uploads the bases (caller keeps ownership of the host arrays; either may be NULL) and precomputes
+ * the fixed-base window tables 2^(c*j) * G_i in HBM. */
+int vdb_srs_load(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, vdb_srs **out);
+void vdb_srs_free(vdb_srs *srs);
+int vdb_srs_info(const vdb_srs *srs, uint32_t *k, uint32_t *window_bits, uint32_t *windows);
+
+/* ---- b2 MSM: replaces halo2 arithmetic::best_multiexp(&[Fr], &[G1Affine]) -> G1 and
+ *      ParamsKZG::commit_lagrange / commit (reached from src/scaffold/mod.rs:296, :273).
+ *      basis: 0 = monomial (g), 1 = lagrange (g_lagrange).  Result: exact group element as canonical
+ *      affine, identity = (0,0).  n <= 2^k scalars use the first n bases. ------------------------- */
+int vdb_msm(const vdb_srs *srs, int basis, const vdb_fr *scalars, size_t n, vdb_g1 *out);
+int vdb_msm_batch(const vdb_srs *srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
+/* scalars_dev: contiguous n_cols x n in HBM; out_host: n_cols points */
+int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, vdb_g1 *out_host);
+
 /* ---- b3 NTT: replaces halo2 arithmetic::best_fft / EvaluationDomain::{lagrange_to_coeff,
  *      coeff_to_extended} (reached from src/scaffold/mod.rs:296) ------------------------------ */
 #define VDB_NTT_INVERSE_SCALE 1 /* multiply the result by n^{-1} (EvaluationDomain::ifft) */

@@ -181,6 +181,120 @@ def msm_batch_dev(srs, dev_ptr, n_cols, n, basis=1):
     return out
 
 
+# ---------------------------------------------------------------- fixed point + witness streams
+METRICS = dict(euclidean=0, cosine=1, manhattan=2)
+
+
+def quantize(x, P=48):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    o = np.zeros(x.shape + (4,), dtype=np.uint64)
+    check(_lib.load().vdb_fp_quantize(ctypes.c_uint32(P), _p(x), _p(o), _sz(x.size)))
+    return o
+
+
+def dequantize(a, P=48):
+    a = _fr(a)
+    o = np.zeros(a.shape[:-1], dtype=np.float64)
+    check(_lib.load().vdb_fp_dequantize(ctypes.c_uint32(P), _p(a), _p(o), _sz(a.size // 4)))
+    return o
+
+
+def _u64():
+    return ctypes.c_uint64(0)
+
+
+def wit_distance(metric, a, b, P=48, L=13, selectors=False):
+    """a, b: (n_pairs, dim, 4).  Returns dict(stream, lookup, selectors, result)."""
+    lib = _lib.init()
+    a, b = _fr(a), _fr(b)
+    n, dim = a.shape[0], a.shape[1]
+    cells, lk = _u64(), _u64()
+    check(lib.vdb_wit_distance_size(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _sz(n), _sz(dim), ctypes.byref(cells), ctypes.byref(lk)))
+    stream = np.zeros((cells.value, 4), dtype=np.uint64)
+    lookup = np.zeros((lk.value, 4), dtype=np.uint64)
+    sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
+    res = np.zeros((n, 4), dtype=np.uint64)
+    check(lib.vdb_wit_distance(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(a), _p(b), _sz(n), _sz(dim), _p(stream), _p(lookup),
+                               _p(sel) if selectors else None, _p(res)))
+    return dict(stream=stream, lookup=lookup, selectors=sel, result=res)
+
+
+def wit_nearest(metric, query, vectors, P=48, L=13, selectors=False):
+    lib = _lib.init()
+    query, vectors = _fr(query), _fr(vectors)
+    n, dim = vectors.shape[0], vectors.shape[1]
+    cells, lk = _u64(), _u64()
+    check(lib.vdb_wit_nearest_size(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _sz(n), _sz(dim), ctypes.byref(cells), ctypes.byref(lk)))
+    stream = np.zeros((cells.value, 4), dtype=np.uint64)
+    lookup = np.zeros((lk.value, 4), dtype=np.uint64)
+    sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
+    ind = np.zeros((n, 4), dtype=np.uint64)
+    res = np.zeros((dim, 4), dtype=np.uint64)
+    check(lib.vdb_wit_nearest(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(query), _p(vectors), _sz(n), _sz(dim), _p(stream), _p(lookup),
+                              _p(sel) if selectors else None, _p(ind), _p(res)))
+    return dict(stream=stream, lookup=lookup, selectors=sel, indicator=ind, result=res)
+
+
+def wit_kmeans(metric, vectors, K, I, P=48, L=13, zero_cached=False, selectors=False):
+    lib = _lib.init()
+    vectors = _fr(vectors)
+    n, dim = vectors.shape[0], vectors.shape[1]
+    cells, lk = _u64(), _u64()
+    check(lib.vdb_wit_kmeans_size(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _sz(n), _sz(dim), _sz(K), _sz(I), int(zero_cached),
+                                  ctypes.byref(cells), ctypes.byref(lk)))
+    stream = np.zeros((cells.value, 4), dtype=np.uint64)
+    lookup = np.zeros((lk.value, 4), dtype=np.uint64)
+    sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
+    cent = np.zeros((K, dim, 4), dtype=np.uint64)
+    ind = np.zeros((n, K, 4), dtype=np.uint64)
+    check(lib.vdb_wit_kmeans(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(vectors), _sz(n), _sz(dim), _sz(K), _sz(I), int(zero_cached),
+                             _p(stream), _p(lookup), _p(sel) if selectors else None, _p(cent), _p(ind)))
+    return dict(stream=stream, lookup=lookup, selectors=sel, centroids=cent, indicators=ind)
+
+
+def wit_merkle(vectors, zero_cached=False, selectors=False):
+    lib = _lib.init()
+    vectors = _fr(vectors)
+    n, dim = vectors.shape[0], vectors.shape[1]
+    cells = _u64()
+    check(lib.vdb_wit_merkle_size(_sz(n), _sz(dim), int(zero_cached), ctypes.byref(cells)))
+    stream = np.zeros((cells.value, 4), dtype=np.uint64)
+    sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
+    root = np.zeros(4, dtype=np.uint64)
+    check(lib.vdb_wit_merkle(_p(vectors), _sz(n), _sz(dim), int(zero_cached), _p(stream), _p(sel) if selectors else None, _p(root)))
+    return dict(stream=stream, selectors=sel, root=root)
+
+
+def layout_plan(selectors, k, minimum_rows=9):
+    lib = _lib.init()
+    selectors = np.ascontiguousarray(selectors, dtype=np.uint8)
+    nbp = _u64()
+    check(lib.vdb_layout_plan(_p(selectors), ctypes.c_uint64(selectors.size), ctypes.c_uint32(k), ctypes.c_uint32(minimum_rows), None, ctypes.c_uint64(0),
+                              ctypes.byref(nbp)))
+    bp = np.zeros(max(nbp.value, 1), dtype=np.uint64)
+    check(lib.vdb_layout_plan(_p(selectors), ctypes.c_uint64(selectors.size), ctypes.c_uint32(k), ctypes.c_uint32(minimum_rows), _p(bp),
+                              ctypes.c_uint64(bp.size), ctypes.byref(nbp)))
+    return bp[:nbp.value]
+
+
+def layout_columns(stream, break_points, k, lookup=None, minimum_rows=9):
+    lib = _lib.init()
+    stream = _fr(stream)
+    bp = np.ascontiguousarray(break_points, dtype=np.uint64)
+    cols = np.zeros((bp.size + 1, 1 << k, 4), dtype=np.uint64)
+    lcols = None
+    n_lc = 0
+    if lookup is not None and len(lookup):
+        lookup = _fr(lookup)
+        max_rows = (1 << k) - minimum_rows
+        n_lc = (lookup.shape[0] + max_rows - 1) // max_rows
+        lcols = np.zeros((n_lc, 1 << k, 4), dtype=np.uint64)
+    check(lib.vdb_layout_columns(_p(stream), ctypes.c_uint64(stream.shape[0]), _p(bp), ctypes.c_uint64(bp.size), _p(lookup) if lcols is not None else None,
+                                 ctypes.c_uint64(lookup.shape[0] if lcols is not None else 0), ctypes.c_uint32(k), ctypes.c_uint32(minimum_rows), _p(cols),
+                                 _p(lcols) if lcols is not None else None, ctypes.c_uint64(n_lc)))
+    return cols, lcols
+
+
 # ---------------------------------------------------------------- Poseidon
 def poseidon_hash_many(msgs):
     L = _lib.init()

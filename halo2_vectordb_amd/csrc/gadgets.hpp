@@ -1,0 +1,664 @@
+// Witness-stream generators for the reference's gadgets, written once as host+device code.
+//
+// What is emitted: exactly the sequence of cells the Rust gadgets push into halo2-base's
+// `Context.advice` (and `cells_to_lookup`), in the same order — SURVEY §8 a1-a28, b5:
+//   FixedPointChip   /root/reference/src/gadget/fixed_point.rs   (line refs at each function)
+//   DistanceChip     /root/reference/src/gadget/distance.rs
+//   VectorDBChip     /root/reference/src/gadget/vectordb.rs
+// on top of the halo2-base v0.3 GateChip/RangeChip cell templates ([UPSTREAM-RECALL]).
+//
+// GPU execution model.  Cell counts are data independent, so every sub-gadget sits at a static
+// offset of the stream.  A generator runs over a *window* [lo, hi) of absolute stream positions:
+// cells outside the window are not stored, and whole sub-gadgets that lie outside are skipped
+// through a value-only fast path (`skip()`), using the size table `Sizes` that the host obtains by
+// running this same code in counting mode.  Kernels give each wavefront one window of 64 different
+// instances, so all lanes follow the same control flow (no divergence) while a long sequential
+// gadget (e.g. qsqrt, ~20k cells) is cut into many windows that run concurrently.
+//
+// Values are Montgomery Fr (u256) throughout, the byte layout the prover consumes.
+#pragma once
+#include "field.hpp"
+
+// mid-level generators are real functions on the device: the call tree is deep (qsqrt -> qlog2 -> qmul
+// -> signed_div_scale -> qabs -> is_neg -> range checks) and full inlining would explode code size
+#define HDN __host__ __device__ __noinline__
+
+namespace vdb {
+
+struct Sizes {  // [0] advice cells, [1] lookup cells
+  uint32_t is_neg[2], qabs[2], sds[2], qmul[2], qdiv[2], qmin[2], cpow2[2], poly13[2], poly15[2], qlog2[2], qexp2[2], qlog[2], qexp[2],
+      qsqrt[2], sfi254[2];
+};
+
+// constants of one FixedPointChip<P> + RangeChip(L) instance, resident in HBM
+struct FpTables {
+  uint32_t P, L;
+  u256 pow2[254];        // 2^i
+  u256 one;
+  u256 scale;            // 2^P
+  u256 exp2_poly[13], log_poly[15];  // fixed_point.rs:138-187, quantized
+  u256 c_half, c_ln2, c_log2e, c_one_q;
+  u256 small[260];       // i
+  u256 small_inv[260];   // 1/i (i >= 1)
+  const u256* limb_tab;  // Montgomery form of 0 .. 2^L - 1 (device pointer)
+  Sizes sz;
+};
+
+struct WCtx {
+  u256* adv;          // advice stream base (absolute indexing)
+  uint8_t* sel;       // optional gate-start bits (keygen run), may be null
+  u256* lk;           // lookup stream base
+  uint64_t pos, lpos; // absolute positions of the next advice / lookup cell
+  uint64_t lo, hi;    // emit window over advice positions
+  bool count_only;    // host sizing run: count cells, store nothing, never skip
+  int err;
+  const FpTables* T;
+
+  HD bool in_window(uint64_t p) const { return p >= lo && p < hi; }
+  HD void push(const u256& v, bool gate) {
+    if (!count_only && in_window(pos)) {
+      adv[pos] = v;
+      if (sel) sel[pos] = gate ? 1 : 0;
+    }
+    pos++;
+  }
+  // a lookup cell belongs to the window that owns the advice cell pushed just before it
+  HD void lookup(const u256& v) {
+    if (!count_only && pos > 0 && in_window(pos - 1)) lk[lpos] = v;
+    lpos++;
+  }
+  // true when a sub-gadget of `cells` advice cells starting here cannot touch the window
+  HD bool skip(uint32_t cells) const { return !count_only && (pos + cells <= lo || pos > hi); }
+  HD void advance(const uint32_t sz[2]) {
+    pos += sz[0];
+    lpos += sz[1];
+  }
+};
+
+struct Gadgets {
+  WCtx& c;
+  const FpTables& T;
+  HD Gadgets(WCtx& ctx) : c(ctx), T(*ctx.T) {}
+
+  HD u256 zero() const { return u256_zero(); }
+  HD u256 small(uint32_t v) const { return T.small[v < 260 ? v : 0]; }
+  // Montgomery form of a small canonical integer (< 2^L) via the limb table
+  HD u256 limb_mont(uint32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return T.limb_tab[v];
+#else
+    (void)v;
+    return u256_zero();  // host runs only count the cells
+#endif
+  }
+  HD u256 inv_or_one(const u256& x) const {
+    if (u256_is_zero(x)) return T.one;
+    return mont_inv<Fr>(x);
+  }
+
+  // ================================================================ GateChip templates
+  HD u256 g_add(const u256& a, const u256& b) {  // [a, b, 1, out]
+    u256 o = fr_add(a, b);
+    c.push(a, true); c.push(b, false); c.push(T.one, false); c.push(o, false);
+    return o;
+  }
+  HD u256 g_sub(const u256& a, const u256& b) {  // [out, b, 1, a]
+    u256 o = fr_sub(a, b);
+    c.push(o, true); c.push(b, false); c.push(T.one, false); c.push(a, false);
+    return o;
+  }
+  HD u256 g_neg(const u256& a) {  // [a, out, 1, 0]
+    u256 o = fr_neg(a);
+    c.push(a, true); c.push(o, false); c.push(T.one, false); c.push(zero(), false);
+    return o;
+  }
+  HD u256 g_mul(const u256& a, const u256& b) {  // [0, a, b, out]
+    u256 o = fr_mul(a, b);
+    c.push(zero(), true); c.push(a, false); c.push(b, false); c.push(o, false);
+    return o;
+  }
+  HD u256 g_mul_add(const u256& a, const u256& b, const u256& cc) {  // [c, a, b, out]
+    u256 o = fr_add(fr_mul(a, b), cc);
+    c.push(cc, true); c.push(a, false); c.push(b, false); c.push(o, false);
+    return o;
+  }
+  HD void g_assert_bit(const u256& x) {  // [0, x, x, x]
+    c.push(zero(), true); c.push(x, false); c.push(x, false); c.push(x, false);
+  }
+  HD u256 g_not(const u256& a) { return g_sub(T.one, a); }
+  HD u256 g_and(const u256& a, const u256& b) { return g_mul(a, b); }
+  HD u256 g_or(const u256& a, const u256& b) {  // [1-b, 1, b, 1, b, a, 1-b, out]
+    u256 nb = fr_sub(T.one, b);
+    u256 o = fr_sub(fr_add(a, b), fr_mul(a, b));
+    c.push(nb, true); c.push(T.one, false); c.push(b, false); c.push(T.one, false);
+    c.push(b, true); c.push(a, false); c.push(nb, false); c.push(o, false);
+    return o;
+  }
+  HD u256 g_select(const u256& a, const u256& b, const u256& s) {  // [a-b, 1, b, a, b, sel, a-b, out]
+    u256 d = fr_sub(a, b);
+    u256 o = u256_is_zero(s) ? b : (u256_eq(s, T.one) ? a : fr_add(fr_mul(d, s), b));
+    c.push(d, true); c.push(T.one, false); c.push(b, false); c.push(a, false);
+    c.push(b, true); c.push(s, false); c.push(d, false); c.push(o, false);
+    return o;
+  }
+  // is_zero with the inverse cell supplied (WitnessFraction evaluated)
+  HD u256 g_is_zero_inv(const u256& a, const u256& inv) {  // [z, a, inv, 1, 0, a, z, 0]
+    u256 z = u256_is_zero(a) ? T.one : zero();
+    c.push(z, true); c.push(a, false); c.push(inv, false); c.push(T.one, false);
+    c.push(zero(), true); c.push(a, false); c.push(z, false); c.push(zero(), false);
+    return z;
+  }
+  HD u256 g_is_zero(const u256& a) {
+    if (c.skip(8)) {
+      c.pos += 8;
+      return u256_is_zero(a) ? T.one : zero();
+    }
+    return g_is_zero_inv(a, inv_or_one(a));
+  }
+  HD u256 g_is_equal(const u256& a, const u256& b) {
+    u256 d = g_sub(a, b);
+    return g_is_zero(d);
+  }
+  HD u256 load_constant(const u256& v) {
+    c.push(v, false);
+    return v;
+  }
+
+  // ================================================================ RangeChip templates
+  HD static uint32_t rc_cells(uint32_t bits, uint32_t L) {
+    uint32_t k = (bits + L - 1) / L, rem = bits % L;
+    return (k == 1 ? 0 : 1 + 3 * (k - 1)) + (rem >= 1 ? 4 : 0);
+  }
+  HD static uint32_t rc_lookups(uint32_t bits, uint32_t L) {
+    uint32_t k = (bits + L - 1) / L, rem = bits % L;
+    return k + (rem > 1 ? 1 : 0);
+  }
+  // range_check(a, bits); `ac` = canonical value of a.  Returns the last cell queued for lookup.
+  HDN u256 r_range_check(const u256& a, const u256& ac, uint32_t bits) {
+    const uint32_t L = T.L, k = (bits + L - 1) / L, rem = bits % L;
+    u256 last;
+    if (k == 1) {
+      c.lookup(a);
+      last = a;
+    } else {
+      // inner_product(limbs, [1, 2^L, 2^2L, ...]) starting with the constant 1:
+      // [l0, l1, B1, s1, l2, B2, s2, ...] then the k limbs are queued for lookup
+      uint32_t l0 = u256_extract(ac, 0, L);
+      u256 s = limb_mont(l0);
+      c.push(s, true);
+      for (uint32_t i = 1; i < k; i++) {
+        u256 lm = limb_mont(u256_extract(ac, i * L, L));
+        s = fr_add(s, fr_mul(lm, T.pow2[i * L]));
+        c.push(lm, false);
+        c.push(T.pow2[i * L], false);
+        c.push(s, i + 1 < k);
+        last = lm;
+      }
+      for (uint32_t i = 0; i < k; i++) c.lookup(limb_mont(u256_extract(ac, i * L, L)));
+    }
+    if (rem == 1) {
+      g_assert_bit(last);
+    } else if (rem > 1) {
+      u256 chk = g_mul(last, T.pow2[L - rem]);
+      c.lookup(chk);
+      last = chk;
+    }
+    return last;
+  }
+  HD u256 r_range_check_skippable(const u256& a, uint32_t bits) {
+    uint32_t sz[2] = {rc_cells(bits, T.L), rc_lookups(bits, T.L)};
+    if (c.skip(sz[0])) {
+      c.advance(sz);
+      return zero();
+    }
+    return r_range_check(a, from_mont<Fr>(a), bits);
+  }
+  HDN void r_check_less_than(const u256& a, const u256& b, uint32_t bits) {
+    // [a + 2^n - b, b, 1, a + 2^n, -2^n, 1, a] gates 0,3 ; then range_check(first, bits)
+    uint32_t sz[2] = {7 + rc_cells(bits, T.L), rc_lookups(bits, T.L)};
+    if (c.skip(sz[0])) {
+      c.advance(sz);
+      return;
+    }
+    u256 sa = fr_add(T.pow2[bits], a), chk = fr_sub(sa, b);
+    c.push(chk, true); c.push(b, false); c.push(T.one, false);
+    c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false); c.push(T.one, false); c.push(a, false);
+    r_range_check(chk, from_mont<Fr>(chk), bits);
+  }
+  HD void r_check_big_less_than_safe(const u256& a, const u256& bound_mont, uint32_t bound_bits) {
+    uint32_t rb = (bound_bits + T.L - 1) / T.L * T.L;
+    r_range_check_skippable(a, rb);
+    r_check_less_than(a, bound_mont, rb);
+  }
+  HD u256 r_is_less_than(const u256& a, const u256& b, uint32_t bits) {
+    const uint32_t L = T.L, k = (bits + L - 1) / L, padded = k * L;
+    u256 sa = fr_add(T.pow2[padded], a), sh = fr_sub(sa, b);
+    c.push(sh, true); c.push(b, false); c.push(T.one, false);
+    c.push(sa, true); c.push(fr_neg(T.pow2[padded]), false); c.push(T.one, false); c.push(a, false);
+    u256 shc = from_mont<Fr>(sh);
+    u256 last = r_range_check(sh, shc, padded + L);
+    return g_is_zero_inv(last, inv_small_or_full(last, u256_extract(shc, padded, L)));
+  }
+  // inverse of a value known to equal the small canonical integer `v` (< 260), else Fermat
+  HD u256 inv_small_or_full(const u256& x, uint32_t v) const {
+    if (v == 0) return T.one;
+    if (v < 260) return T.small_inv[v];
+    return mont_inv<Fr>(x);
+  }
+
+  // div_mod(a, 2^shift, a_bits): quotient/remainder by a power of two  (range.rs div_mod)
+  HD void r_div_mod_pow2(const u256& a, uint32_t shift, uint32_t a_bits, u256& div, u256& rem) {
+    u256 ac = from_mont<Fr>(a);
+    u256 qc = u256_shr(ac, shift), rc = u256_low_bits(ac, shift);
+    div = to_mont<Fr>(qc);
+    rem = to_mont<Fr>(rc);
+    c.push(rem, true); c.push(T.pow2[shift], false); c.push(div, false); c.push(a, false);
+    // div < 2^a_bits / 2^shift + 1 ; rem < 2^shift
+    u256 bound = fr_add(T.pow2[a_bits - shift], T.one);
+    r_check_big_less_than_safe(div, bound, a_bits - shift + 1);
+    r_check_big_less_than_safe(rem, T.pow2[shift], shift + 1);
+  }
+  // 256-bit schoolbook shift-subtract division of canonical integers (BigUint div_mod_floor)
+  HDN static void divmod_u256(const u256& a, const u256& b, u256& q, u256& r) {
+    q = u256_zero();
+    r = u256_zero();
+    int nb = (int)u256_bits(a);
+    for (int i = nb - 1; i >= 0; i--) {
+      r = u256_shl(r, 1);
+      r.w[0] |= u256_bit(a, (unsigned)i);
+      if (u256_geq(r, b)) {
+        u256 t;
+        u256_sub(t, r, b);
+        r = t;
+        q.w[i >> 5] |= 1u << (i & 31);
+      }
+    }
+  }
+  HDN void r_div_mod_var(const u256& a, const u256& b, uint32_t a_bits, uint32_t b_bits, u256& div, u256& rem) {
+    u256 ac = from_mont<Fr>(a), bc = from_mont<Fr>(b), qc, rc;
+    if (u256_is_zero(bc)) {  // BigUint division by zero panics in the reference
+      c.err = 1;
+      qc = u256_zero();
+      rc = u256_zero();
+    } else {
+      divmod_u256(ac, bc, qc, rc);
+    }
+    div = to_mont<Fr>(qc);
+    rem = to_mont<Fr>(rc);
+    c.push(rem, true); c.push(b, false); c.push(div, false); c.push(a, false);
+    r_range_check_skippable(div, a_bits);
+    r_check_less_than(rem, b, b_bits);
+  }
+
+  // ================================================================ FixedPointChip
+  // value-only helpers (no cells)
+  HD bool v_is_neg(const u256& ac) const { return u256_bits(ac) > 2 * T.P + 1; }  // a >= 2^(2P+1)
+  HDN u256 v_signed_div_scale(const u256& a) const {  // quotient of fixed_point.rs:974-996
+    u256 ac = from_mont<Fr>(a);
+    const uint32_t P = T.P;
+    if (u256_bits(ac) > 253 || (u256_bits(ac) == 253 && !u256_is_zero(u256_low_bits(ac, 252)))) {
+      u256 r = mod_p<Fr>(), aabs;
+      u256_sub(aabs, r, ac);
+      u256 cq = u256_shr(aabs, P);
+      if (!u256_is_zero(u256_low_bits(aabs, P))) {
+        u256 t;
+        u256_add(t, cq, u256_from_u64(1));
+        cq = t;
+      }
+      return fr_neg(to_mont<Fr>(cq));
+    }
+    return to_mont<Fr>(u256_shr(ac, P));
+  }
+  HD u256 v_qmul(const u256& a, const u256& b) const { return v_signed_div_scale(fr_mul(a, b)); }
+  HD u256 v_qabs(const u256& a) const { return v_is_neg(from_mont<Fr>(a)) ? fr_neg(a) : a; }
+  HDN u256 v_qdiv(const u256& a, const u256& b, int& err) const {
+    u256 ac = from_mont<Fr>(a), bc = from_mont<Fr>(b);
+    bool sa = v_is_neg(ac), sb = v_is_neg(bc);
+    u256 aa = sa ? fr_neg(a) : a, ba = sb ? fr_neg(b) : b;
+    u256 num = from_mont<Fr>(fr_mul(aa, T.scale)), den = from_mont<Fr>(ba), q, r;
+    if (u256_is_zero(den)) {
+      err = 1;
+      return u256_zero();
+    }
+    divmod_u256(num, den, q, r);
+    u256 qm = to_mont<Fr>(q);
+    return (sa != sb) ? fr_neg(qm) : qm;
+  }
+
+  HDN u256 fp_is_neg(const u256& a) {  // fixed_point.rs:523-539
+    if (c.skip(T.sz.is_neg[0])) {
+      c.advance(T.sz.is_neg);
+      return v_is_neg(from_mont<Fr>(a)) ? T.one : zero();
+    }
+    u256 div, rem;
+    r_div_mod_pow2(a, 2 * T.P + 1, 254, div, rem);
+    u256 is_pos = g_is_zero(div);
+    return g_not(is_pos);
+  }
+  HDN u256 fp_qabs(const u256& a) {  // :511-521
+    if (c.skip(T.sz.qabs[0])) {
+      c.advance(T.sz.qabs);
+      return v_qabs(a);
+    }
+    u256 rev = g_neg(a);
+    u256 n = fp_is_neg(a);
+    return g_select(rev, a, n);
+  }
+  HD u256 fp_cond_neg(const u256& a, const u256& flag) {  // :541-556
+    u256 na = g_neg(a);
+    return g_select(na, a, flag);
+  }
+  HDN u256 fp_signed_div_scale(const u256& a) {  // :974-1016, returns the quotient
+    if (c.skip(T.sz.sds[0])) {
+      c.advance(T.sz.sds);
+      return v_signed_div_scale(a);
+    }
+    const uint32_t P = T.P;
+    u256 ac = from_mont<Fr>(a), div, rem;
+    bool neg = u256_bits(ac) > 253 || (u256_bits(ac) == 253 && !u256_is_zero(u256_low_bits(ac, 252)));  // a > 2^252
+    if (neg) {
+      u256 r = mod_p<Fr>(), aabs, one = u256_from_u64(1);
+      u256_sub(aabs, r, ac);
+      u256 cq = u256_shr(aabs, P), low = u256_low_bits(aabs, P), remc = u256_zero();
+      if (!u256_is_zero(low)) {
+        u256 t;
+        u256_add(t, cq, one);
+        cq = t;
+        u256_sub(remc, u256_shl(one, P), low);  // 2^P * ceil - |a|
+      }
+      div = fr_neg(to_mont<Fr>(cq));
+      rem = to_mont<Fr>(remc);
+    } else {
+      div = to_mont<Fr>(u256_shr(ac, P));
+      rem = to_mont<Fr>(u256_low_bits(ac, P));
+    }
+    c.push(rem, true); c.push(T.scale, false); c.push(div, false); c.push(a, false);
+    r_check_big_less_than_safe(rem, T.pow2[P], P + 1);
+    u256 dabs = fp_qabs(div);
+    r_check_big_less_than_safe(dabs, T.pow2[3 * P], 3 * P + 1);
+    return div;
+  }
+  HDN u256 fp_qmul(const u256& a, const u256& b) {  // :588-604
+    if (c.skip(T.sz.qmul[0])) {
+      c.advance(T.sz.qmul);
+      return v_qmul(a, b);
+    }
+    u256 ab = g_mul(a, b);
+    return fp_signed_div_scale(ab);
+  }
+  HD u256 fp_bit_xor(const u256& a, const u256& b) {  // :797-815
+    u256 a2 = g_add(zero(), a);
+    u256 b2 = g_add(zero(), b);
+    g_assert_bit(a2);
+    g_assert_bit(b2);
+    u256 ab = g_add(a2, b2);
+    u256 one = g_add(T.one, zero());
+    u256 d = g_sub(ab, one);
+    // d in {-1, 0, 1}
+    u256 inv = u256_is_zero(d) ? T.one : (u256_eq(d, T.one) ? T.one : fr_neg(T.one));
+    return g_is_zero_inv(d, inv);
+  }
+  HDN u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
+    if (c.skip(T.sz.qdiv[0])) {
+      c.advance(T.sz.qdiv);
+      return v_qdiv(a, b, c.err);
+    }
+    const uint32_t P = T.P;
+    u256 sa = fp_is_neg(a);
+    u256 sb = fp_is_neg(b);
+    u256 aa = fp_qabs(a);
+    u256 ba = fp_qabs(b);
+    u256 ar = g_mul(aa, T.scale);
+    u256 q, r;
+    r_div_mod_var(ar, ba, 4 * P, 2 * P, q, r);
+    u256 sx = fp_bit_xor(sa, sb);
+    return fp_cond_neg(q, sx);
+  }
+  HD u256 fp_qmin(const u256& a, const u256& b) {  // :936-952
+    u256 amb = g_sub(a, b);
+    u256 s = fp_is_neg(amb);
+    return g_select(a, b, s);
+  }
+  template <int M>
+  HD u256 fp_polynomial(const u256& x, const u256 (&coef)[M], const uint32_t (&sz)[2]) {  // :658-686
+    if (c.skip(sz[0])) {
+      c.advance(sz);
+      u256 y = zero();
+      for (int i = 0; i < M; i++) {
+        y = fr_add(y, coef[i]);
+        if (i < M - 1) y = v_qmul(x, y);
+      }
+      return y;
+    }
+    u256 result = g_add(x, zero());  // dead qadd(x, 0)
+    u256 last = zero();
+    for (int i = 0; i < M; i++) {
+      u256 y_add = g_add(last, coef[i]);
+      if (i < M - 1) last = fp_qmul(x, y_add);
+      else result = y_add;
+    }
+    return result;
+  }
+  // GateChip::select_from_idx over `n` cells with idx known to be the small integer `idx_small`
+  // (or >= n when out of range): idx_to_indicator (v0.3) + select_by_indicator
+  template <class CellFn>
+  HD u256 g_select_from_idx(uint32_t n, const u256& idx, uint64_t idx_small, CellFn&& cell) {
+    // indicator i: i == 0 -> unrolled is_zero(idx); else is_equal(idx, Constant(i))
+    for (uint32_t i = 0; i < n; i++) {
+      int64_t diff = (int64_t)idx_small - (int64_t)i;
+      if (i == 0) {
+        if (c.skip(8)) c.pos += 8;
+        else g_is_zero_inv(idx, signed_small_inv(idx, diff));
+      } else {
+        if (c.skip(12)) {
+          c.pos += 12;
+        } else {
+          u256 ci = i < 260 ? T.small[i] : to_mont<Fr>(u256_from_u64(i));
+          u256 d = g_sub(idx, ci);
+          g_is_zero_inv(d, signed_small_inv(d, diff));
+        }
+      }
+    }
+    // select_by_indicator: [0, a0, ind0, s0, a1, ind1, s1, ...]
+    u256 s = zero();
+    c.push(zero(), n > 0);
+    for (uint32_t i = 0; i < n; i++) {
+      u256 ai = cell(i);
+      bool hit = (idx_small == i);
+      if (hit) s = ai;
+      c.push(ai, false);
+      c.push(hit ? T.one : zero(), false);
+      c.push(s, i + 1 < n);
+    }
+    return s;
+  }
+  HD u256 signed_small_inv(const u256& x, int64_t v) const {
+    if (v == 0) return T.one;
+    if (v > 0 && v < 260) return T.small_inv[v];
+    if (v < 0 && v > -260) return fr_neg(T.small_inv[-v]);
+    return mont_inv<Fr>(x);
+  }
+  HDN void fp_check_power_of_two(const u256& p2, const u256& e, uint64_t e_small) {  // :688-708
+    if (c.skip(T.sz.cpow2[0])) {
+      c.advance(T.sz.cpow2);
+      return;
+    }
+    const uint32_t nb = 2 * T.P;
+    u256 pc = from_mont<Fr>(p2);
+    // num_to_bits: inner_product(bits, pow2) starting with constant 1, then nb assert_bit
+    uint32_t nset = 0;
+    {
+      u256 s = u256_bit(pc, 0) ? T.one : zero();
+      nset += u256_bit(pc, 0);
+      c.push(s, true);
+      for (uint32_t i = 1; i < nb; i++) {
+        uint32_t bit = u256_bit(pc, i);
+        nset += bit;
+        if (bit) s = fr_add(s, T.pow2[i]);
+        c.push(bit ? T.one : zero(), false);
+        c.push(T.pow2[i], false);
+        c.push(s, i + 1 < nb);
+      }
+      for (uint32_t i = 0; i < nb; i++) g_assert_bit(u256_bit(pc, i) ? T.one : zero());
+    }
+    // sum(bits): [b0, b1, 1, s1, b2, 1, s2, ...]
+    {
+      uint32_t run = u256_bit(pc, 0);
+      c.push(run ? T.one : zero(), nb > 1);
+      for (uint32_t i = 1; i < nb; i++) {
+        uint32_t bit = u256_bit(pc, i);
+        run += bit;
+        c.push(bit ? T.one : zero(), false);
+        c.push(T.one, false);
+        c.push(small(run), i + 1 < nb);
+      }
+    }
+    u256 sum = small(nset);
+    u256 sm1 = g_sub(sum, T.one);
+    g_is_zero_inv(sm1, signed_small_inv(sm1, (int64_t)nset - 1));
+    u256 bit = g_select_from_idx(nb, e, e_small, [&](uint32_t i) { return u256_bit(pc, i) ? T.one : u256_zero(); });
+    u256 bm1 = g_sub(bit, T.one);
+    g_is_zero_inv(bm1, u256_is_zero(bm1) ? T.one : fr_neg(T.one));
+  }
+  HD u256 v_qlog2(const u256& a) {
+    u256 ac = from_mont<Fr>(a);
+    uint32_t nd = u256_is_zero(ac) ? 1 : u256_bits(ac) - 1;
+    int64_t shift = (int64_t)T.P + 2 - ((int64_t)nd + 1);
+    uint32_t sa = (uint32_t)(shift < 0 ? -shift : shift);
+    if (sa >= 254) sa = 0;
+    u256 a_norm = shift < 0 ? to_mont<Fr>(u256_shr(ac, sa)) : fr_mul(a, T.pow2[sa]);
+    u256 ln = fp_polynomial<15>(a_norm, T.log_poly, T.sz.poly15);  // skipped => value path
+    u256 shm = shift < 0 ? fr_neg(small_or_mont((uint64_t)(-shift))) : small_or_mont((uint64_t)shift);
+    return fr_add(ln, fr_mul(fr_neg(shm), T.scale));
+  }
+  HD u256 small_or_mont(uint64_t v) const { return v < 260 ? T.small[v] : to_mont<Fr>(u256_from_u64(v)); }
+  HDN u256 fp_qlog2(const u256& a) {  // :736-795
+    if (c.skip(T.sz.qlog2[0])) {
+      uint64_t p0 = c.pos, l0 = c.lpos;
+      u256 v = v_qlog2(a);
+      c.pos = p0 + T.sz.qlog2[0];
+      c.lpos = l0 + T.sz.qlog2[1];
+      return v;
+    }
+    const uint32_t P = T.P;
+    u256 a_assigned = g_add(a, zero());
+    u256 is_neg = fp_is_neg(a);
+    u256 is_zero = g_is_zero(a_assigned);
+    g_or(is_neg, is_zero);
+    u256 ac = from_mont<Fr>(a);
+    uint32_t nd = u256_is_zero(ac) ? 1 : u256_bits(ac) - 1;
+    u256 pow1w = g_add(T.pow2[nd < 254 ? nd : 0], zero());
+    u256 exp1 = g_add(small_or_mont(nd), zero());
+    fp_check_power_of_two(pow1w, exp1, nd);
+    u256 pow2w = g_mul(pow1w, T.small[2]);
+    u256 exp2 = g_add(exp1, T.one);
+    fp_check_power_of_two(pow2w, exp2, (uint64_t)nd + 1);
+    u256 lt2 = r_is_less_than(a, pow2w, 2 * P);
+    u256 gt1 = r_is_less_than(pow1w, a, 2 * P);
+    u256 eq1 = g_is_equal(a, pow1w);
+    u256 ge1 = g_or(eq1, gt1);
+    g_and(lt2, ge1);
+    u256 shift = g_sub(small_or_mont((uint64_t)P + 2), exp2);
+    int64_t shv = (int64_t)P + 2 - ((int64_t)nd + 1);
+    u256 shift_neg = fp_is_neg(shift);
+    u256 shift_abs = fp_qabs(shift);
+    uint32_t sa = (uint32_t)(shv < 0 ? -shv : shv);
+    if (sa >= 254) {  // Vec index out of range panics in the reference
+      c.err = 1;
+      sa = 0;
+    }
+    u256 spw = g_add(T.pow2[sa], zero());
+    fp_check_power_of_two(spw, shift_abs, sa);
+    u256 a_ls = g_mul(a, spw);
+    u256 a_rs, rr;
+    r_div_mod_var(a, spw, 2 * P, P + 1, a_rs, rr);
+    u256 a_norm = g_select(a_rs, a_ls, shift_neg);
+    u256 log_norm = fp_polynomial<15>(a_norm, T.log_poly, T.sz.poly15);
+    u256 log_shift = g_neg(shift);
+    u256 lsq = g_mul(log_shift, T.scale);
+    return g_add(log_norm, lsq);
+  }
+  HD u256 v_qexp2(const u256& a) {
+    u256 a_abs = v_qabs(a);
+    u256 ac = from_mont<Fr>(a_abs);
+    u256 ipc = u256_shr(ac, T.P);
+    uint32_t ip = u256_bits(ipc) > 16 ? 0xffffu : ipc.w[0];
+    u256 fpart = to_mont<Fr>(u256_low_bits(ac, T.P));
+    u256 yf = fp_polynomial<13>(fpart, T.exp2_poly, T.sz.poly13);
+    u256 res_pos = ip < 254 ? fr_mul(T.pow2[ip], yf) : zero();
+    if (u256_is_zero(res_pos)) c.err = 1;  // the emission path always evaluates qdiv(2^P, res_pos)
+    if (v_is_neg(from_mont<Fr>(a))) return v_qdiv(T.scale, res_pos, c.err);
+    return res_pos;
+  }
+  HDN u256 fp_qexp2(const u256& a) {  // :710-734
+    if (c.skip(T.sz.qexp2[0])) {
+      uint64_t p0 = c.pos, l0 = c.lpos;
+      u256 v = v_qexp2(a);
+      c.pos = p0 + T.sz.qexp2[0];
+      c.lpos = l0 + T.sz.qexp2[1];
+      return v;
+    }
+    const uint32_t P = T.P;
+    u256 a_abs = fp_qabs(a);
+    u256 ip, fpart;
+    r_div_mod_pow2(a_abs, P, 2 * P, ip, fpart);
+    u256 ipc = from_mont<Fr>(ip);
+    uint64_t ip_small = u256_bits(ipc) > 32 ? 0xffffffffull : ipc.w[0];
+    u256 ip2 = g_select_from_idx(254, ip, ip_small, [&](uint32_t i) { return T.pow2[i]; });
+    u256 yf = fp_polynomial<13>(fpart, T.exp2_poly, T.sz.poly13);
+    u256 res_pos = g_mul(ip2, yf);
+    u256 res_neg = fp_qdiv(T.scale, res_pos);
+    u256 n = fp_is_neg(a);
+    return g_select(res_neg, res_pos, n);
+  }
+  HD u256 fp_qlog(const u256& a) {  // :954-964
+    u256 l2e = load_constant(T.c_log2e);
+    u256 l2a = fp_qlog2(a);
+    return fp_qdiv(l2a, l2e);
+  }
+  HD u256 fp_qexp(const u256& a) {  // :876-886
+    u256 ln2 = load_constant(T.c_ln2);
+    u256 x1 = fp_qdiv(a, ln2);
+    return fp_qexp2(x1);
+  }
+  HD u256 fp_qpow(const u256& x, const u256& e) {  // :441-456
+    u256 lx = fp_qlog(x);
+    u256 al = fp_qmul(e, lx);
+    return fp_qexp(al);
+  }
+  HD u256 fp_qsqrt(const u256& x) {  // :966-972
+    u256 half = load_constant(T.c_half);
+    return fp_qpow(x, half);
+  }
+};
+
+// Host-side sizing: runs the generators in counting mode and fills T.sz bottom-up.
+inline void compute_sizes(FpTables& T) {
+  auto measure = [&](auto&& fn, uint32_t out[2]) {
+    WCtx c{};
+    c.count_only = true;
+    c.hi = ~0ull;
+    c.T = &T;
+    Gadgets g(c);
+    fn(g);
+    out[0] = (uint32_t)c.pos;
+    out[1] = (uint32_t)c.lpos;
+  };
+  u256 x = T.c_one_q, y = T.c_half;
+  measure([&](Gadgets& g) { g.fp_is_neg(x); }, T.sz.is_neg);
+  measure([&](Gadgets& g) { g.fp_qabs(x); }, T.sz.qabs);
+  measure([&](Gadgets& g) { g.fp_signed_div_scale(x); }, T.sz.sds);
+  measure([&](Gadgets& g) { g.fp_qmul(x, y); }, T.sz.qmul);
+  measure([&](Gadgets& g) { g.fp_qdiv(x, y); }, T.sz.qdiv);
+  measure([&](Gadgets& g) { g.fp_qmin(x, y); }, T.sz.qmin);
+  measure([&](Gadgets& g) { g.fp_check_power_of_two(T.pow2[3], T.small[3], 3); }, T.sz.cpow2);
+  measure([&](Gadgets& g) { g.fp_polynomial<13>(x, T.exp2_poly, T.sz.poly13); }, T.sz.poly13);
+  measure([&](Gadgets& g) { g.fp_polynomial<15>(x, T.log_poly, T.sz.poly15); }, T.sz.poly15);
+  measure([&](Gadgets& g) { g.fp_qlog2(x); }, T.sz.qlog2);
+  measure([&](Gadgets& g) { g.fp_qexp2(x); }, T.sz.qexp2);
+  measure([&](Gadgets& g) { g.fp_qlog(x); }, T.sz.qlog);
+  measure([&](Gadgets& g) { g.fp_qexp(x); }, T.sz.qexp);
+  measure([&](Gadgets& g) { g.fp_qsqrt(x); }, T.sz.qsqrt);
+}
+
+}  // namespace vdb

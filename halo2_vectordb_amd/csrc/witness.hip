@@ -1,0 +1,1181 @@
+// Witness generation (b5), stream->column layout (b4) and fixed-point staging (a2/a3/a18) on gfx950.
+//
+// Every kernel writes cells of the flat advice stream at statically known offsets (gadgets.hpp), so
+// independent gadget instances — distance evaluations, Poseidon permutations, per-dimension folds —
+// run as independent threads; long sequential gadgets are cut into position windows, one window per
+// wavefront of 64 instances.  The stream is written once (32 B per cell: the HBM-write roofline of
+// this stage) and read once by the layout kernel.
+#include <cmath>
+
+#include "common.hpp"
+#include "gadgets.hpp"
+#include "poseidon.hpp"
+
+namespace vdb {
+
+int poseidon_merkle_dev(const u256* vectors_dev, size_t n, size_t dim, u256* lv, u256* tmp);
+
+// ------------------------------------------------------------------ fixed-point staging (host)
+// fixed_point.rs:104-119: round(|x| * 2^P) as u128 (saturating), negative -> r - q
+static u256 quantize_host(uint32_t P, double x) {
+  bool neg = !std::isnan(x) && std::signbit(x);
+  double y = std::round(std::fabs(x) * std::ldexp(1.0, (int)P));
+  unsigned __int128 q;
+  if (std::isnan(y) || y <= 0.0) q = 0;
+  else if (y >= 340282366920938463463374607431768211456.0) q = ~(unsigned __int128)0;
+  else q = (unsigned __int128)y;
+  u256 c = u256_zero();
+  for (int i = 0; i < 4; i++) c.w[i] = (uint32_t)(q >> (32 * i));
+  u256 m = to_mont<Fr>(c);
+  return neg ? fr_neg(m) : m;
+}
+// fixed_point.rs:121-136 (including the "-(|v| - 2)" quirk for negatives)
+static double dequantize_host(uint32_t P, const u256& x) {
+  u256 c = from_mont<Fr>(x);
+  u256 np, t, one = u256_from_u64(1);
+  u256_sub(np, mod_p<Fr>(), u256_shl(one, 2 * P + 1));
+  double sign = 1.0;
+  if (!u256_geq(np, c)) {  // x > negative_point
+    u256 bm;
+    u256_sub(bm, mod_p<Fr>(), one);                // bn254_max
+    u256 xm = fr_sub(fr_sub(to_mont<Fr>(bm), x), mont_one<Fr>());
+    c = from_mont<Fr>(xm);
+    sign = -1.0;
+  }
+  (void)t;
+  unsigned __int128 lo = 0;
+  for (int i = 0; i < 4; i++) lo |= (unsigned __int128)c.w[i] << (32 * i);
+  unsigned __int128 sc = (unsigned __int128)1 << P;
+  double xi = (double)(lo / sc);
+  double xf = (double)(lo % sc) / (double)sc;
+  return sign * (xi + xf);
+}
+
+// ------------------------------------------------------------------ FixedPointChip tables
+struct FpEntry {
+  FpTables host;
+  FpTables* dev;
+  u256* limb_tab;
+};
+static std::map<uint64_t, FpEntry*> g_fp;
+
+__global__ void k_limb_table(u256* tab, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tab[i] = to_mont<Fr>(u256_from_u64(i));
+}
+
+static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
+  if (P < 32 || P > 63) {
+    set_error("PRECISION_BITS must be in [32, 63] (fixed_point.rs:55-56)");
+    return VDB_ERR_ARG;
+  }
+  if (L < 2 || L > 20) {
+    set_error("lookup_bits must be in [2, 20]");
+    return VDB_ERR_ARG;
+  }
+  uint64_t key = ((uint64_t)P << 32) | L;
+  auto it = g_fp.find(key);
+  if (it != g_fp.end()) {
+    *out = it->second;
+    return VDB_OK;
+  }
+  FpEntry* e = new FpEntry();
+  FpTables& T = e->host;
+  memset(&T, 0, sizeof(T));
+  T.P = P;
+  T.L = L;
+  T.one = mont_one<Fr>();
+  T.pow2[0] = T.one;
+  for (int i = 1; i < 254; i++) T.pow2[i] = fr_add(T.pow2[i - 1], T.pow2[i - 1]);
+  T.scale = T.pow2[P];
+  static const double exp2c[13] = {3.6240421303547230336183979205877e-11, 4.1284327467833130245549169910389e-10,
+                                   0.0000000071086385644026346316624185550542, 0.00000010172297085296590958930245291448,
+                                   0.0000013215904023658396206789543841996, 0.000015252713316417140696221389106544,
+                                   0.00015403531076657894204857389177279, 0.0013333558131297097698435464957392,
+                                   0.0096181291078409107025643582456283, 0.055504108664804181586140094858174,
+                                   0.24022650695910142332414229540187, 0.69314718055994529934452147700678, 1.0};
+  static const double logc[15] = {-3.319586265362338e-08, 1.4957235315170112e-06, -3.1350053389526744e-05,
+                                  0.00040554177582512901, -0.0036218342998850703, 0.023663846121538389,
+                                  -0.11691877183255484, 0.44524062371564499, -1.3195777548208449,
+                                  3.0518128028712077, -5.4904626000399528, 7.6298580090181591,
+                                  -8.1653313719804235, 7.1389971101896279, -3.1937385492842112};
+  for (int i = 0; i < 13; i++) T.exp2_poly[i] = quantize_host(P, exp2c[i]);
+  for (int i = 0; i < 15; i++) T.log_poly[i] = quantize_host(P, logc[i]);
+  T.c_half = quantize_host(P, 0.5);
+  T.c_ln2 = quantize_host(P, 0.693147180559945309417232121458176568);
+  T.c_log2e = quantize_host(P, 1.44269504088896340735992468100189214);
+  T.c_one_q = quantize_host(P, 1.0);
+  for (uint32_t i = 0; i < 260; i++) {
+    T.small[i] = host_fr_from_u64(i);
+    T.small_inv[i] = i ? mont_inv<Fr>(T.small[i]) : u256_zero();
+  }
+  compute_sizes(T);
+  VDB_HIP(hipMalloc(&e->limb_tab, ((size_t)1 << L) * sizeof(u256)));
+  hipLaunchKernelGGL(k_limb_table, dim3((unsigned)(((1u << L) + 255) / 256)), dim3(256), 0, ctx().stream, e->limb_tab, 1u << L);
+  VDB_LAUNCH_CHECK();
+  T.limb_tab = e->limb_tab;
+  VDB_HIP(hipMalloc(&e->dev, sizeof(FpTables)));
+  VDB_HIP(hipMemcpyAsync(e->dev, &T, sizeof(FpTables), hipMemcpyHostToDevice, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  g_fp[key] = e;
+  *out = e;
+  return VDB_OK;
+}
+
+// ------------------------------------------------------------------ distance layout
+enum { M_EUCLID = 0, M_COSINE = 1, M_MANHATTAN = 2 };
+struct DistLayout {
+  uint32_t metric, D;
+  uint64_t head_cells, head_lk, tail_cells, tail_lk, total_cells, total_lk;
+};
+static int dist_layout(const FpTables& T, int metric, size_t D, DistLayout* o) {
+  const Sizes& z = T.sz;
+  o->metric = (uint32_t)metric;
+  o->D = (uint32_t)D;
+  uint64_t ip_c = 4 + D * ((uint64_t)z.qmul[0] + 4), ip_l = D * (uint64_t)z.qmul[1];
+  switch (metric) {
+    case M_EUCLID:
+      o->head_cells = 4 * D + ip_c;
+      o->head_lk = ip_l;
+      o->tail_cells = z.qsqrt[0];
+      o->tail_lk = z.qsqrt[1];
+      break;
+    case M_COSINE:
+      o->head_cells = 3 * ip_c;
+      o->head_lk = 3 * ip_l;
+      o->tail_cells = 2ull * z.qsqrt[0] + z.qmul[0] + z.qdiv[0] + 1 + 4;
+      o->tail_lk = 2ull * z.qsqrt[1] + z.qmul[1] + z.qdiv[1];
+      break;
+    case M_MANHATTAN:
+      o->head_cells = 4 * D + D * (uint64_t)z.qabs[0] + (D == 0 ? 0 : (D == 1 ? 1 : 1 + 3 * (D - 1)));
+      o->head_lk = D * (uint64_t)z.qabs[1];
+      o->tail_cells = 0;
+      o->tail_lk = 0;
+      break;
+    default:
+      set_error("unsupported metric %d (0 euclidean, 1 cosine, 2 manhattan; hamming stays on the CPU)", metric);
+      return VDB_ERR_ARG;
+  }
+  o->total_cells = o->head_cells + o->tail_cells;
+  o->total_lk = o->head_lk + o->tail_lk;
+  return VDB_OK;
+}
+
+// where instance t lives in the streams and which operand vectors it uses
+struct InstMap {
+  uint64_t adv_base, lk_base;
+  uint32_t grp;                       // instances per group
+  uint64_t grp_adv_stride, grp_lk_stride;
+  uint32_t a_mod, b_div;              // a = A[(t % a_mod)], b = B[(t / b_div)]
+  __device__ __forceinline__ uint64_t adv(uint32_t t, const DistLayout& dl) const { return adv_base + (uint64_t)(t / grp) * grp_adv_stride + (uint64_t)(t % grp) * dl.total_cells; }
+  __device__ __forceinline__ uint64_t lk(uint32_t t, const DistLayout& dl) const { return lk_base + (uint64_t)(t / grp) * grp_lk_stride + (uint64_t)(t % grp) * dl.total_lk; }
+};
+
+struct Streams {
+  u256* adv;
+  uint8_t* sel;
+  u256* lk;
+  int* err;
+};
+
+__device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, uint64_t pos, uint64_t lpos) {
+  WCtx c;
+  c.adv = s.adv;
+  c.sel = s.sel;
+  c.lk = s.lk;
+  c.pos = pos;
+  c.lpos = lpos;
+  c.lo = 0;
+  c.hi = ~0ull;
+  c.count_only = false;
+  c.err = 0;
+  c.T = T;
+  return c;
+}
+
+#define HEAD_TB 128
+// inner_product(a, b) of fixed_point.rs:854-874 for one instance, cooperatively by the block:
+// thread i emits qmul(a_i, b_i) and the following qadd; running sums come from an LDS prefix.
+// mode 0: operands x_i = A[i], y_i = B[i];  mode 1: x_i = y_i = A[i] - B[i] (already emitted qsub)
+__device__ void block_inner_product(const Streams& st, const FpTables* T, const u256* A, const u256* Bv, int mode, uint32_t D,
+                                    uint64_t ipbase, uint64_t iplbase, u256* sh /* HEAD_TB + 1 */, u256* result) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t qm = T->sz.qmul[0], qml = T->sz.qmul[1];
+  if (tid == 0) {
+    WCtx c = make_ctx(st, T, ipbase, iplbase);
+    Gadgets g(c);
+    g.g_add(u256_zero(), u256_zero());  // res = qadd(0, 0)
+    sh[HEAD_TB] = u256_zero();
+  }
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < D; c0 += HEAD_TB) {
+    uint32_t i = c0 + tid;
+    u256 q = u256_zero();
+    WCtx c = make_ctx(st, T, ipbase + 4 + (uint64_t)i * (qm + 4), iplbase + (uint64_t)i * qml);
+    Gadgets g(c);
+    if (i < D) {
+      u256 x = A[i], y = Bv[i];
+      if (mode == 1) {
+        x = fr_sub(x, y);
+        y = x;
+      }
+      q = g.fp_qmul(x, y);
+      if (c.err) atomicOr(st.err, c.err);
+    }
+    sh[tid] = q;
+    __syncthreads();
+    if (i < D) {
+      u256 prev = sh[HEAD_TB];
+      for (uint32_t j = 0; j < tid; j++) prev = fr_add(prev, sh[j]);
+      g.g_add(prev, q);  // res = qadd(res, a_i b_i)
+    }
+    __syncthreads();
+    if (tid == 0) {
+      u256 carry = sh[HEAD_TB];
+      uint32_t lim = D - c0 < HEAD_TB ? D - c0 : HEAD_TB;
+      for (uint32_t j = 0; j < lim; j++) carry = fr_add(carry, sh[j]);
+      sh[HEAD_TB] = carry;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *result = sh[HEAD_TB];
+  __syncthreads();
+}
+
+// head of a distance: everything before the sequential tail.  One block per instance.
+__global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTables* __restrict__ T, DistLayout dl, InstMap im,
+                                                       const u256* __restrict__ A, const u256* __restrict__ Bv, u256* __restrict__ mid /* 3 per inst */,
+                                                       u256* __restrict__ result) {
+  __shared__ u256 sh[HEAD_TB + 1];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x, D = dl.D;
+  const u256* a = A + (size_t)(t % im.a_mod) * D;
+  const u256* b = Bv + (size_t)(t / im.b_div) * D;
+  const uint64_t base = im.adv(t, dl), lbase = im.lk(t, dl);
+  if (dl.metric == M_EUCLID) {  // distance.rs:97-119
+    for (uint32_t i = tid; i < D; i += HEAD_TB) {
+      WCtx c = make_ctx(st, T, base + 4ull * i, lbase);
+      Gadgets g(c);
+      g.g_sub(a[i], b[i]);
+    }
+    block_inner_product(st, T, a, b, 1, D, base + 4ull * D, lbase, sh, &mid[3 * (size_t)t]);
+  } else if (dl.metric == M_COSINE) {  // distance.rs:121-144
+    const uint64_t ipc = 4 + (uint64_t)D * (T->sz.qmul[0] + 4), ipl = (uint64_t)D * T->sz.qmul[1];
+    block_inner_product(st, T, a, b, 0, D, base, lbase, sh, &mid[3 * (size_t)t]);
+    block_inner_product(st, T, a, a, 0, D, base + ipc, lbase + ipl, sh, &mid[3 * (size_t)t + 1]);
+    block_inner_product(st, T, b, b, 0, D, base + 2 * ipc, lbase + 2 * ipl, sh, &mid[3 * (size_t)t + 2]);
+  } else {  // manhattan, distance.rs:177-195
+    const uint32_t qa = T->sz.qabs[0], qal = T->sz.qabs[1];
+    const uint64_t sumbase = base + 4ull * D + (uint64_t)D * qa;
+    if (tid == 0) sh[HEAD_TB] = u256_zero();
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < D; c0 += HEAD_TB) {
+      uint32_t i = c0 + tid;
+      u256 v = u256_zero();
+      if (i < D) {
+        WCtx c = make_ctx(st, T, base + 4ull * i, lbase);
+        Gadgets g(c);
+        u256 d = g.g_sub(a[i], b[i]);
+        c.pos = base + 4ull * D + (uint64_t)i * qa;
+        c.lpos = lbase + (uint64_t)i * qal;
+        v = g.fp_qabs(d);
+      }
+      sh[tid] = v;
+      __syncthreads();
+      if (i < D) {  // gate().sum: [a0, a1, 1, s1, a2, 1, s2, ...]
+        WCtx c = make_ctx(st, T, 0, 0);
+        if (i == 0) {
+          c.pos = sumbase;
+          c.push(v, D > 1);
+        } else {
+          u256 s = sh[HEAD_TB];
+          for (uint32_t j = 0; j <= tid; j++) s = fr_add(s, sh[j]);
+          c.pos = sumbase + 1 + 3ull * (i - 1);
+          c.push(v, false);
+          c.push(T->one, false);
+          c.push(s, i + 1 < D);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        u256 carry = sh[HEAD_TB];
+        uint32_t lim = D - c0 < HEAD_TB ? D - c0 : HEAD_TB;
+        for (uint32_t j = 0; j < lim; j++) carry = fr_add(carry, sh[j]);
+        sh[HEAD_TB] = carry;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) result[t] = sh[HEAD_TB];
+  }
+}
+
+// sequential tail of a distance, cut into `gridDim.y` position windows; lanes = instances
+__global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __restrict__ T, DistLayout dl, InstMap im, uint32_t n_inst,
+                                                  const u256* __restrict__ mid, u256* __restrict__ result) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  const bool live = t < n_inst;
+  if (!live) t = n_inst - 1;
+  const uint32_t S = gridDim.y, s = blockIdx.y;
+  const uint64_t tb = im.adv(t, dl) + dl.head_cells, tlb = im.lk(t, dl) + dl.head_lk;
+  WCtx c = make_ctx(st, T, tb, tlb);
+  c.lo = tb + dl.tail_cells * s / S;
+  c.hi = tb + dl.tail_cells * (s + 1) / S;
+  if (!live) c.lo = c.hi = tb;  // padding lanes follow the same control flow but store nothing
+  Gadgets g(c);
+  u256 r;
+  if (dl.metric == M_EUCLID) {
+    r = g.fp_qsqrt(mid[3 * (size_t)t]);
+  } else {
+    u256 ab = mid[3 * (size_t)t], aa = mid[3 * (size_t)t + 1], bb = mid[3 * (size_t)t + 2];
+    u256 as = g.fp_qsqrt(aa);
+    u256 bs = g.fp_qsqrt(bb);
+    u256 den = g.fp_qmul(as, bs);
+    u256 sim = g.fp_qdiv(ab, den);
+    u256 one = g.load_constant(T->c_one_q);
+    r = g.g_sub(one, sim);
+  }
+  if (live && s == S - 1) {
+    result[t] = r;
+    if (c.err) atomicOr(st.err, c.err);
+  }
+}
+
+static uint32_t tail_segments(uint32_t n_inst) {
+  uint32_t groups = (n_inst + 63) / 64;
+  uint32_t s = 4096 / (groups ? groups : 1);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+// runs head + tail for n_inst instances; distances land in `result` (device)
+static int run_distances(const Streams& st, FpEntry* fp, const DistLayout& dl, const InstMap& im, uint32_t n_inst, const u256* A,
+                         const u256* Bv, u256* mid, u256* result) {
+  if (n_inst == 0) return VDB_OK;
+  hipLaunchKernelGGL(k_dist_head, dim3(n_inst), dim3(HEAD_TB), 0, ctx().stream, st, fp->dev, dl, im, A, Bv, mid, result);
+  VDB_LAUNCH_CHECK();
+  if (dl.tail_cells) {
+    hipLaunchKernelGGL(k_dist_tail, dim3((n_inst + 63) / 64, tail_segments(n_inst)), dim3(64), 0, ctx().stream, st, fp->dev, dl, im, n_inst,
+                       mid, result);
+    VDB_LAUNCH_CHECK();
+  }
+  return VDB_OK;
+}
+
+// ------------------------------------------------------------------ nearest_vector (vectordb.rs:122-163)
+__global__ void k_nv_prefix_min(const FpTables* __restrict__ T, const u256* __restrict__ d, uint32_t n, u256* __restrict__ pm) {
+  if (blockIdx.x || threadIdx.x) return;
+  WCtx c{};
+  c.T = T;
+  Gadgets g(c);
+  u256 m = d[0];
+  pm[0] = m;
+  for (uint32_t i = 1; i < n; i++) {
+    u256 x = d[i];
+    if (!g.v_is_neg(from_mont<Fr>(fr_sub(m, x)))) m = x;  // qmin(m, x) = is_neg(m - x) ? m : x
+    pm[i] = m;
+  }
+}
+__global__ __launch_bounds__(64) void k_nv_qmin(Streams st, const FpTables* __restrict__ T, uint64_t base, uint64_t lbase, const u256* __restrict__ d,
+                                                const u256* __restrict__ pm, uint32_t n) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x + 1;
+  if (i >= n) return;
+  WCtx c = make_ctx(st, T, base + (uint64_t)(i - 1) * T->sz.qmin[0], lbase + (uint64_t)(i - 1) * T->sz.qmin[1]);
+  Gadgets g(c);
+  g.fp_qmin(pm[i - 1], d[i]);
+}
+__global__ __launch_bounds__(64) void k_nv_is_equal(Streams st, const FpTables* __restrict__ T, uint64_t base, const u256* __restrict__ d,
+                                                    const u256* __restrict__ pm, uint32_t n, u256* __restrict__ ind) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  WCtx c = make_ctx(st, T, base + 12ull * i, 0);
+  Gadgets g(c);
+  ind[i] = g.g_is_equal(pm[n - 1], d[i]);
+}
+// select_by_indicator per dimension: [0, a0, ind0, s0, a1, ind1, s1, ...]
+__global__ __launch_bounds__(64) void k_nv_select(Streams st, const FpTables* __restrict__ T, uint64_t base, const u256* __restrict__ vectors,
+                                                  const u256* __restrict__ ind, uint32_t n, uint32_t D, u256* __restrict__ result) {
+  uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= D) return;
+  WCtx c = make_ctx(st, T, base + (uint64_t)j * (1 + 3ull * n), 0);
+  u256 s = u256_zero();
+  c.push(s, n > 0);
+  for (uint32_t i = 0; i < n; i++) {
+    u256 a = vectors[(size_t)i * D + j], in = ind[i];
+    if (!u256_is_zero(in)) s = a;
+    c.push(a, false);
+    c.push(in, false);
+    c.push(s, i + 1 < n);
+  }
+  result[j] = s;
+}
+
+// ------------------------------------------------------------------ kmeans (vectordb.rs:225-362)
+struct KmLayout {
+  uint32_t N, D, K;
+  uint64_t per_vec, per_vec_l, assign, assign_l, sizes, per_cluster, per_cluster_l, iter, iter_l;
+};
+__global__ __launch_bounds__(64) void k_km_assign(Streams st, const FpTables* __restrict__ T, KmLayout kl, DistLayout dl, uint64_t ibase, uint64_t ilbase,
+                                                  const u256* __restrict__ dist, u256* __restrict__ ind) {
+  uint32_t v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= kl.N) return;
+  const uint32_t K = kl.K;
+  WCtx c = make_ctx(st, T, ibase + (uint64_t)v * kl.per_vec + (uint64_t)K * dl.total_cells, ilbase + (uint64_t)v * kl.per_vec_l + (uint64_t)K * dl.total_lk);
+  Gadgets g(c);
+  const u256* d = dist + (size_t)v * K;
+  u256 m = d[0];
+  for (uint32_t k = 1; k < K; k++) m = g.fp_qmin(m, d[k]);
+  for (uint32_t k = 0; k < K; k++) {
+    u256 eq = g.g_is_equal(m, d[k]);
+    ind[(size_t)v * K + k] = g.g_select(T->c_one_q, u256_zero(), eq);
+  }
+}
+__global__ void k_km_sizes(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t base, const u256* __restrict__ ind, u256* __restrict__ sizes) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= kl.K) return;
+  WCtx c = make_ctx(st, T, 0, 0);
+  Gadgets g(c);
+  u256 s = ind[k];
+  for (uint32_t v = 1; v < kl.N; v++) {
+    c.pos = base + ((uint64_t)(v - 1) * kl.K + k) * 4;
+    s = g.g_add(s, ind[(size_t)v * kl.K + k]);
+  }
+  sizes[k] = s;
+}
+__global__ __launch_bounds__(64) void k_km_filter(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ vectors,
+                                                  const u256* __restrict__ ind, u256 scale_inv, u256* __restrict__ filt) {
+  uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= kl.K * kl.N) return;
+  uint32_t k = id / kl.N, v = id % kl.N;
+  WCtx c = make_ctx(st, T, cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)v * (8 + 8ull * kl.D), 0);
+  Gadgets g(c);
+  u256 sel = ind[(size_t)v * kl.K + k];
+  u256 iz = g.g_is_zero_inv(sel, u256_is_zero(sel) ? T->one : scale_inv);
+  for (uint32_t j = 0; j < kl.D; j++) filt[((size_t)k * kl.N + v) * kl.D + j] = g.g_select(u256_zero(), vectors[(size_t)v * kl.D + j], iz);
+}
+__global__ __launch_bounds__(64) void k_km_sum(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ filt,
+                                               u256* __restrict__ sums) {
+  uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= kl.K * kl.D) return;
+  uint32_t k = id / kl.D, j = id % kl.D;
+  WCtx c = make_ctx(st, T, 0, 0);
+  Gadgets g(c);
+  const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D);
+  u256 s = filt[((size_t)k * kl.N) * kl.D + j];
+  for (uint32_t v = 1; v < kl.N; v++) {
+    c.pos = base + ((uint64_t)(v - 1) * kl.D + j) * 4;
+    s = g.g_add(filt[((size_t)k * kl.N + v) * kl.D + j], s);  // qadd(vector_j, sum_j)
+  }
+  sums[id] = s;
+}
+__global__ __launch_bounds__(64) void k_km_div(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, uint64_t clbase0,
+                                               const u256* __restrict__ sums, const u256* __restrict__ sizes, u256* __restrict__ cent) {
+  uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  const bool live = id < kl.K * kl.D;
+  if (!live) id = kl.K * kl.D - 1;
+  uint32_t k = id / kl.D, j = id % kl.D;
+  const uint32_t S = gridDim.y, s = blockIdx.y;
+  const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D) + (uint64_t)(kl.N - 1) * kl.D * 4 + (uint64_t)j * T->sz.qdiv[0];
+  const uint64_t lbase = clbase0 + (uint64_t)k * kl.per_cluster_l + (uint64_t)j * T->sz.qdiv[1];
+  WCtx c = make_ctx(st, T, base, lbase);
+  c.lo = base + (uint64_t)T->sz.qdiv[0] * s / S;
+  c.hi = base + (uint64_t)T->sz.qdiv[0] * (s + 1) / S;
+  if (!live) c.lo = c.hi = base;
+  Gadgets g(c);
+  u256 r = g.fp_qdiv(sums[id], sizes[k]);
+  if (live && s == S - 1) {
+    cent[id] = r;
+    if (c.err) atomicOr(st.err, c.err);
+  }
+}
+__global__ void k_push_cells(Streams st, uint64_t pos, u256 a, u256 b, uint32_t n) {
+  if (blockIdx.x || threadIdx.x) return;
+  st.adv[pos] = a;
+  if (st.sel) st.sel[pos] = 0;
+  if (n > 1) {
+    st.adv[pos + 1] = b;
+    if (st.sel) st.sel[pos + 1] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ Poseidon trace (merkle_commitment)
+// cells of PoseidonChip::permutation (halo2-lib community-edition poseidon chip, [UPSTREAM-RECALL])
+__device__ u256 trace_sum(WCtx& c, const FpTables* T, const u256* v, int n) {  // GateChip::sum
+  u256 s = v[0];
+  c.push(v[0], n > 1);
+  for (int i = 1; i < n; i++) {
+    s = fr_add(s, v[i]);
+    c.push(v[i], false);
+    c.push(T->one, false);
+    c.push(s, i + 1 < n);
+  }
+  return s;
+}
+__device__ u256 trace_ip_const(WCtx& c, const FpTables* T, const u256* a, const u256* row, int n) {  // inner_product(a, constants)
+  u256 s;
+  int i0, ng;
+  if (u256_eq(row[0], T->one)) {
+    s = a[0];
+    i0 = 1;
+    ng = n - 1;
+    c.push(a[0], ng > 0);
+  } else {
+    s = u256_zero();
+    i0 = 0;
+    ng = n;
+    c.push(u256_zero(), ng > 0);
+  }
+  int gi = 1;
+  for (int i = i0; i < n; i++, gi++) {
+    s = fr_add(s, fr_mul(a[i], row[i]));
+    c.push(a[i], false);
+    c.push(row[i], false);
+    c.push(s, gi < ng);
+  }
+  return s;
+}
+__device__ void trace_sbox(Gadgets& g, u256& x, const u256& cst) {
+  u256 x2 = g.g_mul(x, x);
+  u256 x4 = g.g_mul(x2, x2);
+  x = g.g_mul_add(x, x4, cst);
+}
+__device__ void trace_dense(WCtx& c, const FpTables* T, u256 st[PSD_T], const u256 m[PSD_T][PSD_T]) {
+  u256 r[PSD_T];
+  for (int i = 0; i < PSD_T; i++) r[i] = trace_ip_const(c, T, st, m[i], PSD_T);
+  for (int i = 0; i < PSD_T; i++) st[i] = r[i];
+}
+__device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
+  Gadgets g(c);
+  {
+    u256 v[2] = {st[0], sp->start[0][0]};
+    st[0] = trace_sum(c, T, v, 2);
+  }
+  for (int i = 0; i < n_in; i++) {
+    u256 v[3] = {st[1 + i], in[i], sp->start[0][1 + i]};
+    st[1 + i] = trace_sum(c, T, v, 3);
+  }
+  for (int i = n_in + 1, k = 0; i < PSD_T; i++, k++) {
+    u256 cst = sp->start[0][i];
+    if (k == 0) cst = fr_add(cst, T->one);
+    u256 v[2] = {st[i], cst};
+    st[i] = trace_sum(c, T, v, 2);
+  }
+  for (int r = 1; r < PSD_HALF; r++) {
+    for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], sp->start[r][i]);
+    trace_dense(c, T, st, sp->mds);
+  }
+  for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], sp->start[PSD_HALF][i]);
+  trace_dense(c, T, st, sp->pre_sparse);
+  for (int p = 0; p < PSD_RP; p++) {
+    trace_sbox(g, st[0], sp->partial[p]);
+    u256 r[PSD_T];
+    r[0] = trace_ip_const(c, T, st, sp->sparse_row[p], PSD_T);
+    for (int i = 1; i < PSD_T; i++) r[i] = g.g_mul_add(st[0], sp->sparse_col[p][i - 1], st[i]);
+    for (int i = 0; i < PSD_T; i++) st[i] = r[i];
+  }
+  for (int r = 0; r < PSD_HALF - 1; r++) {
+    for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], sp->end[r][i]);
+    trace_dense(c, T, st, sp->mds);
+  }
+  u256 z = u256_zero();
+  for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], z);
+  trace_dense(c, T, st, sp->mds);
+}
+HD uint32_t perm_cells(int n_in) { return (n_in == 2 ? 18u : (n_in == 1 ? 15u : 12u)) + 2238u; }
+
+// sponge states before every permutation of every leaf (value only)
+__global__ __launch_bounds__(64) void k_mk_leaf_states(const PoseidonSpec* __restrict__ sp, const u256* __restrict__ vectors, uint32_t n, uint32_t D,
+                                                       uint32_t nperm, u256* __restrict__ states /* n * nperm * 3 */, u256* __restrict__ leaves) {
+  uint32_t v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= n) return;
+  u256 st[PSD_T] = {sp->cap, u256_zero(), u256_zero()};
+  const u256* msg = vectors + (size_t)v * D;
+  uint32_t off = 0;
+  for (uint32_t p = 0; p < nperm; p++) {
+    for (int i = 0; i < PSD_T; i++) states[((size_t)v * nperm + p) * PSD_T + i] = st[i];
+    int cnt = off < D ? (int)(D - off < 2 ? D - off : 2) : 0;
+    u256 in[PSD_RATE] = {cnt > 0 ? msg[off] : u256_zero(), cnt > 1 ? msg[off + 1] : u256_zero()};
+    psd_permute_absorb(sp, st, in, cnt);
+    off += (uint32_t)cnt;
+  }
+  leaves[v] = st[1];
+}
+// one thread per leaf permutation: the trace cells
+__global__ __launch_bounds__(64) void k_mk_leaf_trace(Streams stq, const FpTables* __restrict__ T, const PoseidonSpec* __restrict__ sp,
+                                                      const u256* __restrict__ vectors, uint32_t n, uint32_t D, uint32_t nperm, uint64_t base,
+                                                      uint64_t leaf_cells, const u256* __restrict__ states) {
+  uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= n * nperm) return;
+  uint32_t v = id / nperm, p = id % nperm;
+  uint32_t off = 2 * p;
+  int cnt = off < D ? (int)(D - off < 2 ? D - off : 2) : 0;
+  // permutations 0..p-1 of a leaf are full (2 inputs) except possibly the one before the padding-only one
+  uint64_t pos = base + (uint64_t)v * leaf_cells;
+  for (uint32_t q = 0; q < p; q++) {
+    uint32_t o = 2 * q;
+    pos += perm_cells(o < D ? (int)(D - o < 2 ? D - o : 2) : 0);
+  }
+  WCtx c = make_ctx(stq, T, pos, 0);
+  u256 st[PSD_T];
+  for (int i = 0; i < PSD_T; i++) st[i] = states[((size_t)v * nperm + p) * PSD_T + i];
+  const u256* msg = vectors + (size_t)v * D;
+  u256 in[PSD_RATE] = {cnt > 0 ? msg[off] : u256_zero(), cnt > 1 ? msg[off + 1] : u256_zero()};
+  trace_permutation(c, T, sp, st, in, cnt);
+}
+// one thread per tree node: two permutations (absorb [l, r], then padding only)
+__global__ __launch_bounds__(64) void k_mk_node(Streams stq, const FpTables* __restrict__ T, const PoseidonSpec* __restrict__ sp, const u256* __restrict__ in_lv,
+                                                uint32_t n_out, uint64_t base, u256* __restrict__ out_lv) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_out) return;
+  WCtx c = make_ctx(stq, T, base + (uint64_t)t * (perm_cells(2) + perm_cells(0)), 0);
+  u256 st[PSD_T] = {sp->cap, u256_zero(), u256_zero()};
+  u256 in[PSD_RATE] = {in_lv[2 * t], in_lv[2 * t + 1]};
+  trace_permutation(c, T, sp, st, in, 2);
+  trace_permutation(c, T, sp, st, in, 0);
+  out_lv[t] = st[1];
+}
+
+// ------------------------------------------------------------------ layout (halo2-base assign_threads_in)
+// break points from the gate-start bits: the row walk of GateThreadBuilder::assign_all.  A column that
+// starts at stream cell S breaks at the first row r in {M-3, M-2 (if that cell starts a gate), M-1}.
+__global__ void k_layout_plan(const uint8_t* __restrict__ sel, uint64_t n_cells, uint64_t max_rows, uint64_t* __restrict__ bp, uint64_t cap,
+                              uint64_t* __restrict__ n_bp) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t S = 0, cnt = 0;
+  const uint64_t M = max_rows;
+  for (;;) {
+    uint64_t r;
+    if (M >= 3 && S + M - 3 < n_cells && sel[S + M - 3]) r = M - 3;
+    else if (M >= 2 && S + M - 2 < n_cells && sel[S + M - 2]) r = M - 2;
+    else r = M - 1;
+    if (S + r >= n_cells) break;
+    if (cnt < cap) bp[cnt] = r;
+    cnt++;
+    S += r;
+  }
+  *n_bp = cnt;
+}
+__global__ void k_layout_starts(const uint64_t* __restrict__ bp, uint64_t n_bp, uint64_t* __restrict__ starts) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t s = 0;
+  starts[0] = 0;
+  for (uint64_t i = 0; i < n_bp; i++) {
+    s += bp[i];
+    starts[i + 1] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_layout_columns(const u256* __restrict__ stream, uint64_t n_cells, const uint64_t* __restrict__ starts,
+                                                        const uint64_t* __restrict__ bp, uint64_t n_bp, uint32_t k, u256* __restrict__ cols,
+                                                        const u256* __restrict__ blind, uint32_t n_blind) {
+  const uint64_t rows = 1ull << k;
+  uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t total = (n_bp + 1) * rows;
+  if (idx >= total) return;
+  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t start = starts[col];
+  uint64_t len = col < n_bp ? bp[col] + 1 : n_cells - start;  // cells held by this column
+  u256 v = u256_zero();
+  if (row < len) v = ld256(stream + start + row);
+  else if (blind && row >= rows - n_blind) v = ld256(blind + col * n_blind + (row - (rows - n_blind)));
+  st256(cols + idx, v);
+}
+__global__ __launch_bounds__(256) void k_layout_lookup(const u256* __restrict__ lk, uint64_t n_cells, uint64_t max_rows, uint32_t k, uint64_t n_cols,
+                                                       u256* __restrict__ cols, const u256* __restrict__ blind, uint32_t n_blind) {
+  const uint64_t rows = 1ull << k;
+  uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_cols * rows) return;
+  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t src = col * max_rows + row;
+  u256 v = u256_zero();
+  if (row < max_rows && src < n_cells) v = ld256(lk + src);
+  else if (blind && row >= rows - n_blind) v = ld256(blind + col * n_blind + (row - (rows - n_blind)));
+  st256(cols + idx, v);
+}
+
+// ------------------------------------------------------------------ helpers for the host-pointer ABI
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    return VDB_OK;
+  }
+  template <class U>
+  U* as() { return (U*)p; }
+};
+#define TRY(x)             \
+  do {                     \
+    int _rc = (x);         \
+    if (_rc) return _rc;   \
+  } while (0)
+
+static int check_err_flag(int* derr) {
+  int h = 0;
+  VDB_HIP(hipMemcpyAsync(&h, derr, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  if (h) {
+    set_error("data-dependent failure the reference turns into a panic (division by zero / index out of range)");
+    return VDB_ERR_DOMAIN;
+  }
+  return VDB_OK;
+}
+
+// ---- device-level drivers -------------------------------------------------------------------
+int wit_distance_dev(FpEntry* fp, int metric, const u256* a, const u256* b, size_t n_pairs, size_t dim, Streams st, uint64_t adv_off,
+                     uint64_t lk_off, u256* result) {
+  DistLayout dl;
+  TRY(dist_layout(fp->host, metric, dim, &dl));
+  InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 1};
+  u256* mid = (u256*)scratch_get(0, n_pairs * 3 * sizeof(u256) + 64);
+  if (!mid) return VDB_ERR_OOM;
+  return run_distances(st, fp, dl, im, (uint32_t)n_pairs, a, b, mid, result);
+}
+
+struct NvLayout {
+  uint64_t dist, dist_l, qmin, qmin_l, iseq, sel, total, total_l;
+};
+static int nv_layout(FpEntry* fp, int metric, size_t n, size_t dim, DistLayout* dl, NvLayout* o) {
+  TRY(dist_layout(fp->host, metric, dim, dl));
+  o->dist = n * dl->total_cells;
+  o->dist_l = n * dl->total_lk;
+  o->qmin = (n - 1) * (uint64_t)fp->host.sz.qmin[0];
+  o->qmin_l = (n - 1) * (uint64_t)fp->host.sz.qmin[1];
+  o->iseq = 12ull * n;
+  o->sel = dim * (1 + 3ull * n);
+  o->total = o->dist + o->qmin + o->iseq + o->sel;
+  o->total_l = o->dist_l + o->qmin_l;
+  return VDB_OK;
+}
+int wit_nearest_dev(FpEntry* fp, int metric, const u256* query, const u256* vectors, size_t n, size_t dim, Streams st, uint64_t adv_off,
+                    uint64_t lk_off, u256* ind, u256* result) {
+  DistLayout dl;
+  NvLayout nl;
+  TRY(nv_layout(fp, metric, n, dim, &dl, &nl));
+  InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 0xffffffffu};  // (vector_i, query)
+  u256* mid = (u256*)scratch_get(0, (n * 5 + 8) * sizeof(u256));
+  if (!mid) return VDB_ERR_OOM;
+  u256* dist = mid + 3 * n;
+  u256* pm = dist + n;
+  TRY(run_distances(st, fp, dl, im, (uint32_t)n, vectors, query, mid, dist));
+  hipStream_t s = ctx().stream;
+  hipLaunchKernelGGL(k_nv_prefix_min, dim3(1), dim3(1), 0, s, fp->dev, dist, (uint32_t)n, pm);
+  VDB_LAUNCH_CHECK();
+  if (n > 1) {
+    hipLaunchKernelGGL(k_nv_qmin, dim3((unsigned)((n - 1 + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist, lk_off + nl.dist_l, dist, pm,
+                       (uint32_t)n);
+    VDB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_nv_is_equal, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin, dist, pm, (uint32_t)n,
+                     ind);
+  VDB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_nv_select, dim3((unsigned)((dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin + nl.iseq, vectors, ind,
+                     (uint32_t)n, (uint32_t)dim, result);
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+static int km_layout(FpEntry* fp, int metric, size_t n, size_t dim, size_t K, DistLayout* dl, KmLayout* kl) {
+  TRY(dist_layout(fp->host, metric, dim, dl));
+  const Sizes& z = fp->host.sz;
+  kl->N = (uint32_t)n;
+  kl->D = (uint32_t)dim;
+  kl->K = (uint32_t)K;
+  kl->per_vec = K * dl->total_cells + (K - 1) * (uint64_t)z.qmin[0] + K * 20ull;
+  kl->per_vec_l = K * dl->total_lk + (K - 1) * (uint64_t)z.qmin[1];
+  kl->assign = n * kl->per_vec;
+  kl->assign_l = n * kl->per_vec_l;
+  kl->sizes = (n - 1) * K * 4ull;
+  kl->per_cluster = n * (8 + 8ull * dim) + (n - 1) * dim * 4ull + dim * (uint64_t)z.qdiv[0];
+  kl->per_cluster_l = dim * (uint64_t)z.qdiv[1];
+  kl->iter = kl->assign + kl->sizes + K * kl->per_cluster;
+  kl->iter_l = kl->assign_l + K * kl->per_cluster_l;
+  return VDB_OK;
+}
+int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_t dim, size_t K, size_t I, int zero_cached, Streams st,
+                   uint64_t adv_off, uint64_t lk_off, u256* cent_out, u256* ind_out) {
+  DistLayout dl;
+  KmLayout kl;
+  TRY(km_layout(fp, metric, n, dim, K, &dl, &kl));
+  hipStream_t s = ctx().stream;
+  size_t need = (n * K * 4 + K * dim * 2 + K + K * n * dim + 16) * sizeof(u256);
+  u256* buf = (u256*)scratch_get(0, need);
+  if (!buf) return VDB_ERR_OOM;
+  u256* mid = buf;
+  u256* dist = mid + 3 * n * K;
+  u256* cent = dist + n * K;
+  u256* sums = cent + K * dim;
+  u256* sizes = sums + K * dim;
+  u256* filt = sizes + K;
+  // preamble: load_constant(quantization(1.0)); load_zero()
+  hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, adv_off, fp->host.c_one_q, u256_zero(), zero_cached ? 1u : 2u);
+  VDB_LAUNCH_CHECK();
+  uint64_t pos = adv_off + (zero_cached ? 1 : 2), lpos = lk_off;
+  VDB_HIP(hipMemcpyAsync(cent, vectors, K * dim * sizeof(u256), hipMemcpyDeviceToDevice, s));
+  u256 scale_inv = mont_inv<Fr>(fp->host.scale);
+  for (size_t it = 0; it < I; it++) {
+    InstMap im{pos, lpos, (uint32_t)K, kl.per_vec, kl.per_vec_l, (uint32_t)K, (uint32_t)K};  // distance(centroid_k, vector_v)
+    TRY(run_distances(st, fp, dl, im, (uint32_t)(n * K), cent, vectors, mid, dist));
+    hipLaunchKernelGGL(k_km_assign, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, dl, pos, lpos, dist, ind_out);
+    VDB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_km_sizes, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, pos + kl.assign, ind_out, sizes);
+    VDB_LAUNCH_CHECK();
+    uint64_t cb = pos + kl.assign + kl.sizes, clb = lpos + kl.assign_l;
+    hipLaunchKernelGGL(k_km_filter, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, vectors, ind_out, scale_inv, filt);
+    VDB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_km_sum, dim3((unsigned)((K * dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, filt, sums);
+    VDB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_km_div, dim3((unsigned)((K * dim + 63) / 64), 8), dim3(64), 0, s, st, fp->dev, kl, cb, clb, sums, sizes, cent);
+    VDB_LAUNCH_CHECK();
+    pos += kl.iter;
+    lpos += kl.iter_l;
+  }
+  VDB_HIP(hipMemcpyAsync(cent_out, cent, K * dim * sizeof(u256), hipMemcpyDeviceToDevice, s));
+  return VDB_OK;
+}
+
+struct MkLayout {
+  uint32_t nperm;
+  uint64_t leaf_cells, leaves, n_leaves_pow2, zero_cell, total;
+};
+static void mk_layout(size_t n, size_t dim, int zero_cached, MkLayout* o) {
+  o->nperm = (uint32_t)((dim + 1) / 2 + (dim % 2 == 0 ? 1 : 0));
+  o->leaf_cells = 0;
+  for (uint32_t p = 0; p < o->nperm; p++) {
+    size_t off = 2 * (size_t)p;
+    o->leaf_cells += perm_cells(off < dim ? (int)(dim - off < 2 ? dim - off : 2) : 0);
+  }
+  o->leaves = n * o->leaf_cells;
+  uint64_t lp = 1;
+  while (lp < n) lp <<= 1;
+  o->n_leaves_pow2 = lp;
+  o->zero_cell = (lp > n && !zero_cached) ? 1 : 0;
+  o->total = o->leaves + o->zero_cell + (lp - 1) * (uint64_t)(perm_cells(2) + perm_cells(0));
+}
+int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, Streams st, uint64_t adv_off, u256* root_out) {
+  FpEntry* fp;
+  TRY(get_fp(48, 13, &fp));  // only GateChip primitives are used: P and L are irrelevant
+  const PoseidonSpec* sp;
+  TRY(poseidon_spec_dev(&sp, nullptr));
+  MkLayout ml;
+  mk_layout(n, dim, zero_cached, &ml);
+  hipStream_t s = ctx().stream;
+  size_t need = (n * ml.nperm * PSD_T + 2 * ml.n_leaves_pow2 + 8) * sizeof(u256);
+  u256* buf = (u256*)scratch_get(0, need);
+  if (!buf) return VDB_ERR_OOM;
+  u256* states = buf;
+  u256* lva = states + n * ml.nperm * PSD_T;
+  u256* lvb = lva + ml.n_leaves_pow2;
+  VDB_HIP(hipMemsetAsync(lva, 0, ml.n_leaves_pow2 * sizeof(u256), s));
+  hipLaunchKernelGGL(k_mk_leaf_states, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sp, vectors, (uint32_t)n, (uint32_t)dim, ml.nperm, states, lva);
+  VDB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_mk_leaf_trace, dim3((unsigned)((n * ml.nperm + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, vectors, (uint32_t)n, (uint32_t)dim,
+                     ml.nperm, adv_off, ml.leaf_cells, states);
+  VDB_LAUNCH_CHECK();
+  uint64_t pos = adv_off + ml.leaves;
+  if (ml.zero_cell) {
+    hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, pos, u256_zero(), u256_zero(), 1u);
+    VDB_LAUNCH_CHECK();
+    pos += 1;
+  }
+  uint64_t lv = ml.n_leaves_pow2;
+  while (lv > 1) {
+    uint64_t no = lv / 2;
+    hipLaunchKernelGGL(k_mk_node, dim3((unsigned)((no + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, lva, (uint32_t)no, pos, lvb);
+    VDB_LAUNCH_CHECK();
+    pos += no * (uint64_t)(perm_cells(2) + perm_cells(0));
+    std::swap(lva, lvb);
+    lv = no;
+  }
+  VDB_HIP(hipMemcpyAsync(root_out, lva, sizeof(u256), hipMemcpyDeviceToDevice, s));
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+// upload helper for the host-pointer entry points
+static int upload(DevBuf& d, const void* src, size_t bytes) {
+  TRY(d.alloc(bytes));
+  if (bytes) VDB_HIP(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  return VDB_OK;
+}
+static int download(void* dst, const void* src, size_t bytes) {
+  if (dst && bytes) VDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+  return VDB_OK;
+}
+struct HostStreams {
+  DevBuf adv, sel, lk, err;
+  Streams st;
+  int init(uint64_t cells, uint64_t lookups, bool want_sel) {
+    TRY(adv.alloc(cells * sizeof(u256)));
+    TRY(lk.alloc(lookups * sizeof(u256)));
+    if (want_sel) TRY(sel.alloc(cells));
+    TRY(err.alloc(sizeof(int)));
+    VDB_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx().stream));
+    st.adv = adv.as<u256>();
+    st.sel = want_sel ? sel.as<uint8_t>() : nullptr;
+    st.lk = lk.as<u256>();
+    st.err = err.as<int>();
+    return VDB_OK;
+  }
+  int finish(vdb_fr* stream_out, vdb_fr* lookup_out, uint8_t* sel_out, uint64_t cells, uint64_t lookups) {
+    TRY(download(stream_out, st.adv, cells * sizeof(u256)));
+    TRY(download(lookup_out, st.lk, lookups * sizeof(u256)));
+    if (sel_out && st.sel) TRY(download(sel_out, st.sel, cells));
+    return check_err_flag(st.err);
+  }
+};
+
+extern "C" {
+
+int vdb_fp_quantize(uint32_t precision_bits, const double* x, vdb_fr* out, size_t n) {
+  VDB_ARG(x && out && precision_bits >= 32 && precision_bits <= 63, "bad argument");
+  for (size_t i = 0; i < n; i++) {
+    u256 q = quantize_host(precision_bits, x[i]);
+    memcpy(&out[i], &q, 32);
+  }
+  return VDB_OK;
+}
+int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr* x, double* out, size_t n) {
+  VDB_ARG(x && out && precision_bits >= 32 && precision_bits <= 63, "bad argument");
+  for (size_t i = 0; i < n; i++) {
+    u256 v;
+    memcpy(&v, &x[i], 32);
+    out[i] = dequantize_host(precision_bits, v);
+  }
+  return VDB_OK;
+}
+
+int vdb_wit_distance_size(int metric, uint32_t P, uint32_t L, size_t n_pairs, size_t dim, uint64_t* cells, uint64_t* lookups) {
+  VDB_REQUIRE_INIT();
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  DistLayout dl;
+  TRY(dist_layout(fp->host, metric, dim, &dl));
+  if (cells) *cells = n_pairs * dl.total_cells;
+  if (lookups) *lookups = n_pairs * dl.total_lk;
+  return VDB_OK;
+}
+int vdb_wit_distance(int metric, uint32_t P, uint32_t L, const vdb_fr* a, const vdb_fr* b, size_t n_pairs, size_t dim, vdb_fr* stream_out,
+                     vdb_fr* lookup_out, uint8_t* selector_out, vdb_fr* result_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(a && b && dim > 0, "null pointer or dim == 0");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  uint64_t cells, lookups;
+  TRY(vdb_wit_distance_size(metric, P, L, n_pairs, dim, &cells, &lookups));
+  if (n_pairs == 0) return VDB_OK;
+  DevBuf da, db, dres;
+  HostStreams hs;
+  TRY(upload(da, a, n_pairs * dim * sizeof(u256)));
+  TRY(upload(db, b, n_pairs * dim * sizeof(u256)));
+  TRY(dres.alloc(n_pairs * sizeof(u256)));
+  TRY(hs.init(cells, lookups, selector_out != nullptr));
+  TRY(wit_distance_dev(fp, metric, da.as<u256>(), db.as<u256>(), n_pairs, dim, hs.st, 0, 0, dres.as<u256>()));
+  TRY(download(result_out, dres.p, n_pairs * sizeof(u256)));
+  return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
+}
+
+int vdb_wit_nearest_size(int metric, uint32_t P, uint32_t L, size_t n, size_t dim, uint64_t* cells, uint64_t* lookups) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(n > 0, "empty database");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  DistLayout dl;
+  NvLayout nl;
+  TRY(nv_layout(fp, metric, n, dim, &dl, &nl));
+  if (cells) *cells = nl.total;
+  if (lookups) *lookups = nl.total_l;
+  return VDB_OK;
+}
+int vdb_wit_nearest(int metric, uint32_t P, uint32_t L, const vdb_fr* query, const vdb_fr* vectors, size_t n, size_t dim, vdb_fr* stream_out,
+                    vdb_fr* lookup_out, uint8_t* selector_out, vdb_fr* indicator_out, vdb_fr* result_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(query && vectors && n > 0 && dim > 0, "null pointer or empty input");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  uint64_t cells, lookups;
+  TRY(vdb_wit_nearest_size(metric, P, L, n, dim, &cells, &lookups));
+  DevBuf dq, dv, dind, dres;
+  HostStreams hs;
+  TRY(upload(dq, query, dim * sizeof(u256)));
+  TRY(upload(dv, vectors, n * dim * sizeof(u256)));
+  TRY(dind.alloc(n * sizeof(u256)));
+  TRY(dres.alloc(dim * sizeof(u256)));
+  TRY(hs.init(cells, lookups, selector_out != nullptr));
+  TRY(wit_nearest_dev(fp, metric, dq.as<u256>(), dv.as<u256>(), n, dim, hs.st, 0, 0, dind.as<u256>(), dres.as<u256>()));
+  TRY(download(indicator_out, dind.p, n * sizeof(u256)));
+  TRY(download(result_out, dres.p, dim * sizeof(u256)));
+  return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
+}
+
+int vdb_wit_kmeans_size(int metric, uint32_t P, uint32_t L, size_t n, size_t dim, size_t K, size_t I, int zero_cached, uint64_t* cells,
+                        uint64_t* lookups) {
+  VDB_REQUIRE_INIT();
+  if (!(K < n) || K == 0) {
+    set_error("kmeans requires 0 < K < #vectors (vectordb.rs:238 assert)");
+    return VDB_ERR_DOMAIN;
+  }
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  DistLayout dl;
+  KmLayout kl;
+  TRY(km_layout(fp, metric, n, dim, K, &dl, &kl));
+  if (cells) *cells = (zero_cached ? 1 : 2) + I * kl.iter;
+  if (lookups) *lookups = I * kl.iter_l;
+  return VDB_OK;
+}
+int vdb_wit_kmeans_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* vectors_dev, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
+                       vdb_fr* stream_dev, vdb_fr* lookup_dev, uint8_t* selector_dev, vdb_fr* centroids_dev, vdb_fr* indicators_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(vectors_dev && stream_dev && lookup_dev && centroids_dev && indicators_dev && dim > 0, "null pointer");
+  uint64_t cells, lookups;
+  TRY(vdb_wit_kmeans_size(metric, P, L, n, dim, K, I, zero_cached, &cells, &lookups));
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  int* derr = (int*)scratch_get(1, 64);
+  if (!derr) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr};
+  TRY(wit_kmeans_dev(fp, metric, as_u256(vectors_dev), n, dim, K, I, zero_cached, st, 0, 0, as_u256(centroids_dev), as_u256(indicators_dev)));
+  return check_err_flag(derr);
+}
+int vdb_wit_kmeans(int metric, uint32_t P, uint32_t L, const vdb_fr* vectors, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
+                   vdb_fr* stream_out, vdb_fr* lookup_out, uint8_t* selector_out, vdb_fr* centroids_out, vdb_fr* indicators_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(vectors && dim > 0, "null pointer");
+  uint64_t cells, lookups;
+  TRY(vdb_wit_kmeans_size(metric, P, L, n, dim, K, I, zero_cached, &cells, &lookups));
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  DevBuf dv, dc, di;
+  HostStreams hs;
+  TRY(upload(dv, vectors, n * dim * sizeof(u256)));
+  TRY(dc.alloc(K * dim * sizeof(u256)));
+  TRY(di.alloc(n * K * sizeof(u256)));
+  TRY(hs.init(cells, lookups, selector_out != nullptr));
+  TRY(wit_kmeans_dev(fp, metric, dv.as<u256>(), n, dim, K, I, zero_cached, hs.st, 0, 0, dc.as<u256>(), di.as<u256>()));
+  TRY(download(centroids_out, dc.p, K * dim * sizeof(u256)));
+  TRY(download(indicators_out, di.p, n * K * sizeof(u256)));
+  return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
+}
+
+int vdb_wit_merkle_size(size_t n, size_t dim, int zero_cached, uint64_t* cells) {
+  VDB_ARG(n > 0 && cells, "empty database");
+  MkLayout ml;
+  mk_layout(n, dim, zero_cached, &ml);
+  *cells = ml.total;
+  return VDB_OK;
+}
+int vdb_wit_merkle_dev(const vdb_fr* vectors_dev, size_t n, size_t dim, int zero_cached, vdb_fr* stream_dev, uint8_t* selector_dev, vdb_fr* root_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(vectors_dev && stream_dev && root_dev && n > 0, "null pointer");
+  Streams st{as_u256(stream_dev), selector_dev, nullptr, nullptr};
+  return wit_merkle_dev(as_u256(vectors_dev), n, dim, zero_cached, st, 0, as_u256(root_dev));
+}
+int vdb_wit_merkle(const vdb_fr* vectors, size_t n, size_t dim, int zero_cached, vdb_fr* stream_out, uint8_t* selector_out, vdb_fr* root_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(vectors && n > 0, "null pointer or empty database");
+  uint64_t cells;
+  TRY(vdb_wit_merkle_size(n, dim, zero_cached, &cells));
+  DevBuf dv, droot;
+  HostStreams hs;
+  TRY(upload(dv, vectors, n * dim * sizeof(u256)));
+  TRY(droot.alloc(sizeof(u256)));
+  TRY(hs.init(cells, 0, selector_out != nullptr));
+  TRY(wit_merkle_dev(dv.as<u256>(), n, dim, zero_cached, hs.st, 0, droot.as<u256>()));
+  TRY(download(root_out, droot.p, sizeof(u256)));
+  return hs.finish(stream_out, nullptr, selector_out, cells, 0);
+}
+
+// ---- b4 layout ---------------------------------------------------------------------------------
+int vdb_layout_plan_dev(const uint8_t* selector_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t* break_points_out, uint64_t cap,
+                        uint64_t* n_break_points) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(selector_dev && n_break_points && k >= 3 && k <= 28 && ((uint64_t)1 << k) > minimum_rows + 4, "bad argument");
+  uint64_t max_rows = ((uint64_t)1 << k) - minimum_rows;
+  uint64_t est = n_cells / (max_rows - 3) + 2;
+  uint64_t* d = (uint64_t*)scratch_get(1, (est + 1) * sizeof(uint64_t));
+  if (!d) return VDB_ERR_OOM;
+  hipLaunchKernelGGL(k_layout_plan, dim3(1), dim3(1), 0, ctx().stream, selector_dev, n_cells, max_rows, d + 1, est, d);
+  VDB_LAUNCH_CHECK();
+  uint64_t nbp = 0;
+  VDB_HIP(hipMemcpyAsync(&nbp, d, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  *n_break_points = nbp;
+  if (break_points_out) {
+    VDB_ARG(cap >= nbp, "break point buffer too small");
+    VDB_HIP(hipMemcpy(break_points_out, d + 1, nbp * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return VDB_OK;
+}
+int vdb_layout_plan(const uint8_t* selector, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t* break_points_out, uint64_t cap,
+                    uint64_t* n_break_points) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(selector, "null pointer");
+  DevBuf ds;
+  TRY(upload(ds, selector, n_cells));
+  return vdb_layout_plan_dev(ds.as<uint8_t>(), n_cells, k, minimum_rows, break_points_out, cap, n_break_points);
+}
+int vdb_layout_columns_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, vdb_fr* cols_dev,
+                           const vdb_fr* blind_dev, uint32_t n_blind) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(stream_dev && cols_dev && (break_points || n_bp == 0) && k <= 28, "bad argument");
+  const uint64_t rows = 1ull << k;
+  uint64_t sum = 0;
+  for (uint64_t i = 0; i < n_bp; i++) {
+    VDB_ARG(break_points[i] < rows, "break point beyond the column height");
+    sum += break_points[i];
+  }
+  VDB_ARG(sum <= n_cells && n_cells - sum <= rows, "break points do not match the stream length");
+  uint64_t* d = (uint64_t*)scratch_get(1, (2 * n_bp + 2) * sizeof(uint64_t));
+  if (!d) return VDB_ERR_OOM;
+  uint64_t* dbp = d;
+  uint64_t* dst = d + n_bp;
+  if (n_bp) VDB_HIP(hipMemcpyAsync(dbp, break_points, n_bp * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
+  hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
+  VDB_LAUNCH_CHECK();
+  uint64_t total = (n_bp + 1) * rows;
+  hipLaunchKernelGGL(k_layout_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(stream_dev), n_cells, dst, dbp, n_bp, k,
+                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipStreamSynchronize(ctx().stream));  // break_points is a host buffer the caller may free
+  return VDB_OK;
+}
+int vdb_layout_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr* cols_dev, uint64_t n_cols,
+                          const vdb_fr* blind_dev, uint32_t n_blind) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols_dev && (lookup_dev || n_cells == 0) && k <= 28, "bad argument");
+  uint64_t max_rows = ((uint64_t)1 << k) - minimum_rows;
+  VDB_ARG(n_cols * max_rows >= n_cells, "not enough lookup columns");
+  if (n_cols == 0) return VDB_OK;
+  uint64_t total = n_cols << k;
+  hipLaunchKernelGGL(k_layout_lookup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(lookup_dev), n_cells, max_rows, k, n_cols,
+                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_layout_columns(const vdb_fr* stream, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, const vdb_fr* lookup, uint64_t n_lookup,
+                       uint32_t k, uint32_t minimum_rows, vdb_fr* advice_cols_out, vdb_fr* lookup_cols_out, uint64_t n_lookup_cols) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(stream && advice_cols_out, "null pointer");
+  const uint64_t rows = 1ull << k;
+  DevBuf ds, dc, dl, dlc;
+  TRY(upload(ds, stream, n_cells * sizeof(u256)));
+  TRY(dc.alloc((n_bp + 1) * rows * sizeof(u256)));
+  TRY(vdb_layout_columns_dev(ds.as<vdb_fr>(), n_cells, break_points, n_bp, k, dc.as<vdb_fr>(), nullptr, 0));
+  TRY(download(advice_cols_out, dc.p, (n_bp + 1) * rows * sizeof(u256)));
+  if (lookup_cols_out && n_lookup_cols) {
+    TRY(upload(dl, lookup, n_lookup * sizeof(u256)));
+    TRY(dlc.alloc(n_lookup_cols * rows * sizeof(u256)));
+    TRY(vdb_layout_lookup_dev(dl.as<vdb_fr>(), n_lookup, k, minimum_rows, dlc.as<vdb_fr>(), n_lookup_cols, nullptr, 0));
+    TRY(download(lookup_cols_out, dlc.p, n_lookup_cols * rows * sizeof(u256)));
+  }
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+
+}  // extern "C"

@@ -76,6 +76,59 @@ int vdb_fr_batch_invert(const vdb_fr *in, vdb_fr *out, size_t n);
  * reports Fr multiplications per second (kernel time only) */
 int vdb_bench_fr_mul(size_t threads, size_t iters, double *mul_per_sec);
 
+/* ---- a2/a3/a18 fixed-point staging: replaces FixedPointChip::{quantization, dequantization} and
+ *      FixedPointVectorInstructions::{quantize_vector, dequantize_vector}
+ *      (src/gadget/fixed_point.rs:104-136, src/gadget/fixed_point_vec.rs:29-51).  Host side, exact. ---- */
+int vdb_fp_quantize(uint32_t precision_bits, const double *x, vdb_fr *out, size_t n);
+int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr *x, double *out, size_t n);
+
+/* ---- b5 witness streams.  Each call emits exactly the cells the Rust gadget pushes into
+ *      halo2-base `Context.advice` (stream_out) and `cells_to_lookup` (lookup_out), in order, for
+ *      already-assigned quantized inputs; sizes come from the matching *_size call.
+ *      metric: 0 euclidean, 1 cosine, 2 manhattan (DistanceChip, src/gadget/distance.rs:97-195).
+ *      selector_out (optional, 1 byte per advice cell) marks gate starts — the keygen-side information
+ *      from which vdb_layout_plan derives the break points that the reference pins in configs/*.json
+ *      (src/scaffold/mod.rs:272, 285-287).  VDB_ERR_DOMAIN replaces the reference's panics. ---------- */
+int vdb_wit_distance_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n_pairs, size_t dim, uint64_t *cells, uint64_t *lookups);
+/* DistanceChip::{euclidean,cosine,manhattan}_distance for n_pairs independent (a_i, b_i) */
+int vdb_wit_distance(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a, const vdb_fr *b, size_t n_pairs, size_t dim,
+                     vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *result_out);
+/* VectorDBChip::nearest_vector (src/gadget/vectordb.rs:122-163): indicator_out n raw 0/1 field bits */
+int vdb_wit_nearest_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, uint64_t *cells, uint64_t *lookups);
+int vdb_wit_nearest(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *query, const vdb_fr *vectors, size_t n, size_t dim,
+                    vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *indicator_out, vdb_fr *result_out);
+/* VectorDBChip::kmeans::<K, I> (src/gadget/vectordb.rs:225-362): centroids K x dim, indicators n x K
+ * (quantized 1.0 / 0).  zero_cached: Context::load_zero already called earlier in this context. */
+int vdb_wit_kmeans_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
+                        uint64_t *cells, uint64_t *lookups);
+int vdb_wit_kmeans(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors, size_t n, size_t dim, size_t K, size_t I,
+                   int zero_cached, vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *centroids_out, vdb_fr *indicators_out);
+int vdb_wit_kmeans_dev(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors_dev, size_t n, size_t dim, size_t K, size_t I,
+                       int zero_cached, vdb_fr *stream_dev, vdb_fr *lookup_dev, uint8_t *selector_dev, vdb_fr *centroids_dev, vdb_fr *indicators_dev);
+/* VectorDBChip::merkle_commitment with PoseidonChip<F,3,2>(R_F=8, R_P=57) (src/gadget/vectordb.rs:165-223):
+ * the permutation trace cells; no lookups */
+int vdb_wit_merkle_size(size_t n, size_t dim, int zero_cached, uint64_t *cells);
+int vdb_wit_merkle(const vdb_fr *vectors, size_t n, size_t dim, int zero_cached, vdb_fr *stream_out, uint8_t *selector_out, vdb_fr *root_out);
+int vdb_wit_merkle_dev(const vdb_fr *vectors_dev, size_t n, size_t dim, int zero_cached, vdb_fr *stream_dev, uint8_t *selector_dev, vdb_fr *root_dev);
+
+/* ---- b4 stream -> columns: replaces halo2-base GateThreadBuilder::assign_all (break points, keygen)
+ *      and assign_threads_in (prover) as driven by RangeCircuitBuilder::prover(builder, break_points)
+ *      (src/scaffold/mod.rs:393-396).  Columns are 2^k rows; the cell on a break row is duplicated at
+ *      row 0 of the next column.  Lookup cells fill dedicated columns of 2^k - minimum_rows cells. ---- */
+int vdb_layout_plan(const uint8_t *selector, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t *break_points_out, uint64_t cap,
+                    uint64_t *n_break_points);
+int vdb_layout_plan_dev(const uint8_t *selector_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t *break_points_out, uint64_t cap,
+                        uint64_t *n_break_points);
+/* advice_cols_out: (n_bp + 1) x 2^k; lookup_cols_out: n_lookup_cols x 2^k (may be NULL) */
+int vdb_layout_columns(const vdb_fr *stream, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, const vdb_fr *lookup, uint64_t n_lookup,
+                       uint32_t k, uint32_t minimum_rows, vdb_fr *advice_cols_out, vdb_fr *lookup_cols_out, uint64_t n_lookup_cols);
+/* device variants; blind_dev (optional): n_cols x n_blind scalars written to the last n_blind rows
+ * (the prover's blinding rows) */
+int vdb_layout_columns_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, vdb_fr *cols_dev,
+                           const vdb_fr *blind_dev, uint32_t n_blind);
+int vdb_layout_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr *cols_dev, uint64_t n_cols,
+                          const vdb_fr *blind_dev, uint32_t n_blind);
+
 /* ---- b1 SRS: replaces halo2 ParamsKZG::{get_g, g_lagrange} as consumed by commit / commit_lagrange;
  *      the reference obtains the params with gen_srs(k) (src/scaffold/mod.rs:260) ------------------ */
 /* Uploads the bases (caller keeps ownership of the host arrays; either may be NULL) and precomputes

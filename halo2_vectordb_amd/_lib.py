@@ -39,7 +39,48 @@ def load():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.vdb_last_error.restype = ctypes.c_char_p
         _lib.vdb_version.restype = ctypes.c_char_p
+        _declare(_lib)
     return _lib
+
+
+_P, _SZ, _U32, _U64, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+# argument types of every entry point of include/vdb.h (pointers are passed as void*)
+_SIGNATURES = {
+    "vdb_init": [_I], "vdb_malloc": [_P, _SZ], "vdb_free": [_P], "vdb_memcpy_h2d": [_P, _P, _SZ], "vdb_memcpy_d2h": [_P, _P, _SZ],
+    "vdb_memcpy_d2d": [_P, _P, _SZ], "vdb_memset_dev": [_P, _I, _SZ], "vdb_timer_stop": [_P],
+    "vdb_fr_from_canonical": [_P, _P, _SZ], "vdb_fr_to_canonical": [_P, _P, _SZ], "vdb_fr_mul": [_P, _P, _P, _SZ], "vdb_fr_add": [_P, _P, _P, _SZ],
+    "vdb_fr_sub": [_P, _P, _P, _SZ], "vdb_fr_batch_invert": [_P, _P, _SZ], "vdb_bench_fr_mul": [_SZ, _SZ, _P],
+    "vdb_fp_quantize": [_U32, _P, _P, _SZ], "vdb_fp_dequantize": [_U32, _P, _P, _SZ],
+    "vdb_wit_distance_size": [_I, _U32, _U32, _SZ, _SZ, _P, _P],
+    "vdb_wit_distance": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P],
+    "vdb_wit_nearest_size": [_I, _U32, _U32, _SZ, _SZ, _P, _P],
+    "vdb_wit_nearest": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P, _P],
+    "vdb_wit_kmeans_size": [_I, _U32, _U32, _SZ, _SZ, _SZ, _SZ, _I, _P, _P],
+    "vdb_wit_kmeans": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
+    "vdb_wit_kmeans_dev": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
+    "vdb_wit_merkle_size": [_SZ, _SZ, _I, _P], "vdb_wit_merkle": [_P, _SZ, _SZ, _I, _P, _P, _P],
+    "vdb_wit_merkle_dev": [_P, _SZ, _SZ, _I, _P, _P, _P],
+    "vdb_layout_plan": [_P, _U64, _U32, _U32, _P, _U64, _P], "vdb_layout_plan_dev": [_P, _U64, _U32, _U32, _P, _U64, _P],
+    "vdb_layout_columns": [_P, _U64, _P, _U64, _P, _U64, _U32, _U32, _P, _P, _U64],
+    "vdb_layout_columns_dev": [_P, _U64, _P, _U64, _U32, _P, _P, _U32],
+    "vdb_layout_lookup_dev": [_P, _U64, _U32, _U32, _P, _U64, _P, _U32],
+    "vdb_srs_load": [_U32, _P, _P, _P], "vdb_srs_setup_unsafe": [_U32, _P, _P, _P], "vdb_srs_free": [_P], "vdb_srs_info": [_P, _P, _P, _P],
+    "vdb_msm": [_P, _I, _P, _SZ, _P], "vdb_msm_batch": [_P, _I, _P, _SZ, _SZ, _P], "vdb_msm_batch_dev": [_P, _I, _P, _SZ, _SZ, _P],
+    "vdb_ntt_batch": [_P, _SZ, _U32, _P, _I], "vdb_ntt_batch_dev": [_P, _SZ, _U32, _P, _I],
+    "vdb_lagrange_to_coeff": [_P, _SZ, _U32], "vdb_lagrange_to_coeff_dev": [_P, _SZ, _U32],
+    "vdb_coeff_to_extended": [_P, _P, _SZ, _U32, _U32], "vdb_coeff_to_extended_dev": [_P, _P, _SZ, _U32, _U32],
+    "vdb_fr_root_of_unity": [_U32, _P], "vdb_profile_end": [_P, _SZ],
+    "vdb_poseidon_hash_many": [_P, _SZ, _SZ, _P], "vdb_poseidon_merkle_root": [_P, _SZ, _SZ, _P], "vdb_poseidon_permute": [_P, _SZ],
+}
+
+
+def _declare(lib):
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        if name != "vdb_srs_free":
+            fn.restype = ctypes.c_int
+    lib.vdb_srs_free.restype = None
 
 
 def check(rc):

@@ -159,6 +159,16 @@ class Srs:
             pass
 
 
+def srs_setup_unsafe(k, tau_mont):
+    """(g, g_lagrange) for a known tau (Montgomery Fr limbs)."""
+    lib = _lib.init()
+    tau = _fr(tau_mont)
+    g = np.zeros((1 << k, 8), dtype=np.uint64)
+    gl = np.zeros((1 << k, 8), dtype=np.uint64)
+    check(lib.vdb_srs_setup_unsafe(ctypes.c_uint32(k), _p(tau), _p(g), _p(gl)))
+    return g, gl
+
+
 def msm_batch(srs, cols, basis=1):
     """cols: (n_cols, n, 4) Montgomery scalars (host) -> (n_cols, 8) affine points."""
     cols = _fr(cols)
@@ -369,3 +379,14 @@ def timer_stop():
     ms = ctypes.c_float(0)
     check(_lib.init().vdb_timer_stop(ctypes.byref(ms)))
     return ms.value
+
+
+def profile_begin():
+    check(_lib.init().vdb_profile_begin())
+
+
+def profile_end():
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(_lib.init().vdb_profile_end(buf, _sz(len(buf))))
+    return json.loads(buf.value.decode())

@@ -70,6 +70,38 @@ void* scratch_get(int slot, size_t bytes);
 static inline const u256* as_u256(const vdb_fr* p) { return reinterpret_cast<const u256*>(p); }
 static inline u256* as_u256(vdb_fr* p) { return reinterpret_cast<u256*>(p); }
 
+// Optional per-kernel timing with HIP events on the library stream (vdb_profile_begin/_end).  Off in
+// the timed path; bench.py turns it on for one extra pass to measure the dominant kernel's duration.
+struct ProfEntry {
+  double ms = 0;
+  uint64_t launches = 0;
+};
+extern bool g_prof_on;
+extern std::map<std::string, ProfEntry> g_prof;
+struct ProfScope {
+  const char* name;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  explicit ProfScope(const char* n) : name(n) {
+    if (!g_prof_on) return;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, ctx().stream);
+  }
+  ~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx().stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ProfEntry& pe = g_prof[name];
+    pe.ms += ms;
+    pe.launches += 1;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+};
+#define VDB_PROF(name) vdb::ProfScope _prof_scope_(name)
+
 // Fr domain constants computed on the host with the same field code
 u256 host_root_of_unity(uint32_t k);  // ROOT_OF_UNITY^(2^(28-k)), Montgomery
 u256 host_zeta();                     // halo2curves bn256 Fr::ZETA, Montgomery

@@ -8,6 +8,8 @@ static Context g_ctx;
 static thread_local char g_err[512] = "";
 
 Context& ctx() { return g_ctx; }
+bool g_prof_on = false;
+std::map<std::string, ProfEntry> g_prof;
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -211,6 +213,11 @@ int vdb_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   VDB_HIP(hipStreamSynchronize(ctx().stream));
   return VDB_OK;
 }
+int vdb_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+  return VDB_OK;
+}
 int vdb_memset_dev(void* dst, int value, size_t bytes) {
   VDB_REQUIRE_INIT();
   VDB_HIP(hipMemsetAsync(dst, value, bytes, ctx().stream));
@@ -275,6 +282,30 @@ int vdb_bench_fr_mul(size_t threads, size_t iters, double* mul_per_sec) {
   float ms = 0;
   VDB_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
   *mul_per_sec = (double)threads * (double)iters * 4.0 / ((double)ms * 1e-3);
+  return VDB_OK;
+}
+
+int vdb_profile_begin(void) {
+  VDB_REQUIRE_INIT();
+  g_prof.clear();
+  g_prof_on = true;
+  return VDB_OK;
+}
+int vdb_profile_end(char* json_out, size_t cap) {
+  g_prof_on = false;
+  VDB_ARG(json_out && cap > 2, "null buffer");
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : g_prof) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s\"%s\": {\"ms\": %.6f, \"launches\": %llu}", first ? "" : ", ", kv.first.c_str(), kv.second.ms,
+             (unsigned long long)kv.second.launches);
+    js += buf;
+    first = false;
+  }
+  js += "}";
+  VDB_ARG(js.size() + 1 <= cap, "profile buffer too small");
+  memcpy(json_out, js.c_str(), js.size() + 1);
   return VDB_OK;
 }
 

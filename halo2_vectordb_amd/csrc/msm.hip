@@ -283,6 +283,29 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ part
   }
 }
 
+
+// ---------------------------------------------------------------- test / bench SRS ("unsafe" setup with a known tau)
+// g[i] = tau^i * G,  g_lagrange[i] = L_i(tau) * G with L_i(tau) = omega^i (tau^n - 1) / (n (tau - omega^i))
+__global__ __launch_bounds__(64) void k_srs_setup(u256 tau, u256 omega, u256 tn_minus_1_over_n, uint64_t n, Affine* __restrict__ g, Affine* __restrict__ gl) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine gen;
+  gen.x = to_mont<Fq>(u256_from_u64(1));
+  gen.y = to_mont<Fq>(u256_from_u64(2));
+  u256 e = u256_from_u64(i);
+  u256 ti = mont_pow<Fr>(tau, e), wi = mont_pow<Fr>(omega, e);
+  u256 li = fr_mul(fr_mul(wi, tn_minus_1_over_n), mont_inv<Fr>(fr_sub(tau, wi)));
+  for (int which = 0; which < 2; which++) {
+    u256 k = from_mont<Fr>(which == 0 ? ti : li);
+    XYZZ acc = xyzz_identity();
+    for (int b = (int)u256_bits(k) - 1; b >= 0; b--) {
+      acc = xyzz_double(acc);
+      if (u256_bit(k, (unsigned)b)) xyzz_add_mixed(acc, gen, false);
+    }
+    st_affine((which == 0 ? g : gl) + i, xyzz_to_affine(acc));
+  }
+}
+
 static uint32_t pick_window(uint32_t k) {
   const char* env = getenv("VDB_MSM_C");
   if (env) {
@@ -321,13 +344,22 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   for (size_t c0 = 0; c0 < n_cols; c0 += nb) {
     size_t nc = n_cols - c0 < nb ? n_cols - c0 : nb;
     VDB_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), cx.stream));
-    hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
+    {
+      VDB_PROF("k_msm_sort");
+      hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
                        ent_cap, task_off, tasks, counters, task_cap);
+    }
     VDB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, tasks, counters,
+    {
+      VDB_PROF("k_msm_accum");
+      hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, tasks, counters,
                        partials, task_cap);
+    }
     VDB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, out_dev + c0);
+    {
+      VDB_PROF("k_msm_reduce");
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, out_dev + c0);
+    }
     VDB_LAUNCH_CHECK();
   }
   uint32_t h_counters[2] = {0, 0};
@@ -345,6 +377,29 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
 using namespace vdb;
 
 extern "C" {
+
+int vdb_srs_setup_unsafe(uint32_t k, const vdb_fr* tau, vdb_g1* g_out, vdb_g1* g_lagrange_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(tau && g_out && g_lagrange_out && k >= 1 && k <= 22, "bad argument");
+  Context& cx = ctx();
+  const uint64_t n = 1ull << k;
+  u256 t;
+  memcpy(&t, tau, 32);
+  u256 omega = host_root_of_unity(k);
+  u256 tn = mont_pow<Fr>(t, u256_from_u64(n));
+  u256 c = fr_mul(fr_sub(tn, mont_one<Fr>()), mont_inv<Fr>(host_fr_from_u64(n)));
+  Affine* d = (Affine*)scratch_get(0, 2 * n * sizeof(Affine));
+  if (!d) return VDB_ERR_OOM;
+  {
+    VDB_PROF("k_srs_setup");
+    hipLaunchKernelGGL(k_srs_setup, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, cx.stream, t, omega, c, n, d, d + n);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(g_out, d, n * sizeof(Affine), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipMemcpyAsync(g_lagrange_out, d + n, n * sizeof(Affine), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  return VDB_OK;
+}
 
 int vdb_srs_load(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, vdb_srs** out) {
   VDB_REQUIRE_INIT();
@@ -376,7 +431,10 @@ int vdb_srs_load(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, vdb_srs*
       return hip_fail(e, "hipMalloc(srs table)", __FILE__, __LINE__);
     }
     VDB_HIP(hipMemcpyAsync(bases, src[b], s->n * sizeof(Affine), hipMemcpyHostToDevice, cx.stream));
-    hipLaunchKernelGGL(k_srs_table, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, cx.stream, bases, s->table[b], s->n, s->c, s->W);
+    {
+      VDB_PROF("k_srs_table");
+      hipLaunchKernelGGL(k_srs_table, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, cx.stream, bases, s->table[b], s->n, s->c, s->W);
+    }
     VDB_LAUNCH_CHECK();
     VDB_HIP(hipStreamSynchronize(cx.stream));
   }

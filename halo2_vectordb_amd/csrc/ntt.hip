@@ -199,7 +199,10 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, int* err) {
   }
   uint32_t chunk = 16;
   uint64_t threads = (n + chunk - 1) / chunk;
-  hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, n, chunk);
+  {
+    VDB_PROF("k_twiddles");
+    hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, n, chunk);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) {
     *err = hip_fail(e, "k_twiddles", __FILE__, __LINE__);
@@ -301,9 +304,15 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       size_t lds = (size_t)(2 * G * (m + 1) + 2 * (m / 2 ? m / 2 : 1)) * sizeof(uint4);
       dim3 grid((unsigned)(nc * tiles));
       if (last) {
-        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+        {
+          VDB_PROF("k_ntt_pass");
+          hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+        }
       } else {
-        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+        {
+          VDB_PROF("k_ntt_pass");
+          hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+        }
       }
       VDB_LAUNCH_CHECK();
       done_bits += S[l];

@@ -236,12 +236,18 @@ int poseidon_merkle_dev(const u256* vectors_dev, size_t n, size_t dim, u256* lv 
   size_t leaves = 1;
   while (leaves < n) leaves <<= 1;
   VDB_HIP(hipMemsetAsync(lv, 0, leaves * sizeof(u256), c.stream));
-  hipLaunchKernelGGL(k_poseidon_hash_many, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, sp, vectors_dev, n, dim, lv);
+  {
+    VDB_PROF("k_poseidon_hash_many");
+    hipLaunchKernelGGL(k_poseidon_hash_many, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, sp, vectors_dev, n, dim, lv);
+  }
   VDB_LAUNCH_CHECK();
   u256 *a = lv, *b = tmp;
   while (leaves > 1) {
     size_t no = leaves / 2;
-    hipLaunchKernelGGL(k_poseidon_level, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, c.stream, sp, a, no, b);
+    {
+      VDB_PROF("k_poseidon_level");
+      hipLaunchKernelGGL(k_poseidon_level, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, c.stream, sp, a, no, b);
+    }
     VDB_LAUNCH_CHECK();
     std::swap(a, b);
     leaves = no;
@@ -269,7 +275,10 @@ int vdb_poseidon_hash_many(const vdb_fr* inputs, size_t n_msgs, size_t msg_len, 
   u256* dout = (u256*)scratch_get(1, n_msgs * sizeof(u256));
   if (!din || !dout) return VDB_ERR_OOM;
   if (in_bytes) VDB_HIP(hipMemcpyAsync(din, inputs, in_bytes, hipMemcpyHostToDevice, c.stream));
-  hipLaunchKernelGGL(k_poseidon_hash_many, dim3((unsigned)((n_msgs + 255) / 256)), dim3(256), 0, c.stream, sp, din, n_msgs, msg_len, dout);
+  {
+    VDB_PROF("k_poseidon_hash_many");
+    hipLaunchKernelGGL(k_poseidon_hash_many, dim3((unsigned)((n_msgs + 255) / 256)), dim3(256), 0, c.stream, sp, din, n_msgs, msg_len, dout);
+  }
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipMemcpyAsync(digests, dout, n_msgs * sizeof(u256), hipMemcpyDeviceToHost, c.stream));
   VDB_HIP(hipStreamSynchronize(c.stream));
@@ -306,7 +315,10 @@ int vdb_poseidon_permute(vdb_fr* states, size_t n) {
   u256* d = (u256*)scratch_get(0, bytes);
   if (!d) return VDB_ERR_OOM;
   VDB_HIP(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, c.stream));
-  hipLaunchKernelGGL(k_poseidon_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, sp, d, n);
+  {
+    VDB_PROF("k_poseidon_permute");
+    hipLaunchKernelGGL(k_poseidon_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, sp, d, n);
+  }
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, c.stream));
   VDB_HIP(hipStreamSynchronize(c.stream));

@@ -111,7 +111,10 @@ static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
   }
   compute_sizes(T);
   VDB_HIP(hipMalloc(&e->limb_tab, ((size_t)1 << L) * sizeof(u256)));
-  hipLaunchKernelGGL(k_limb_table, dim3((unsigned)(((1u << L) + 255) / 256)), dim3(256), 0, ctx().stream, e->limb_tab, 1u << L);
+  {
+    VDB_PROF("k_limb_table");
+    hipLaunchKernelGGL(k_limb_table, dim3((unsigned)(((1u << L) + 255) / 256)), dim3(256), 0, ctx().stream, e->limb_tab, 1u << L);
+  }
   VDB_LAUNCH_CHECK();
   T.limb_tab = e->limb_tab;
   VDB_HIP(hipMalloc(&e->dev, sizeof(FpTables)));
@@ -351,11 +354,17 @@ static uint32_t tail_segments(uint32_t n_inst) {
 static int run_distances(const Streams& st, FpEntry* fp, const DistLayout& dl, const InstMap& im, uint32_t n_inst, const u256* A,
                          const u256* Bv, u256* mid, u256* result) {
   if (n_inst == 0) return VDB_OK;
-  hipLaunchKernelGGL(k_dist_head, dim3(n_inst), dim3(HEAD_TB), 0, ctx().stream, st, fp->dev, dl, im, A, Bv, mid, result);
+  {
+    VDB_PROF("k_dist_head");
+    hipLaunchKernelGGL(k_dist_head, dim3(n_inst), dim3(HEAD_TB), 0, ctx().stream, st, fp->dev, dl, im, A, Bv, mid, result);
+  }
   VDB_LAUNCH_CHECK();
   if (dl.tail_cells) {
-    hipLaunchKernelGGL(k_dist_tail, dim3((n_inst + 63) / 64, tail_segments(n_inst)), dim3(64), 0, ctx().stream, st, fp->dev, dl, im, n_inst,
+    {
+      VDB_PROF("k_dist_tail");
+      hipLaunchKernelGGL(k_dist_tail, dim3((n_inst + 63) / 64, tail_segments(n_inst)), dim3(64), 0, ctx().stream, st, fp->dev, dl, im, n_inst,
                        mid, result);
+    }
     VDB_LAUNCH_CHECK();
   }
   return VDB_OK;
@@ -760,18 +769,30 @@ int wit_nearest_dev(FpEntry* fp, int metric, const u256* query, const u256* vect
   u256* pm = dist + n;
   TRY(run_distances(st, fp, dl, im, (uint32_t)n, vectors, query, mid, dist));
   hipStream_t s = ctx().stream;
-  hipLaunchKernelGGL(k_nv_prefix_min, dim3(1), dim3(1), 0, s, fp->dev, dist, (uint32_t)n, pm);
+  {
+    VDB_PROF("k_nv_prefix_min");
+    hipLaunchKernelGGL(k_nv_prefix_min, dim3(1), dim3(1), 0, s, fp->dev, dist, (uint32_t)n, pm);
+  }
   VDB_LAUNCH_CHECK();
   if (n > 1) {
-    hipLaunchKernelGGL(k_nv_qmin, dim3((unsigned)((n - 1 + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist, lk_off + nl.dist_l, dist, pm,
+    {
+      VDB_PROF("k_nv_qmin");
+      hipLaunchKernelGGL(k_nv_qmin, dim3((unsigned)((n - 1 + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist, lk_off + nl.dist_l, dist, pm,
                        (uint32_t)n);
+    }
     VDB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_nv_is_equal, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin, dist, pm, (uint32_t)n,
+  {
+    VDB_PROF("k_nv_is_equal");
+    hipLaunchKernelGGL(k_nv_is_equal, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin, dist, pm, (uint32_t)n,
                      ind);
+  }
   VDB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_nv_select, dim3((unsigned)((dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin + nl.iseq, vectors, ind,
+  {
+    VDB_PROF("k_nv_select");
+    hipLaunchKernelGGL(k_nv_select, dim3((unsigned)((dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, adv_off + nl.dist + nl.qmin + nl.iseq, vectors, ind,
                      (uint32_t)n, (uint32_t)dim, result);
+  }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
 }
@@ -809,7 +830,10 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
   u256* sizes = sums + K * dim;
   u256* filt = sizes + K;
   // preamble: load_constant(quantization(1.0)); load_zero()
-  hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, adv_off, fp->host.c_one_q, u256_zero(), zero_cached ? 1u : 2u);
+  {
+    VDB_PROF("k_push_cells");
+    hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, adv_off, fp->host.c_one_q, u256_zero(), zero_cached ? 1u : 2u);
+  }
   VDB_LAUNCH_CHECK();
   uint64_t pos = adv_off + (zero_cached ? 1 : 2), lpos = lk_off;
   VDB_HIP(hipMemcpyAsync(cent, vectors, K * dim * sizeof(u256), hipMemcpyDeviceToDevice, s));
@@ -817,16 +841,31 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
   for (size_t it = 0; it < I; it++) {
     InstMap im{pos, lpos, (uint32_t)K, kl.per_vec, kl.per_vec_l, (uint32_t)K, (uint32_t)K};  // distance(centroid_k, vector_v)
     TRY(run_distances(st, fp, dl, im, (uint32_t)(n * K), cent, vectors, mid, dist));
-    hipLaunchKernelGGL(k_km_assign, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, dl, pos, lpos, dist, ind_out);
+    {
+      VDB_PROF("k_km_assign");
+      hipLaunchKernelGGL(k_km_assign, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, dl, pos, lpos, dist, ind_out);
+    }
     VDB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_km_sizes, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, pos + kl.assign, ind_out, sizes);
+    {
+      VDB_PROF("k_km_sizes");
+      hipLaunchKernelGGL(k_km_sizes, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, pos + kl.assign, ind_out, sizes);
+    }
     VDB_LAUNCH_CHECK();
     uint64_t cb = pos + kl.assign + kl.sizes, clb = lpos + kl.assign_l;
-    hipLaunchKernelGGL(k_km_filter, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, vectors, ind_out, scale_inv, filt);
+    {
+      VDB_PROF("k_km_filter");
+      hipLaunchKernelGGL(k_km_filter, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, vectors, ind_out, scale_inv, filt);
+    }
     VDB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_km_sum, dim3((unsigned)((K * dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, filt, sums);
+    {
+      VDB_PROF("k_km_sum");
+      hipLaunchKernelGGL(k_km_sum, dim3((unsigned)((K * dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, filt, sums);
+    }
     VDB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_km_div, dim3((unsigned)((K * dim + 63) / 64), 8), dim3(64), 0, s, st, fp->dev, kl, cb, clb, sums, sizes, cent);
+    {
+      VDB_PROF("k_km_div");
+      hipLaunchKernelGGL(k_km_div, dim3((unsigned)((K * dim + 63) / 64), 8), dim3(64), 0, s, st, fp->dev, kl, cb, clb, sums, sizes, cent);
+    }
     VDB_LAUNCH_CHECK();
     pos += kl.iter;
     lpos += kl.iter_l;
@@ -868,21 +907,33 @@ int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, S
   u256* lva = states + n * ml.nperm * PSD_T;
   u256* lvb = lva + ml.n_leaves_pow2;
   VDB_HIP(hipMemsetAsync(lva, 0, ml.n_leaves_pow2 * sizeof(u256), s));
-  hipLaunchKernelGGL(k_mk_leaf_states, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sp, vectors, (uint32_t)n, (uint32_t)dim, ml.nperm, states, lva);
+  {
+    VDB_PROF("k_mk_leaf_states");
+    hipLaunchKernelGGL(k_mk_leaf_states, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sp, vectors, (uint32_t)n, (uint32_t)dim, ml.nperm, states, lva);
+  }
   VDB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_mk_leaf_trace, dim3((unsigned)((n * ml.nperm + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, vectors, (uint32_t)n, (uint32_t)dim,
+  {
+    VDB_PROF("k_mk_leaf_trace");
+    hipLaunchKernelGGL(k_mk_leaf_trace, dim3((unsigned)((n * ml.nperm + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, vectors, (uint32_t)n, (uint32_t)dim,
                      ml.nperm, adv_off, ml.leaf_cells, states);
+  }
   VDB_LAUNCH_CHECK();
   uint64_t pos = adv_off + ml.leaves;
   if (ml.zero_cell) {
-    hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, pos, u256_zero(), u256_zero(), 1u);
+    {
+      VDB_PROF("k_push_cells");
+      hipLaunchKernelGGL(k_push_cells, dim3(1), dim3(1), 0, s, st, pos, u256_zero(), u256_zero(), 1u);
+    }
     VDB_LAUNCH_CHECK();
     pos += 1;
   }
   uint64_t lv = ml.n_leaves_pow2;
   while (lv > 1) {
     uint64_t no = lv / 2;
-    hipLaunchKernelGGL(k_mk_node, dim3((unsigned)((no + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, lva, (uint32_t)no, pos, lvb);
+    {
+      VDB_PROF("k_mk_node");
+      hipLaunchKernelGGL(k_mk_node, dim3((unsigned)((no + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, lva, (uint32_t)no, pos, lvb);
+    }
     VDB_LAUNCH_CHECK();
     pos += no * (uint64_t)(perm_cells(2) + perm_cells(0));
     std::swap(lva, lvb);
@@ -1100,7 +1151,10 @@ int vdb_layout_plan_dev(const uint8_t* selector_dev, uint64_t n_cells, uint32_t 
   uint64_t est = n_cells / (max_rows - 3) + 2;
   uint64_t* d = (uint64_t*)scratch_get(1, (est + 1) * sizeof(uint64_t));
   if (!d) return VDB_ERR_OOM;
-  hipLaunchKernelGGL(k_layout_plan, dim3(1), dim3(1), 0, ctx().stream, selector_dev, n_cells, max_rows, d + 1, est, d);
+  {
+    VDB_PROF("k_layout_plan");
+    hipLaunchKernelGGL(k_layout_plan, dim3(1), dim3(1), 0, ctx().stream, selector_dev, n_cells, max_rows, d + 1, est, d);
+  }
   VDB_LAUNCH_CHECK();
   uint64_t nbp = 0;
   VDB_HIP(hipMemcpyAsync(&nbp, d, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
@@ -1136,11 +1190,17 @@ int vdb_layout_columns_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uin
   uint64_t* dbp = d;
   uint64_t* dst = d + n_bp;
   if (n_bp) VDB_HIP(hipMemcpyAsync(dbp, break_points, n_bp * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
-  hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
+  {
+    VDB_PROF("k_layout_starts");
+    hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
+  }
   VDB_LAUNCH_CHECK();
   uint64_t total = (n_bp + 1) * rows;
-  hipLaunchKernelGGL(k_layout_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(stream_dev), n_cells, dst, dbp, n_bp, k,
+  {
+    VDB_PROF("k_layout_columns");
+    hipLaunchKernelGGL(k_layout_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(stream_dev), n_cells, dst, dbp, n_bp, k,
                      as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+  }
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipStreamSynchronize(ctx().stream));  // break_points is a host buffer the caller may free
   return VDB_OK;
@@ -1153,8 +1213,11 @@ int vdb_layout_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k
   VDB_ARG(n_cols * max_rows >= n_cells, "not enough lookup columns");
   if (n_cols == 0) return VDB_OK;
   uint64_t total = n_cols << k;
-  hipLaunchKernelGGL(k_layout_lookup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(lookup_dev), n_cells, max_rows, k, n_cols,
+  {
+    VDB_PROF("k_layout_lookup");
+    hipLaunchKernelGGL(k_layout_lookup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(lookup_dev), n_cells, max_rows, k, n_cols,
                      as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+  }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
 }

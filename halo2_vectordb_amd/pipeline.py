@@ -1,0 +1,185 @@
+"""HBM-resident driver of the proving hot path for one circuit (plumbing above the C ABI).
+
+Mirrors what the reference's `Prove` arm does up to the committed / extended advice columns
+(/root/reference/src/scaffold/mod.rs:284-298 -> create_proof):
+
+    closure (witness gen)  ->  assign_threads_in (stream -> columns)  ->  commit_lagrange per column
+    ->  lagrange_to_coeff  ->  coeff_to_extended
+
+`setup()` plays the Keygen arm's role for the layout (src/scaffold/mod.rs:267-283): one run with gate
+selectors recorded, from which the break points ("pinning") are derived.  Everything stays in HBM;
+only commitments (64 B per column) come back to the host.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import api
+from ._lib import check
+
+MINIMUM_ROWS = 9   # MINIMUM_ROWS default, src/scaffold/mod.rs:383
+N_BLIND = 6        # blinding rows filled with random scalars by the prover (halo2: blinding_factors + 1)
+
+
+def sift_like_vectors(seed, n, dim, k_distinct=0):
+    """integers uniform in [0, 218] stored as f64; rows non-zero; first K rows distinct."""
+    while True:
+        rng = np.random.default_rng(seed)
+        v = rng.integers(0, 219, size=(n, dim)).astype(np.float64)
+        ok = (v.sum(axis=1) > 0).all()
+        if k_distinct:
+            ok = ok and len({tuple(r) for r in v[:k_distinct]}) == k_distinct
+        if ok:
+            return v, seed
+        seed += 1
+
+
+class KmeansHotPath:
+    """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
+
+    def __init__(self, n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="euclidean", seed=20260004, tau=0x5EED5EED5EED,
+                 col_shard=(0, 1)):
+        self.n, self.dim, self.K, self.I, self.k, self.P, self.L = n, dim, K, I, k, P, L
+        self.metric = api.METRICS[metric]
+        self.metric_name = metric
+        self.rows = 1 << k
+        self.lib = api.init()
+        self.rank, self.world = col_shard
+        self.seed = seed
+        self.tau = tau
+
+    # ------------------------------------------------------------------ keygen-like setup (untimed)
+    def setup(self):
+        lib, n, dim, K, I = self.lib, self.n, self.dim, self.K, self.I
+        vec, self.seed = sift_like_vectors(self.seed, n, dim, K)
+        self.vectors_f64 = vec
+        self.qvec = api.quantize(vec, self.P)
+        cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.vdb_wit_kmeans_size(self.metric, self.P, self.L, n, dim, K, I, 0, ctypes.byref(cells), ctypes.byref(lk)))
+        self.n_in = n * dim                       # ctx.assign_witnesses(quantize_vector(v)) for every vector
+        self.n_cells = self.n_in + cells.value
+        self.n_lookup = lk.value
+        B = 32
+        self.d_vec = api.DeviceBuffer(self.qvec.nbytes)
+        self.d_vec.upload(self.qvec)
+        self.d_stream = api.DeviceBuffer(self.n_cells * B)
+        self.d_lookup = api.DeviceBuffer(max(self.n_lookup, 1) * B)
+        self.d_cent = api.DeviceBuffer(K * dim * B)
+        self.d_ind = api.DeviceBuffer(n * K * B)
+        # keygen-style run: record gate starts, derive break points (the reference pins them in configs/*.json)
+        d_sel = api.DeviceBuffer(self.n_cells)
+        check(lib.vdb_memset_dev(d_sel.ptr, 0, ctypes.c_size_t(self.n_cells)))
+        self._witness(sel=d_sel)
+        nbp = ctypes.c_uint64()
+        check(lib.vdb_layout_plan_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), self.k, MINIMUM_ROWS, None, ctypes.c_uint64(0), ctypes.byref(nbp)))
+        self.bp = np.zeros(max(nbp.value, 1), dtype=np.uint64)
+        check(lib.vdb_layout_plan_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), self.k, MINIMUM_ROWS, api._p(self.bp), ctypes.c_uint64(self.bp.size),
+                                      ctypes.byref(nbp)))
+        self.bp = self.bp[:nbp.value]
+        d_sel.free()
+        self.n_adv_cols = len(self.bp) + 1
+        max_rows = self.rows - MINIMUM_ROWS
+        self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
+        self.n_cols = self.n_adv_cols + self.n_lk_cols
+        # column sharding over ranks (contiguous blocks of the concatenated [advice | lookup] column list)
+        lo = self.n_cols * self.rank // self.world
+        hi = self.n_cols * (self.rank + 1) // self.world
+        self.col_lo, self.col_hi = lo, hi
+        self.my_cols = hi - lo
+        rng = np.random.default_rng(self.seed + 7)
+        from_ints = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        raw = rng.integers(0, 1 << 62, size=(self.n_cols * N_BLIND, 4), dtype=np.int64).astype(object)
+        blind = from_ints([(int(r[0]) | int(r[1]) << 62 | int(r[2]) << 124 | int(r[3]) << 186) % R for r in raw])
+        self.blind = blind  # treated as Montgomery representatives: any value < r is a valid field element
+        self.d_blind = api.DeviceBuffer(blind.nbytes)
+        self.d_blind.upload(blind)
+        self.d_cols = api.DeviceBuffer(self.n_cols * self.rows * B)
+        self.d_ext = api.DeviceBuffer(self.my_cols * self.rows * 4 * B)
+        tau = from_ints([self.tau * (1 << 256) % R])[0]
+        g, gl = api.srs_setup_unsafe(self.k, tau)
+        self.g_lagrange = gl
+        self.srs = api.Srs(self.k, None, gl)
+        api.sync()
+        return self
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        # [assign_witnesses(vectors)] [kmeans cells]
+        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
+        check(lib.vdb_wit_kmeans_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.n, self.dim, self.K, self.I, 0, self.d_stream.at(self.n_in * 32),
+                                     self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_cent.ptr,
+                                     self.d_ind.ptr))
+
+    # ------------------------------------------------------------------ one pass of the hot path
+    def step(self, timings=None):
+        lib, B = self.lib, 32
+
+        def stage(name, fn):
+            if timings is not None:
+                api.timer_start()
+            fn()
+            if timings is not None:
+                timings[name] = timings.get(name, 0.0) + api.timer_stop()
+
+        stage("witness", self._witness)
+
+        def layout():
+            check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                             self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
+            if self.n_lk_cols:
+                check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
+                                                self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
+                                                self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
+
+        stage("layout", layout)
+        my = self.d_cols.at(self.col_lo * self.rows * B)
+        self.commitments = np.zeros((self.my_cols, 8), dtype=np.uint64)
+
+        def commit():
+            check(lib.vdb_msm_batch_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), api._p(self.commitments)))
+
+        stage("commit_msm", commit)
+
+        def ntt():
+            check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
+            check(lib.vdb_coeff_to_extended_dev(my, self.d_ext.ptr, ctypes.c_size_t(self.my_cols), self.k, 2))
+
+        stage("ntt", ntt)
+        api.sync()
+        return self.commitments
+
+    def download_columns(self, col_indices):
+        """Lagrange-basis columns as laid out (call right after `layout`, i.e. use relayout())."""
+        out = np.zeros((len(col_indices), self.rows, 4), dtype=np.uint64)
+        for j, c in enumerate(col_indices):
+            out[j] = self.d_cols.download((self.rows, 4), offset=c * self.rows * 32)
+        return out
+
+    def relayout(self):
+        """Re-run witness + layout only (columns are overwritten in place by the NTT stage)."""
+        t = {}
+        self._witness()
+        lib, B = self.lib, 32
+        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                         self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
+        if self.n_lk_cols:
+            check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
+                                            self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
+                                            self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
+        api.sync()
+        return t
+
+    def results(self):
+        cent = self.d_cent.download((self.K, self.dim, 4))
+        ind = self.d_ind.download((self.n, self.K, 4))
+        return cent, ind
+
+    def free(self):
+        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext"):
+            b = getattr(self, name, None)
+            if b is not None:
+                b.free()
+        if getattr(self, "srs", None) is not None:
+            self.srs.free()

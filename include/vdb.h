@@ -57,11 +57,16 @@ int vdb_malloc(void **dptr, size_t bytes);
 int vdb_free(void *dptr);
 int vdb_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int vdb_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous on the library stream */
 int vdb_memset_dev(void *dst_dev, int value, size_t bytes);
 int vdb_sync(void);
 /* HIP-event timing on the library's own stream (bench.py: torch.cuda.Event does not see it) */
 int vdb_timer_start(void);
 int vdb_timer_stop(float *ms_out);
+/* per-kernel HIP-event timing: between begin and end every kernel launch of the library is bracketed by
+ * events on its stream (serialising them); end returns {"kernel": {"ms": total, "launches": n}, ...} */
+int vdb_profile_begin(void);
+int vdb_profile_end(char *json_out, size_t cap);
 
 /* ---- field helpers (tests / staging) -------------------------------------------------------- */
 int vdb_fr_from_canonical(const vdb_fr *in, vdb_fr *out, size_t n);
@@ -134,6 +139,9 @@ int vdb_layout_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k
 /* Uploads the bases (caller keeps ownership of the host arrays; either may be NULL) and precomputes
  * the fixed-base window tables 2^(c*j) * G_i in HBM. */
 int vdb_srs_load(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, vdb_srs **out);
+/* "unsafe" trusted setup with a caller-supplied tau, the construction ParamsKZG::setup performs behind
+ * gen_srs(k) (src/scaffold/mod.rs:260-261: "unsafe" message); tau is a Montgomery Fr.  Test/bench SRS. */
+int vdb_srs_setup_unsafe(uint32_t k, const vdb_fr *tau, vdb_g1 *g_out, vdb_g1 *g_lagrange_out);
 void vdb_srs_free(vdb_srs *srs);
 int vdb_srs_info(const vdb_srs *srs, uint32_t *k, uint32_t *window_bits, uint32_t *windows);
 

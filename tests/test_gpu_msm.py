@@ -95,3 +95,10 @@ def test_msm_linearity_k14(api, O):
     want = O.g1_mul_generator([ka, kb, (ka + kb) % R])
     assert np.array_equal(got, want)
     srs.free()
+
+
+def test_srs_setup_unsafe(api, O):
+    k, tau = 6, 0x1234567
+    g, gl = api.srs_setup_unsafe(k, O.fr_from_ints([tau])[0])
+    wg, wgl = O.srs_from_tau(k, tau)
+    assert np.array_equal(g, wg) and np.array_equal(gl, wgl)

@@ -220,6 +220,31 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
   }
 }
 
+
+// Segmented tree reduction of the partial sums of every bucket: in pass p a bucket that still holds
+// len_p > 1 partials folds its upper half onto its lower half (len_{p+1} = ceil(len_p / 2)).  One
+// thread per task slot; after ceil(log2(max tasks per bucket)) passes the sum of bucket b sits in the
+// first slot of its segment.  This is what removes the witness-column skew from the reduce kernel.
+__global__ __launch_bounds__(256) void k_msm_combine(XYZZ* __restrict__ partials, const MsmTask* __restrict__ tasks, const uint32_t* __restrict__ task_off,
+                                                     const uint32_t* __restrict__ counters, uint32_t B, uint32_t pass, uint32_t task_cap) {
+  if (counters[1]) return;
+  const uint32_t total = counters[0] < task_cap ? counters[0] : task_cap;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    MsmTask tk = tasks[t];
+    const uint32_t* toff = task_off + (size_t)tk.col * (B + 1);
+    uint32_t s = toff[tk.bucket - 1], len = toff[tk.bucket] - s;
+    for (uint32_t q = 0; q < pass && len > 1; q++) len = (len + 1) >> 1;
+    if (len <= 1) continue;
+    uint32_t half = (len + 1) >> 1, i = t - s;
+    if (i + half < len) {
+      XYZZ a = ld_xyzz(partials + t), b = ld_xyzz(partials + t + half);
+      xyzz_add(a, b);
+      st_xyzz(partials + t, a);
+    }
+  }
+}
+
 __device__ __forceinline__ u256 shfl_u256(const u256& v, int src) {
   u256 r;
 #pragma unroll
@@ -248,8 +273,8 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ part
   if (lo < B) {
     for (int b = (int)(lo + per) - 1; b >= (int)lo; b--) {
       uint32_t t0 = toff[b], t1 = toff[b + 1];
-      for (uint32_t t = t0; t < t1; t++) {
-        XYZZ p = ld_xyzz(partials + t);
+      if (t1 > t0) {  // bucket sum was folded into its first slot by k_msm_combine
+        XYZZ p = ld_xyzz(partials + t0);
         xyzz_add(running, p);
       }
       xyzz_add(total, running);
@@ -325,12 +350,13 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   const uint32_t c = srs->c, W = srs->W, B = srs->B;
   const size_t ent_cap = n * W;
   const size_t task_cap_col = B + (ent_cap + MSM_LCAP - 1) / MSM_LCAP;
-  // batch so that the worst-case scratch stays below ~6 GiB
+  // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
+  // thousands of independent column reductions in flight
   size_t per_col = ent_cap * 4 + task_cap_col * (sizeof(MsmTask) + sizeof(XYZZ)) + (B + 1) * 4;
-  size_t nb = ((size_t)6 << 30) / per_col;
+  size_t nb = ((size_t)40 << 30) / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;
-  if (nb > 1024) nb = 1024;
+  if (nb > 4096) nb = 4096;
   if (nb * task_cap_col > 0x7fffffffull) nb = 0x7fffffffull / task_cap_col;
   uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 256);
   if (!buf) return VDB_ERR_OOM;
@@ -356,6 +382,16 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
                        partials, task_cap);
     }
     VDB_LAUNCH_CHECK();
+    {
+      // ceil(log2(max tasks per bucket)) <= ceil(log2(n * W / LCAP)) passes; later passes exit immediately
+      uint32_t max_nt = (uint32_t)((ent_cap + MSM_LCAP - 1) / MSM_LCAP), passes = 0;
+      while ((1u << passes) < max_nt) passes++;
+      for (uint32_t ps = 0; ps < passes; ps++) {
+        VDB_PROF("k_msm_combine");
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, tasks, task_off, counters, B, ps, task_cap);
+      }
+      VDB_LAUNCH_CHECK();
+    }
     {
       VDB_PROF("k_msm_reduce");
       hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, out_dev + c0);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories (gpurun_out/prof_rNN_{stats,fetch,write}) into the small
+tracked summaries under profiles/.  Usage: python profiles/summarize.py r01 [suffix]"""
+import collections
+import csv
+import glob
+import shutil
+import sys
+
+tag = sys.argv[1]
+suffix = sys.argv[2] if len(sys.argv) > 2 else ""
+src = f"gpurun_out/prof_{tag}{suffix}"
+stats = glob.glob(f"{src}_stats/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{tag}{suffix}_kernel_stats.csv")
+rows = []
+for kind in ("fetch", "write"):
+    files = glob.glob(f"{src}_{kind}/*/*_counter_collection.csv")
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+        agg[k][2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for k, (n, v, ms) in agg.items():
+        rows.append((kind, k, n, v, ms))
+with open(f"profiles/{tag}{suffix}_pmc_summary.csv", "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
+    f.write("# Counter_Value is in KiB as reported; gfx950 correction (MI355X_MICROARCH.md §HBM): HBM read bytes = 2 * FETCH_SIZE * 1024\n")
+    f.write("# for wide coalesced 16 B/lane streams, HBM write bytes = WRITE_SIZE * 1024.\n")
+    f.write("counter,kernel,launches,sum_counter_KiB,per_launch_KiB,sum_ms\n")
+    for kind, k, n, v, ms in sorted(rows, key=lambda r: (r[0], -r[3])):
+        f.write(f"{kind},{k},{n},{v:.1f},{v / n:.1f},{ms:.3f}\n")
+print("wrote", f"profiles/{tag}{suffix}_kernel_stats.csv", f"profiles/{tag}{suffix}_pmc_summary.csv")

@@ -35,6 +35,25 @@ def sift_like_vectors(seed, n, dim, k_distinct=0):
         seed += 1
 
 
+def shard_range(n_cols, rank, world):
+    """Contiguous block of the concatenated [advice | lookup] column list owned by `rank`."""
+    return n_cols * rank // world, n_cols * (rank + 1) // world
+
+
+def gather_commitments(dist, local, n_cols, rank, world, device):
+    """The one real exchange step of the path: all_gather of the 64-byte commitments of every rank's column
+    shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64.  Returns (n_cols, 8)."""
+    import torch
+    counts = [shard_range(n_cols, r, world)[1] - shard_range(n_cols, r, world)[0] for r in range(world)]
+    mx = max(counts)
+    mine = torch.zeros((mx, 8), dtype=torch.int64, device=device)
+    if len(local):
+        mine[: len(local)] = torch.from_numpy(np.ascontiguousarray(local).view(np.int64)).to(device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return np.concatenate([g[:c].cpu().numpy().view(np.uint64) for g, c in zip(gathered, counts)])
+
+
 class KmeansHotPath:
     """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
 
@@ -83,8 +102,7 @@ class KmeansHotPath:
         self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
         self.n_cols = self.n_adv_cols + self.n_lk_cols
         # column sharding over ranks (contiguous blocks of the concatenated [advice | lookup] column list)
-        lo = self.n_cols * self.rank // self.world
-        hi = self.n_cols * (self.rank + 1) // self.world
+        lo, hi = shard_range(self.n_cols, self.rank, self.world)
         self.col_lo, self.col_hi = lo, hi
         self.my_cols = hi - lo
         rng = np.random.default_rng(self.seed + 7)

@@ -415,6 +415,10 @@ struct Gadgets {
     return fp_cond_neg(q, sx);
   }
   HD u256 fp_qmin(const u256& a, const u256& b) {  // :936-952
+    if (c.skip(T.sz.qmin[0])) {
+      c.advance(T.sz.qmin);
+      return v_is_neg(from_mont<Fr>(fr_sub(a, b))) ? a : b;
+    }
     u256 amb = g_sub(a, b);
     u256 s = fp_is_neg(amb);
     return g_select(a, b, s);

@@ -211,10 +211,17 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
     MsmTask tk = tasks[t];
     const uint32_t* e = entries + (size_t)tk.col * ent_cap + tk.start;
     XYZZ acc = xyzz_identity();
+    // software prefetch: the gather of the next table point is in flight during the current addition
+    uint32_t v = e[0];
+    Affine nxt = ld_affine(table + (v & 0x7fffffffu));
     for (uint32_t q = 0; q < tk.len; q++) {
-      uint32_t v = e[q];
-      Affine p = ld_affine(table + (v & 0x7fffffffu));
-      xyzz_add_mixed(acc, p, (v >> 31) != 0);
+      Affine p = nxt;
+      bool neg = (v >> 31) != 0;
+      if (q + 1 < tk.len) {
+        v = e[q + 1];
+        nxt = ld_affine(table + (v & 0x7fffffffu));
+      }
+      xyzz_add_mixed(acc, p, neg);
     }
     st_xyzz(partials + t, acc);
   }

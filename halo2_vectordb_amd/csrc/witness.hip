@@ -425,17 +425,25 @@ struct KmLayout {
 };
 __global__ __launch_bounds__(64) void k_km_assign(Streams st, const FpTables* __restrict__ T, KmLayout kl, DistLayout dl, uint64_t ibase, uint64_t ilbase,
                                                   const u256* __restrict__ dist, u256* __restrict__ ind) {
+  // lanes = vectors, blockIdx.y = position window of the per-vector assignment block
   uint32_t v = blockIdx.x * 64 + threadIdx.x;
-  if (v >= kl.N) return;
-  const uint32_t K = kl.K;
-  WCtx c = make_ctx(st, T, ibase + (uint64_t)v * kl.per_vec + (uint64_t)K * dl.total_cells, ilbase + (uint64_t)v * kl.per_vec_l + (uint64_t)K * dl.total_lk);
+  const bool live = v < kl.N;
+  if (!live) v = kl.N - 1;
+  const uint32_t K = kl.K, S = gridDim.y, s = blockIdx.y;
+  const uint64_t base = ibase + (uint64_t)v * kl.per_vec + (uint64_t)K * dl.total_cells;
+  const uint64_t cells = (uint64_t)(K - 1) * T->sz.qmin[0] + 20ull * K;
+  WCtx c = make_ctx(st, T, base, ilbase + (uint64_t)v * kl.per_vec_l + (uint64_t)K * dl.total_lk);
+  c.lo = base + cells * s / S;
+  c.hi = base + cells * (s + 1) / S;
+  if (!live) c.lo = c.hi = base;
   Gadgets g(c);
   const u256* d = dist + (size_t)v * K;
   u256 m = d[0];
   for (uint32_t k = 1; k < K; k++) m = g.fp_qmin(m, d[k]);
   for (uint32_t k = 0; k < K; k++) {
     u256 eq = g.g_is_equal(m, d[k]);
-    ind[(size_t)v * K + k] = g.g_select(T->c_one_q, u256_zero(), eq);
+    u256 r = g.g_select(T->c_one_q, u256_zero(), eq);
+    if (live && s == S - 1) ind[(size_t)v * K + k] = r;
   }
 }
 __global__ void k_km_sizes(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t base, const u256* __restrict__ ind, u256* __restrict__ sizes) {
@@ -843,7 +851,7 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
     TRY(run_distances(st, fp, dl, im, (uint32_t)(n * K), cent, vectors, mid, dist));
     {
       VDB_PROF("k_km_assign");
-      hipLaunchKernelGGL(k_km_assign, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, dl, pos, lpos, dist, ind_out);
+      hipLaunchKernelGGL(k_km_assign, dim3((unsigned)((n + 63) / 64), (unsigned)(2 * K)), dim3(64), 0, s, st, fp->dev, kl, dl, pos, lpos, dist, ind_out);
     }
     VDB_LAUNCH_CHECK();
     {

@@ -29,6 +29,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
+def pmc_traffic_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.csv, produced by
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of a wide
+    coalesced read stream, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes.  None when no summary is present."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    fetch = write = 0.0
+    nf = nw = 0
+    for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
+        name = row["kernel"].replace("void ", "").replace("vdb::", "").split("<")[0]
+        if name != kernel:
+            continue
+        if row["counter"] == "fetch":
+            fetch += float(row["sum_counter_KiB"])
+            nf += int(row["launches"])
+        else:
+            write += float(row["sum_counter_KiB"])
+            nw += int(row["launches"])
+    if not nf or not nw:
+        return None, os.path.basename(files[-1])
+    return (2.0 * fetch / nf + write / nw) * 1024.0, os.path.basename(files[-1])
+
+
 def cpu_baseline(hp, cols_sample, commitments_sample):
     """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload."""
     from oracle import oracle as O  # test infrastructure: allowed here as the cpu_baseline leg only
@@ -152,8 +178,10 @@ def main():
         else:
             algo_bytes = 32.0 * total_cells / rec["launches"]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_per_launch(name)
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": rec["launches"],
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                    "avg_launch_ms": avg_ms, "launches_per_step": rec["launches"],
                     "note": "integer-ALU bound (254-bit Montgomery products on v_mad_u64_u32); see valu",
                     "kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
         try:

@@ -95,6 +95,8 @@ def init(device=None):
     """Bind this process to one GPU (LOCAL_RANK by default).  Raises if no GPU is visible."""
     global _inited
     if device is None:
+        if _inited is not None:
+            return load()  # already bound by an explicit init(device)
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if _inited != device:
         check(load().vdb_init(int(device)))

@@ -98,6 +98,18 @@ __global__ __launch_bounds__(256) void k_batch_invert(const u256* __restrict__ i
 }
 
 // 4 independent dependency chains per thread so the measurement is throughput-, not latency-bound
+__global__ __launch_bounds__(256) void k_bench_mul32(u256* __restrict__ sink, size_t iters) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u256 a = to_mont<Fr>(u256_from_u64(t * 2654435761ull + 12345)), b = fr_add(a, mont_one<Fr>());
+  u256 c = fr_add(b, mont_one<Fr>()), d = fr_add(c, mont_one<Fr>());
+  for (size_t i = 0; i < iters; i++) {
+    a = mont_mul32<Fr>(a, b);
+    b = mont_mul32<Fr>(b, c);
+    c = mont_mul32<Fr>(c, d);
+    d = mont_mul32<Fr>(d, a);
+  }
+  st256(sink + t, fr_add(fr_add(a, b), fr_add(c, d)));
+}
 __global__ __launch_bounds__(256) void k_bench_mul(u256* __restrict__ sink, size_t iters) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   u256 a = to_mont<Fr>(u256_from_u64(t * 2654435761ull + 12345)), b = fr_add(a, mont_one<Fr>());
@@ -272,10 +284,12 @@ int vdb_bench_fr_mul(size_t threads, size_t iters, double* mul_per_sec) {
   Context& c = ctx();
   u256* sink = (u256*)scratch_get(0, threads * sizeof(u256));
   if (!sink) return VDB_ERR_OOM;
+  const bool v32 = getenv("VDB_BENCH_MUL32") != nullptr;
   hipLaunchKernelGGL(k_bench_mul, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, (size_t)8);  // warm-up
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipEventRecord(c.ev0, c.stream));
-  hipLaunchKernelGGL(k_bench_mul, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, iters);
+  if (v32) hipLaunchKernelGGL(k_bench_mul32, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, iters);
+  else hipLaunchKernelGGL(k_bench_mul, dim3((unsigned)(threads / 256)), dim3(256), 0, c.stream, sink, iters);
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipEventRecord(c.ev1, c.stream));
   VDB_HIP(hipEventSynchronize(c.ev1));

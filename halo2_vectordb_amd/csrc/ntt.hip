@@ -5,7 +5,7 @@
 // Semantics: X[i] = sum_j a[j] * omega^(i*j), natural order in and out.
 //
 // Structure (MI355X-first, not a port of the CPU recursion):
-//   n = m_0 * m_1 * ... * m_{L-1}, every m_l = 2^S_l <= 256.  Pass l performs, for every residue of
+//   n = m_0 * m_1 * ... * m_{L-1}, every m_l = 2^S_l <= 512.  Pass l performs, for every residue of
 //   the other digits, a size-m_l DFT along digit l inside LDS (decimation in frequency, 2 butterflies
 //   per thread per stage), multiplies by the inter-pass twiddle omega_{N_l}^(q*i) and writes back.
 //   A workgroup owns a tile of m_l x G elements (G*32 B contiguous = whole 128-B lines in HBM).
@@ -241,7 +241,9 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     L = 1;
     S[0] = log_n;
   } else {
-    L = (log_n + 7) / 8;
+    static const uint32_t max_s = getenv("VDB_NTT_MAX_S") ? (uint32_t)atoi(getenv("VDB_NTT_MAX_S")) : 9u;
+    const uint32_t ms = max_s >= 5 && max_s <= 9 ? max_s : 9u;
+    L = (log_n + ms - 1) / ms;  // passes of up to 512 points: 2^16 = 256 x 256, 2^18 = 512 x 512
     for (uint32_t l = 0; l < L; l++) S[l] = log_n / L + (l < log_n % L ? 1 : 0);
   }
   u256 ninv = mont_inv<Fr>(host_fr_from_u64(n));
@@ -295,7 +297,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
         p.logG = 0;
         p.nprev = 0;
       } else {
-        p.logG = 10 - S[l];
+        p.logG = 10 - S[l];  // 1024-element tiles: G = 4 for 256-point, G = 2 for 512-point DFTs
         p.nprev = l;  // only read when last
         for (uint32_t q = 0; q < l && q < NTT_MAX_PASSES; q++) p.prevS[q] = S[q];
       }
@@ -303,6 +305,14 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       uint32_t tiles = (uint32_t)(n / ((uint64_t)m * G));
       size_t lds = (size_t)(2 * G * (m + 1) + 2 * (m / 2 ? m / 2 : 1)) * sizeof(uint4);
       dim3 grid((unsigned)(nc * tiles));
+      if (lds > 64 * 1024) {  // 512-point tiles need 74 KiB of the CU's 160 KiB LDS
+        static bool raised = false;
+        if (!raised) {
+          VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          raised = true;
+        }
+      }
       if (last) {
         {
           VDB_PROF("k_ntt_pass");

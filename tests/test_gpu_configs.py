@@ -1,0 +1,87 @@
+"""BASELINE.json configs at (or near) their full sizes, through the C ABI.
+
+C1 euclidean_distance on two 4-dim vectors, k=13 (LOOKUP_BITS=12): full stream + MockProver-like gate check.
+C2 nearest_vector over 64 x 128-dim SIFT-shaped vectors (LOOKUP_BITS=13): full stream vs the oracle.
+C3 merkle_commitment over 1024 x 128 (154 M trace cells): size-independent properties — the trace kernel's root
+   equals the hash-only kernel's root (two independent GPU code paths) and the oracle's value-level root; sampled
+   leaf traces equal the oracle's trace of that leaf.
+C4 k=16 MSM: exact closed form with known discrete logs (65,536 points).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init()
+    return a
+
+
+def sift(seed, n, dim):
+    v = np.random.default_rng(seed).integers(0, 219, size=(n, dim)).astype(np.float64)
+    v[v.sum(axis=1) == 0, 0] = 1
+    return v
+
+
+def test_c1_euclid_k13_mock(api, O):
+    a, b = [0.123, 0.456, 1.789, 1.123], [1.123, 0.456, 0.789, 0.123]   # data/distances.in extended to 4 dims
+    qa, qb = api.quantize([a]), api.quantize([b])
+    got = api.wit_distance("euclidean", qa, qb, L=12, selectors=True)
+    c = O.Ctx(store=True, keygen=True, plan_k=13)
+    c.assign_witnesses(qa[0])
+    c.assign_witnesses(qb[0])
+    r = c.distance("euclidean", qa[0], qb[0], L=12)
+    assert np.array_equal(got["result"][0], r)
+    assert np.array_equal(got["stream"], c.advice()[8:]) and np.array_equal(got["lookup"], c.lookup())
+    assert c.check_gates(12) == 0                      # every gate row and lookup cell satisfied
+    want = float(np.linalg.norm(np.array(a) - np.array(b)))
+    assert abs(float(api.dequantize(got["result"])[0]) - want) <= 1e-6 * want
+    # 3 advice + 1 lookup column at k = 13
+    assert len(c.break_points()) + 1 == 3 and -(-c.n_lookup // (8192 - 9)) == 1
+
+
+def test_c2_nearest_64x128(api, O):
+    db, q = sift(20260002, 64, 128), sift(20261002, 1, 128)[0]
+    qdb, qq = api.quantize(db), api.quantize(q)
+    got = api.wit_nearest("euclidean", qq, qdb, L=13)
+    c = O.Ctx(store=True)
+    ind, res = c.nearest_vector("euclidean", qq, qdb, L=13)
+    assert np.array_equal(got["indicator"], ind) and np.array_equal(got["result"], res)
+    assert np.array_equal(got["stream"], c.advice()) and np.array_equal(got["lookup"], c.lookup())
+    want = int(np.argmin(np.linalg.norm(db - q, axis=1)))
+    assert [int(v) for v in O.fr_to_ints(ind)].index(1) == want
+
+
+def test_c3_merkle_1024x128(api, O):
+    v = api.quantize(sift(20260003, 1024, 128), 32)   # examples/merkle.rs uses PRECISION_BITS = 32
+    got = api.wit_merkle(v)
+    assert got["stream"].shape[0] == 1024 * (64 * 2256 + 2250) + 1023 * (2256 + 2250)
+    assert np.array_equal(got["root"], api.poseidon_merkle_root(v))
+    assert np.array_equal(got["root"], O.poseidon_merkle_root(v))
+    leaf_cells = 64 * 2256 + 2250
+    for leaf in (0, 517, 1023):
+        c = O.Ctx(store=True)
+        c.merkle_commitment(v[leaf:leaf + 1])
+        assert np.array_equal(got["stream"][leaf * leaf_cells:(leaf + 1) * leaf_cells], c.advice()[:leaf_cells])
+
+
+def test_c4_msm_k16_closed_form(api, O):
+    k, n = 16, 1 << 16
+    rng = np.random.default_rng(20260004)
+    hs = [int(x) for x in rng.integers(1, 1 << 62, size=n)]
+    bases = O.g1_mul_generator(hs)
+    srs = api.Srs(k, None, bases)
+    vals = rng.integers(0, 1 << 15, size=n)
+    vals[rng.random(n) < 0.4] = 0
+    vals[rng.random(n) < 0.1] = 1
+    small = [int(x) for x in vals]
+    neg = [(R - int(x)) % R for x in rng.integers(0, 1 << 60, size=n)]
+    cols = np.stack([O.fr_from_ints(small), O.fr_from_ints(neg), O.random_fr(rng, n)])
+    got = api.msm_batch(srs, cols, basis=1)
+    ks = [sum(x * h for x, h in zip(O.fr_to_ints(cc), hs)) % R for cc in cols]
+    assert np.array_equal(got, O.g1_mul_generator(ks))
+    srs.free()

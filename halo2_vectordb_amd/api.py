@@ -213,6 +213,13 @@ def _u64():
     return ctypes.c_uint64(0)
 
 
+def _split_flags(flags):
+    """flag byte per advice cell: bit 0 = gate start (selector), bit 1 = data-independent constant cell"""
+    if flags is None:
+        return dict(selectors=None, const_mask=None, flags=None)
+    return dict(selectors=flags & 1, const_mask=(flags >> 1) & 1, flags=flags)
+
+
 def wit_distance(metric, a, b, P=48, L=13, selectors=False):
     """a, b: (n_pairs, dim, 4).  Returns dict(stream, lookup, selectors, result)."""
     lib = _lib.init()
@@ -226,7 +233,7 @@ def wit_distance(metric, a, b, P=48, L=13, selectors=False):
     res = np.zeros((n, 4), dtype=np.uint64)
     check(lib.vdb_wit_distance(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(a), _p(b), _sz(n), _sz(dim), _p(stream), _p(lookup),
                                _p(sel) if selectors else None, _p(res)))
-    return dict(stream=stream, lookup=lookup, selectors=sel, result=res)
+    return dict(stream=stream, lookup=lookup, **_split_flags(sel), result=res)
 
 
 def wit_nearest(metric, query, vectors, P=48, L=13, selectors=False):
@@ -242,7 +249,7 @@ def wit_nearest(metric, query, vectors, P=48, L=13, selectors=False):
     res = np.zeros((dim, 4), dtype=np.uint64)
     check(lib.vdb_wit_nearest(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(query), _p(vectors), _sz(n), _sz(dim), _p(stream), _p(lookup),
                               _p(sel) if selectors else None, _p(ind), _p(res)))
-    return dict(stream=stream, lookup=lookup, selectors=sel, indicator=ind, result=res)
+    return dict(stream=stream, lookup=lookup, **_split_flags(sel), indicator=ind, result=res)
 
 
 def wit_kmeans(metric, vectors, K, I, P=48, L=13, zero_cached=False, selectors=False):
@@ -259,7 +266,7 @@ def wit_kmeans(metric, vectors, K, I, P=48, L=13, zero_cached=False, selectors=F
     ind = np.zeros((n, K, 4), dtype=np.uint64)
     check(lib.vdb_wit_kmeans(METRICS[metric], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(vectors), _sz(n), _sz(dim), _sz(K), _sz(I), int(zero_cached),
                              _p(stream), _p(lookup), _p(sel) if selectors else None, _p(cent), _p(ind)))
-    return dict(stream=stream, lookup=lookup, selectors=sel, centroids=cent, indicators=ind)
+    return dict(stream=stream, lookup=lookup, **_split_flags(sel), centroids=cent, indicators=ind)
 
 
 def wit_merkle(vectors, zero_cached=False, selectors=False):
@@ -272,7 +279,7 @@ def wit_merkle(vectors, zero_cached=False, selectors=False):
     sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
     root = np.zeros(4, dtype=np.uint64)
     check(lib.vdb_wit_merkle(_p(vectors), _sz(n), _sz(dim), int(zero_cached), _p(stream), _p(sel) if selectors else None, _p(root)))
-    return dict(stream=stream, selectors=sel, root=root)
+    return dict(stream=stream, **_split_flags(sel), root=root)
 
 
 def layout_plan(selectors, k, minimum_rows=9):

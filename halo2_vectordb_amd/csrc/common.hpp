@@ -33,8 +33,8 @@ struct Context {
   };
   std::map<TwKey, u256*> twiddles;
   // grow-only scratch buffers
-  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[4] = {0, 0, 0, 0};
+  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
 };
 
 Context& ctx();

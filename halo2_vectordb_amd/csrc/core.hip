@@ -191,7 +191,7 @@ void vdb_shutdown(void) {
   (void)hipStreamSynchronize(c.stream);
   for (auto& kv : c.twiddles) (void)hipFree(kv.second);
   c.twiddles.clear();
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 6; i++) {
     if (c.scratch[i]) (void)hipFree(c.scratch[i]);
     c.scratch[i] = nullptr;
     c.scratch_bytes[i] = 0;

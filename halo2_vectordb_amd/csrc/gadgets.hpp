@@ -53,12 +53,20 @@ struct WCtx {
   bool count_only;    // host sizing run: count cells, store nothing, never skip
   int err;
   const FpTables* T;
+  // deferred inversions (halo2's Assigned::Rational + batch_invert): instead of a 380-product Fermat chain on
+  // the critical path, (cell position, denominator) is appended here and k_inv_fixup patches the cell later
+  uint64_t* inv_pos;
+  u256* inv_val;
+  uint32_t* inv_cnt;
+  uint32_t inv_cap;
 
   HD bool in_window(uint64_t p) const { return p >= lo && p < hi; }
-  HD void push(const u256& v, bool gate) {
+  // `cst`: the cell holds a data-independent constant of the gate template (QuantumCell::Constant); recorded in
+  // bit 1 of the keygen-side flag byte so the prover's MSM can take those cells from a precomputed point
+  HD void push(const u256& v, bool gate, bool cst = false) {
     if (!count_only && in_window(pos)) {
       adv[pos] = v;
-      if (sel) sel[pos] = gate ? 1 : 0;
+      if (sel) sel[pos] = (uint8_t)((gate ? 1 : 0) | (cst ? 2 : 0));
     }
     pos++;
   }
@@ -91,30 +99,45 @@ struct Gadgets {
     return u256_zero();  // host runs only count the cells
 #endif
   }
+  // value of the inverse cell of an is_zero block that starts at the current position (the cell is pos + 2)
+  HD u256 inv_cell(const u256& x) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (c.inv_cnt) {
+      if (!c.in_window(c.pos + 2)) return T.one;  // this window does not store the cell at all
+      uint32_t i = atomicAdd(c.inv_cnt, 1u);
+      if (i < c.inv_cap) {
+        c.inv_pos[i] = c.pos + 2;
+        c.inv_val[i] = x;
+        return T.one;  // placeholder, overwritten by k_inv_fixup
+      }
+    }
+#endif
+    return mont_inv<Fr>(x);
+  }
   HD u256 inv_or_one(const u256& x) const {
     if (u256_is_zero(x)) return T.one;
-    return mont_inv<Fr>(x);
+    return inv_cell(x);
   }
 
   // ================================================================ GateChip templates
   HD u256 g_add(const u256& a, const u256& b) {  // [a, b, 1, out]
     u256 o = fr_add(a, b);
-    c.push(a, true); c.push(b, false); c.push(T.one, false); c.push(o, false);
+    c.push(a, true); c.push(b, false); c.push(T.one, false, true); c.push(o, false);
     return o;
   }
   HD u256 g_sub(const u256& a, const u256& b) {  // [out, b, 1, a]
     u256 o = fr_sub(a, b);
-    c.push(o, true); c.push(b, false); c.push(T.one, false); c.push(a, false);
+    c.push(o, true); c.push(b, false); c.push(T.one, false, true); c.push(a, false);
     return o;
   }
   HD u256 g_neg(const u256& a) {  // [a, out, 1, 0]
     u256 o = fr_neg(a);
-    c.push(a, true); c.push(o, false); c.push(T.one, false); c.push(zero(), false);
+    c.push(a, true); c.push(o, false); c.push(T.one, false, true); c.push(zero(), false, true);
     return o;
   }
   HD u256 g_mul(const u256& a, const u256& b) {  // [0, a, b, out]
     u256 o = fr_mul(a, b);
-    c.push(zero(), true); c.push(a, false); c.push(b, false); c.push(o, false);
+    c.push(zero(), true, true); c.push(a, false); c.push(b, false); c.push(o, false);
     return o;
   }
   HD u256 g_mul_add(const u256& a, const u256& b, const u256& cc) {  // [c, a, b, out]
@@ -123,29 +146,29 @@ struct Gadgets {
     return o;
   }
   HD void g_assert_bit(const u256& x) {  // [0, x, x, x]
-    c.push(zero(), true); c.push(x, false); c.push(x, false); c.push(x, false);
+    c.push(zero(), true, true); c.push(x, false); c.push(x, false); c.push(x, false);
   }
   HD u256 g_not(const u256& a) { return g_sub(T.one, a); }
   HD u256 g_and(const u256& a, const u256& b) { return g_mul(a, b); }
   HD u256 g_or(const u256& a, const u256& b) {  // [1-b, 1, b, 1, b, a, 1-b, out]
     u256 nb = fr_sub(T.one, b);
     u256 o = fr_sub(fr_add(a, b), fr_mul(a, b));
-    c.push(nb, true); c.push(T.one, false); c.push(b, false); c.push(T.one, false);
+    c.push(nb, true); c.push(T.one, false, true); c.push(b, false); c.push(T.one, false, true);
     c.push(b, true); c.push(a, false); c.push(nb, false); c.push(o, false);
     return o;
   }
   HD u256 g_select(const u256& a, const u256& b, const u256& s) {  // [a-b, 1, b, a, b, sel, a-b, out]
     u256 d = fr_sub(a, b);
     u256 o = u256_is_zero(s) ? b : (u256_eq(s, T.one) ? a : fr_add(fr_mul(d, s), b));
-    c.push(d, true); c.push(T.one, false); c.push(b, false); c.push(a, false);
+    c.push(d, true); c.push(T.one, false, true); c.push(b, false); c.push(a, false);
     c.push(b, true); c.push(s, false); c.push(d, false); c.push(o, false);
     return o;
   }
   // is_zero with the inverse cell supplied (WitnessFraction evaluated)
   HD u256 g_is_zero_inv(const u256& a, const u256& inv) {  // [z, a, inv, 1, 0, a, z, 0]
     u256 z = u256_is_zero(a) ? T.one : zero();
-    c.push(z, true); c.push(a, false); c.push(inv, false); c.push(T.one, false);
-    c.push(zero(), true); c.push(a, false); c.push(z, false); c.push(zero(), false);
+    c.push(z, true); c.push(a, false); c.push(inv, false); c.push(T.one, false, true);
+    c.push(zero(), true, true); c.push(a, false); c.push(z, false); c.push(zero(), false, true);
     return z;
   }
   HD u256 g_is_zero(const u256& a) {
@@ -160,7 +183,7 @@ struct Gadgets {
     return g_is_zero(d);
   }
   HD u256 load_constant(const u256& v) {
-    c.push(v, false);
+    c.push(v, false, true);
     return v;
   }
 
@@ -190,7 +213,7 @@ struct Gadgets {
         u256 lm = limb_mont(u256_extract(ac, i * L, L));
         s = fr_add(s, fr_mul(lm, T.pow2[i * L]));
         c.push(lm, false);
-        c.push(T.pow2[i * L], false);
+        c.push(T.pow2[i * L], false, true);
         c.push(s, i + 1 < k);
         last = lm;
       }
@@ -213,28 +236,31 @@ struct Gadgets {
     }
     return r_range_check(a, from_mont<Fr>(a), bits);
   }
-  HDN void r_check_less_than(const u256& a, const u256& b, uint32_t bits) {
+  HD void r_check_less_than(const u256& a, const u256& b, uint32_t bits, bool b_const = false) {
     // [a + 2^n - b, b, 1, a + 2^n, -2^n, 1, a] gates 0,3 ; then range_check(first, bits)
     uint32_t sz[2] = {7 + rc_cells(bits, T.L), rc_lookups(bits, T.L)};
     if (c.skip(sz[0])) {
       c.advance(sz);
       return;
     }
+    r_check_less_than_emit(a, b, bits, b_const);
+  }
+  HDN void r_check_less_than_emit(const u256& a, const u256& b, uint32_t bits, bool b_const) {
     u256 sa = fr_add(T.pow2[bits], a), chk = fr_sub(sa, b);
-    c.push(chk, true); c.push(b, false); c.push(T.one, false);
-    c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false); c.push(T.one, false); c.push(a, false);
+    c.push(chk, true); c.push(b, false, b_const); c.push(T.one, false, true);
+    c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false, true); c.push(T.one, false, true); c.push(a, false);
     r_range_check(chk, from_mont<Fr>(chk), bits);
   }
   HD void r_check_big_less_than_safe(const u256& a, const u256& bound_mont, uint32_t bound_bits) {
     uint32_t rb = (bound_bits + T.L - 1) / T.L * T.L;
     r_range_check_skippable(a, rb);
-    r_check_less_than(a, bound_mont, rb);
+    r_check_less_than(a, bound_mont, rb, true);  // the bound is a Constant cell
   }
   HD u256 r_is_less_than(const u256& a, const u256& b, uint32_t bits) {
     const uint32_t L = T.L, k = (bits + L - 1) / L, padded = k * L;
     u256 sa = fr_add(T.pow2[padded], a), sh = fr_sub(sa, b);
-    c.push(sh, true); c.push(b, false); c.push(T.one, false);
-    c.push(sa, true); c.push(fr_neg(T.pow2[padded]), false); c.push(T.one, false); c.push(a, false);
+    c.push(sh, true); c.push(b, false); c.push(T.one, false, true);
+    c.push(sa, true); c.push(fr_neg(T.pow2[padded]), false, true); c.push(T.one, false, true); c.push(a, false);
     u256 shc = from_mont<Fr>(sh);
     u256 last = r_range_check(sh, shc, padded + L);
     return g_is_zero_inv(last, inv_small_or_full(last, u256_extract(shc, padded, L)));
@@ -243,7 +269,7 @@ struct Gadgets {
   HD u256 inv_small_or_full(const u256& x, uint32_t v) const {
     if (v == 0) return T.one;
     if (v < 260) return T.small_inv[v];
-    return mont_inv<Fr>(x);
+    return inv_cell(x);
   }
 
   // div_mod(a, 2^shift, a_bits): quotient/remainder by a power of two  (range.rs div_mod)
@@ -252,14 +278,14 @@ struct Gadgets {
     u256 qc = u256_shr(ac, shift), rc = u256_low_bits(ac, shift);
     div = to_mont<Fr>(qc);
     rem = to_mont<Fr>(rc);
-    c.push(rem, true); c.push(T.pow2[shift], false); c.push(div, false); c.push(a, false);
+    c.push(rem, true); c.push(T.pow2[shift], false, true); c.push(div, false); c.push(a, false);
     // div < 2^a_bits / 2^shift + 1 ; rem < 2^shift
     u256 bound = fr_add(T.pow2[a_bits - shift], T.one);
     r_check_big_less_than_safe(div, bound, a_bits - shift + 1);
     r_check_big_less_than_safe(rem, T.pow2[shift], shift + 1);
   }
   // 256-bit schoolbook shift-subtract division of canonical integers (BigUint div_mod_floor)
-  HDN static void divmod_u256(const u256& a, const u256& b, u256& q, u256& r) {
+  HD static void divmod_u256(const u256& a, const u256& b, u256& q, u256& r) {
     q = u256_zero();
     r = u256_zero();
     int nb = (int)u256_bits(a);
@@ -293,7 +319,7 @@ struct Gadgets {
   // ================================================================ FixedPointChip
   // value-only helpers (no cells)
   HD bool v_is_neg(const u256& ac) const { return u256_bits(ac) > 2 * T.P + 1; }  // a >= 2^(2P+1)
-  HDN u256 v_signed_div_scale(const u256& a) const {  // quotient of fixed_point.rs:974-996
+  HD u256 v_signed_div_scale(const u256& a) const {  // quotient of fixed_point.rs:974-996
     u256 ac = from_mont<Fr>(a);
     const uint32_t P = T.P;
     if (u256_bits(ac) > 253 || (u256_bits(ac) == 253 && !u256_is_zero(u256_low_bits(ac, 252)))) {
@@ -311,7 +337,7 @@ struct Gadgets {
   }
   HD u256 v_qmul(const u256& a, const u256& b) const { return v_signed_div_scale(fr_mul(a, b)); }
   HD u256 v_qabs(const u256& a) const { return v_is_neg(from_mont<Fr>(a)) ? fr_neg(a) : a; }
-  HDN u256 v_qdiv(const u256& a, const u256& b, int& err) const {
+  HD u256 v_qdiv(const u256& a, const u256& b, int& err) const {
     u256 ac = from_mont<Fr>(a), bc = from_mont<Fr>(b);
     bool sa = v_is_neg(ac), sb = v_is_neg(bc);
     u256 aa = sa ? fr_neg(a) : a, ba = sb ? fr_neg(b) : b;
@@ -325,21 +351,29 @@ struct Gadgets {
     return (sa != sb) ? fr_neg(qm) : qm;
   }
 
-  HDN u256 fp_is_neg(const u256& a) {  // fixed_point.rs:523-539
+  // Skipped sub-gadgets never make a call: the window test and the value-only path are inline, only real
+  // emission goes through the out-of-line *_emit generators.
+  HD u256 fp_is_neg(const u256& a) {  // fixed_point.rs:523-539
     if (c.skip(T.sz.is_neg[0])) {
       c.advance(T.sz.is_neg);
       return v_is_neg(from_mont<Fr>(a)) ? T.one : zero();
     }
+    return fp_is_neg_emit(a);
+  }
+  HDN u256 fp_is_neg_emit(const u256& a) {
     u256 div, rem;
     r_div_mod_pow2(a, 2 * T.P + 1, 254, div, rem);
     u256 is_pos = g_is_zero(div);
     return g_not(is_pos);
   }
-  HDN u256 fp_qabs(const u256& a) {  // :511-521
+  HD u256 fp_qabs(const u256& a) {  // :511-521
     if (c.skip(T.sz.qabs[0])) {
       c.advance(T.sz.qabs);
       return v_qabs(a);
     }
+    return fp_qabs_emit(a);
+  }
+  HDN u256 fp_qabs_emit(const u256& a) {
     u256 rev = g_neg(a);
     u256 n = fp_is_neg(a);
     return g_select(rev, a, n);
@@ -348,11 +382,14 @@ struct Gadgets {
     u256 na = g_neg(a);
     return g_select(na, a, flag);
   }
-  HDN u256 fp_signed_div_scale(const u256& a) {  // :974-1016, returns the quotient
+  HD u256 fp_signed_div_scale(const u256& a) {  // :974-1016, returns the quotient
     if (c.skip(T.sz.sds[0])) {
       c.advance(T.sz.sds);
       return v_signed_div_scale(a);
     }
+    return fp_signed_div_scale_emit(a);
+  }
+  HDN u256 fp_signed_div_scale_emit(const u256& a) {
     const uint32_t P = T.P;
     u256 ac = from_mont<Fr>(a), div, rem;
     bool neg = u256_bits(ac) > 253 || (u256_bits(ac) == 253 && !u256_is_zero(u256_low_bits(ac, 252)));  // a > 2^252
@@ -372,17 +409,20 @@ struct Gadgets {
       div = to_mont<Fr>(u256_shr(ac, P));
       rem = to_mont<Fr>(u256_low_bits(ac, P));
     }
-    c.push(rem, true); c.push(T.scale, false); c.push(div, false); c.push(a, false);
+    c.push(rem, true); c.push(T.scale, false, true); c.push(div, false); c.push(a, false);
     r_check_big_less_than_safe(rem, T.pow2[P], P + 1);
     u256 dabs = fp_qabs(div);
     r_check_big_less_than_safe(dabs, T.pow2[3 * P], 3 * P + 1);
     return div;
   }
-  HDN u256 fp_qmul(const u256& a, const u256& b) {  // :588-604
+  HD u256 fp_qmul(const u256& a, const u256& b) {  // :588-604
     if (c.skip(T.sz.qmul[0])) {
       c.advance(T.sz.qmul);
       return v_qmul(a, b);
     }
+    return fp_qmul_emit(a, b);
+  }
+  HDN u256 fp_qmul_emit(const u256& a, const u256& b) {
     u256 ab = g_mul(a, b);
     return fp_signed_div_scale(ab);
   }
@@ -398,11 +438,14 @@ struct Gadgets {
     u256 inv = u256_is_zero(d) ? T.one : (u256_eq(d, T.one) ? T.one : fr_neg(T.one));
     return g_is_zero_inv(d, inv);
   }
-  HDN u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
+  HD u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
     if (c.skip(T.sz.qdiv[0])) {
       c.advance(T.sz.qdiv);
       return v_qdiv(a, b, c.err);
     }
+    return fp_qdiv_emit(a, b);
+  }
+  HDN u256 fp_qdiv_emit(const u256& a, const u256& b) {
     const uint32_t P = T.P;
     u256 sa = fp_is_neg(a);
     u256 sb = fp_is_neg(b);
@@ -437,7 +480,8 @@ struct Gadgets {
     u256 result = g_add(x, zero());  // dead qadd(x, 0)
     u256 last = zero();
     for (int i = 0; i < M; i++) {
-      u256 y_add = g_add(last, coef[i]);
+      u256 y_add = fr_add(last, coef[i]);  // qadd(last_y, Constant(coef)): [last_y, coef, 1, out]
+      c.push(last, true, i == 0); c.push(coef[i], false, true); c.push(T.one, false, true); c.push(y_add, false);
       if (i < M - 1) last = fp_qmul(x, y_add);
       else result = y_add;
     }
@@ -446,7 +490,7 @@ struct Gadgets {
   // GateChip::select_from_idx over `n` cells with idx known to be the small integer `idx_small`
   // (or >= n when out of range): idx_to_indicator (v0.3) + select_by_indicator
   template <class CellFn>
-  HD u256 g_select_from_idx(uint32_t n, const u256& idx, uint64_t idx_small, CellFn&& cell) {
+  HD u256 g_select_from_idx(uint32_t n, const u256& idx, uint64_t idx_small, CellFn&& cell, bool cells_const = false) {
     // indicator i: i == 0 -> unrolled is_zero(idx); else is_equal(idx, Constant(i))
     for (uint32_t i = 0; i < n; i++) {
       int64_t diff = (int64_t)idx_small - (int64_t)i;
@@ -458,19 +502,20 @@ struct Gadgets {
           c.pos += 12;
         } else {
           u256 ci = i < 260 ? T.small[i] : to_mont<Fr>(u256_from_u64(i));
-          u256 d = g_sub(idx, ci);
+          u256 d = fr_sub(idx, ci);  // is_equal(idx, Constant(i)) = sub [d, i, 1, idx] + is_zero
+          c.push(d, true); c.push(ci, false, true); c.push(T.one, false, true); c.push(idx, false);
           g_is_zero_inv(d, signed_small_inv(d, diff));
         }
       }
     }
     // select_by_indicator: [0, a0, ind0, s0, a1, ind1, s1, ...]
     u256 s = zero();
-    c.push(zero(), n > 0);
+    c.push(zero(), n > 0, true);
     for (uint32_t i = 0; i < n; i++) {
       u256 ai = cell(i);
       bool hit = (idx_small == i);
       if (hit) s = ai;
-      c.push(ai, false);
+      c.push(ai, false, cells_const);
       c.push(hit ? T.one : zero(), false);
       c.push(s, i + 1 < n);
     }
@@ -480,13 +525,16 @@ struct Gadgets {
     if (v == 0) return T.one;
     if (v > 0 && v < 260) return T.small_inv[v];
     if (v < 0 && v > -260) return fr_neg(T.small_inv[-v]);
-    return mont_inv<Fr>(x);
+    return inv_cell(x);
   }
-  HDN void fp_check_power_of_two(const u256& p2, const u256& e, uint64_t e_small) {  // :688-708
+  HD void fp_check_power_of_two(const u256& p2, const u256& e, uint64_t e_small) {  // :688-708
     if (c.skip(T.sz.cpow2[0])) {
       c.advance(T.sz.cpow2);
       return;
     }
+    fp_check_power_of_two_emit(p2, e, e_small);
+  }
+  HDN void fp_check_power_of_two_emit(const u256& p2, const u256& e, uint64_t e_small) {
     const uint32_t nb = 2 * T.P;
     u256 pc = from_mont<Fr>(p2);
     // num_to_bits: inner_product(bits, pow2) starting with constant 1, then nb assert_bit
@@ -500,7 +548,7 @@ struct Gadgets {
         nset += bit;
         if (bit) s = fr_add(s, T.pow2[i]);
         c.push(bit ? T.one : zero(), false);
-        c.push(T.pow2[i], false);
+        c.push(T.pow2[i], false, true);
         c.push(s, i + 1 < nb);
       }
       for (uint32_t i = 0; i < nb; i++) g_assert_bit(u256_bit(pc, i) ? T.one : zero());
@@ -513,7 +561,7 @@ struct Gadgets {
         uint32_t bit = u256_bit(pc, i);
         run += bit;
         c.push(bit ? T.one : zero(), false);
-        c.push(T.one, false);
+        c.push(T.one, false, true);
         c.push(small(run), i + 1 < nb);
       }
     }
@@ -536,7 +584,7 @@ struct Gadgets {
     return fr_add(ln, fr_mul(fr_neg(shm), T.scale));
   }
   HD u256 small_or_mont(uint64_t v) const { return v < 260 ? T.small[v] : to_mont<Fr>(u256_from_u64(v)); }
-  HDN u256 fp_qlog2(const u256& a) {  // :736-795
+  HD u256 fp_qlog2(const u256& a) {  // :736-795
     if (c.skip(T.sz.qlog2[0])) {
       uint64_t p0 = c.pos, l0 = c.lpos;
       u256 v = v_qlog2(a);
@@ -544,6 +592,9 @@ struct Gadgets {
       c.lpos = l0 + T.sz.qlog2[1];
       return v;
     }
+    return fp_qlog2_emit(a);
+  }
+  HDN u256 fp_qlog2_emit(const u256& a) {
     const uint32_t P = T.P;
     u256 a_assigned = g_add(a, zero());
     u256 is_neg = fp_is_neg(a);
@@ -594,7 +645,7 @@ struct Gadgets {
     if (v_is_neg(from_mont<Fr>(a))) return v_qdiv(T.scale, res_pos, c.err);
     return res_pos;
   }
-  HDN u256 fp_qexp2(const u256& a) {  // :710-734
+  HD u256 fp_qexp2(const u256& a) {  // :710-734
     if (c.skip(T.sz.qexp2[0])) {
       uint64_t p0 = c.pos, l0 = c.lpos;
       u256 v = v_qexp2(a);
@@ -602,13 +653,16 @@ struct Gadgets {
       c.lpos = l0 + T.sz.qexp2[1];
       return v;
     }
+    return fp_qexp2_emit(a);
+  }
+  HDN u256 fp_qexp2_emit(const u256& a) {
     const uint32_t P = T.P;
     u256 a_abs = fp_qabs(a);
     u256 ip, fpart;
     r_div_mod_pow2(a_abs, P, 2 * P, ip, fpart);
     u256 ipc = from_mont<Fr>(ip);
     uint64_t ip_small = u256_bits(ipc) > 32 ? 0xffffffffull : ipc.w[0];
-    u256 ip2 = g_select_from_idx(254, ip, ip_small, [&](uint32_t i) { return T.pow2[i]; });
+    u256 ip2 = g_select_from_idx(254, ip, ip_small, [&](uint32_t i) { return T.pow2[i]; }, true);  // Constant(pow_of_two[i]) cells
     u256 yf = fp_polynomial<13>(fpart, T.exp2_poly, T.sz.poly13);
     u256 res_pos = g_mul(ip2, yf);
     u256 res_neg = fp_qdiv(T.scale, res_pos);

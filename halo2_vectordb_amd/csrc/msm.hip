@@ -129,7 +129,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, size_t n, size_t table_n, uint32_t c, uint32_t W,
                                                                uint32_t* __restrict__ entries, size_t ent_cap,
                                                                uint32_t* __restrict__ task_off, MsmTask* __restrict__ tasks,
-                                                               uint32_t* __restrict__ counters /* [0]=tasks, [1]=overflow */, uint32_t task_cap) {
+                                                               uint32_t* __restrict__ counters /* [0]=tasks, [1]=overflow */, uint32_t task_cap,
+                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
@@ -138,9 +139,11 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __shared__ uint32_t s_base;
   const uint32_t col = blockIdx.x, tid = threadIdx.x;
   const u256* sc = scalars + (size_t)col * n;
+  const uint8_t* mk = skip_mask ? skip_mask + (size_t)col * n : nullptr;
   for (uint32_t b = tid; b < B; b += MSM_SORT_THREADS) hist[b] = 0;
   __syncthreads();
   for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
+    if (mk && mk[i]) continue;  // constant cell: its term is part of the precomputed per-column point
     for_each_digit(ld256(sc + i), c, W, [&](uint32_t, uint32_t d, bool) { atomicAdd(&hist[d - 1], 1u); });
   }
   __syncthreads();
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __syncthreads();
   uint32_t* ent = entries + (size_t)col * ent_cap;
   for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
+    if (mk && mk[i]) continue;
     for_each_digit(ld256(sc + i), c, W, [&](uint32_t j, uint32_t d, bool neg) {
       uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
       ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
@@ -272,7 +276,7 @@ __device__ __forceinline__ XYZZ shfl_xyzz(const XYZZ& p, int src) {
 
 // One wavefront per column: result = sum_b b * B_b with B_b = sum of the partials of bucket b.
 __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ partials, const uint32_t* __restrict__ task_off, uint32_t c,
-                                                   const uint32_t* __restrict__ counters, Affine* __restrict__ out) {
+                                                   const uint32_t* __restrict__ counters, const Affine* __restrict__ add_points, Affine* __restrict__ out) {
   if (counters[1]) return;
   const uint32_t B = 1u << (c - 1);
   const uint32_t col = blockIdx.x, lane = threadIdx.x;
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ part
   if (lane == 0) {
     for (uint32_t d = 0; d < log_per; d++) t2 = xyzz_double(t2);
     xyzz_add(t1, t2);
+    if (add_points) xyzz_add_mixed(t1, ld_affine(add_points + col), false);  // + precomputed constant-cell part
     st_affine(out + col, xyzz_to_affine(t1));
   }
 }
@@ -354,7 +359,8 @@ static uint32_t pick_window(uint32_t k) {
 }
 
 // device-level batched MSM: scalars_dev = n_cols x n (contiguous), out_dev = n_cols affine points
-int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev) {
+int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev, const uint8_t* skip_mask = nullptr,
+                  const Affine* add_points = nullptr) {
   Context& cx = ctx();
   if (n_cols == 0) return VDB_OK;
   const Affine* table = srs->table[basis];
@@ -384,7 +390,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     {
       VDB_PROF("k_msm_sort");
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
-                       ent_cap, task_off, tasks, counters, task_cap);
+                       ent_cap, task_off, tasks, counters, task_cap, skip_mask ? skip_mask + c0 * n : nullptr);
     }
     VDB_LAUNCH_CHECK();
     {
@@ -405,7 +411,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     }
     {
       VDB_PROF("k_msm_reduce");
-      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, out_dev + c0);
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
     }
     VDB_LAUNCH_CHECK();
   }
@@ -511,6 +517,21 @@ int vdb_msm_batch_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, 
   Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
   if (!dout) return VDB_ERR_OOM;
   int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout);
+  if (rc) return rc;
+  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_msm_batch_masked_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev,
+                             const vdb_g1* const_points_dev, vdb_g1* out_host) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && scalars_dev && out_host && (basis == 0 || basis == 1) && skip_mask_dev && const_points_dev, "bad argument");
+  VDB_ARG(srs->table[basis], "srs was loaded without this basis");
+  VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size");
+  if (n_cols == 0) return VDB_OK;
+  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  if (!dout) return VDB_ERR_OOM;
+  int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev));
   if (rc) return rc;
   VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
   VDB_HIP(hipStreamSynchronize(ctx().stream));

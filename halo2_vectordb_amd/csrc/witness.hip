@@ -179,6 +179,11 @@ struct Streams {
   uint8_t* sel;
   u256* lk;
   int* err;
+  // deferred-inversion list (see WCtx)
+  uint64_t* inv_pos;
+  u256* inv_val;
+  uint32_t* inv_cnt;
+  uint32_t inv_cap;
 };
 
 __device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, uint64_t pos, uint64_t lpos) {
@@ -193,6 +198,10 @@ __device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, ui
   c.count_only = false;
   c.err = 0;
   c.T = T;
+  c.inv_pos = s.inv_pos;
+  c.inv_val = s.inv_val;
+  c.inv_cnt = s.inv_cnt;
+  c.inv_cap = s.inv_cap;
   return c;
 }
 
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTable
           for (uint32_t j = 0; j <= tid; j++) s = fr_add(s, sh[j]);
           c.pos = sumbase + 1 + 3ull * (i - 1);
           c.push(v, false);
-          c.push(T->one, false);
+          c.push(T->one, false, true);
           c.push(s, i + 1 < D);
         }
       }
@@ -342,11 +351,59 @@ __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __
   }
 }
 
+// Batched evaluation of the deferred inverse cells: Montgomery's trick over runs of 16 entries
+#define INVFIX_CH 16
+__global__ __launch_bounds__(64) void k_inv_fixup(u256* __restrict__ adv, const uint64_t* __restrict__ pos, const u256* __restrict__ val,
+                                                  const uint32_t* __restrict__ cnt, uint32_t cap) {
+  const uint32_t n = *cnt < cap ? *cnt : cap;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; (uint64_t)t * INVFIX_CH < n; t += stride) {
+    const uint32_t lo = t * INVFIX_CH, hi = lo + INVFIX_CH < n ? lo + INVFIX_CH : n;
+    u256 pre[INVFIX_CH];
+    u256 acc = mont_one<Fr>();
+    for (uint32_t i = lo; i < hi; i++) {
+      pre[i - lo] = acc;
+      acc = fr_mul(acc, val[i]);  // entries are non-zero by construction
+    }
+    acc = mont_inv<Fr>(acc);
+    for (uint32_t i = hi; i-- > lo;) {
+      adv[pos[i]] = fr_mul(acc, pre[i - lo]);
+      acc = fr_mul(acc, val[i]);
+    }
+  }
+}
+// attaches the context-owned deferred-inversion list to `st` and resets its counter
+static int inv_list_attach(Streams& st, uint64_t cells) {
+  uint64_t cap = cells / 16 + 4096;
+  if (cap > (16u << 20)) cap = 16u << 20;
+  uint8_t* buf = (uint8_t*)scratch_get(4, cap * (sizeof(u256) + sizeof(uint64_t)) + 64);
+  if (!buf) return VDB_ERR_OOM;
+  st.inv_cnt = (uint32_t*)buf;
+  st.inv_val = (u256*)(buf + 64);
+  st.inv_pos = (uint64_t*)(buf + 64 + cap * sizeof(u256));
+  st.inv_cap = (uint32_t)cap;
+  VDB_HIP(hipMemsetAsync(st.inv_cnt, 0, sizeof(uint32_t), ctx().stream));
+  return VDB_OK;
+}
+static int inv_list_fixup(const Streams& st) {
+  if (!st.inv_cnt) return VDB_OK;
+  {
+    VDB_PROF("k_inv_fixup");
+    hipLaunchKernelGGL(k_inv_fixup, dim3((unsigned)(ctx().cu_count * 8)), dim3(64), 0, ctx().stream, st.adv, st.inv_pos, st.inv_val, st.inv_cnt, st.inv_cap);
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
 static uint32_t tail_segments(uint32_t n_inst) {
   uint32_t groups = (n_inst + 63) / 64;
   uint32_t s = 4096 / (groups ? groups : 1);
   if (s < 1) s = 1;
   if (s > 64) s = 64;
+  if (const char* e = getenv("VDB_TAIL_SEGMENTS")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 1024) s = (uint32_t)v;
+  }
   return s;
 }
 
@@ -506,23 +563,24 @@ __global__ __launch_bounds__(64) void k_km_div(Streams st, const FpTables* __res
 }
 __global__ void k_push_cells(Streams st, uint64_t pos, u256 a, u256 b, uint32_t n) {
   if (blockIdx.x || threadIdx.x) return;
-  st.adv[pos] = a;
-  if (st.sel) st.sel[pos] = 0;
+  st.adv[pos] = a;  // load_constant / load_zero cells: data-independent
+  if (st.sel) st.sel[pos] = 2;
   if (n > 1) {
     st.adv[pos + 1] = b;
-    if (st.sel) st.sel[pos + 1] = 0;
+    if (st.sel) st.sel[pos + 1] = 2;
   }
 }
 
 // ------------------------------------------------------------------ Poseidon trace (merkle_commitment)
 // cells of PoseidonChip::permutation (halo2-lib community-edition poseidon chip, [UPSTREAM-RECALL])
-__device__ u256 trace_sum(WCtx& c, const FpTables* T, const u256* v, int n) {  // GateChip::sum
+// GateChip::sum; cmask bit i set = v[i] is a Constant cell
+__device__ u256 trace_sum(WCtx& c, const FpTables* T, const u256* v, int n, unsigned cmask) {
   u256 s = v[0];
-  c.push(v[0], n > 1);
+  c.push(v[0], n > 1, cmask & 1u);
   for (int i = 1; i < n; i++) {
     s = fr_add(s, v[i]);
-    c.push(v[i], false);
-    c.push(T->one, false);
+    c.push(v[i], false, (cmask >> i) & 1u);
+    c.push(T->one, false, true);
     c.push(s, i + 1 < n);
   }
   return s;
@@ -539,13 +597,13 @@ __device__ u256 trace_ip_const(WCtx& c, const FpTables* T, const u256* a, const 
     s = u256_zero();
     i0 = 0;
     ng = n;
-    c.push(u256_zero(), ng > 0);
+    c.push(u256_zero(), ng > 0, true);
   }
   int gi = 1;
   for (int i = i0; i < n; i++, gi++) {
     s = fr_add(s, fr_mul(a[i], row[i]));
     c.push(a[i], false);
-    c.push(row[i], false);
+    c.push(row[i], false, true);  // Constant(matrix entry)
     c.push(s, gi < ng);
   }
   return s;
@@ -553,7 +611,9 @@ __device__ u256 trace_ip_const(WCtx& c, const FpTables* T, const u256* a, const 
 __device__ void trace_sbox(Gadgets& g, u256& x, const u256& cst) {
   u256 x2 = g.g_mul(x, x);
   u256 x4 = g.g_mul(x2, x2);
-  x = g.g_mul_add(x, x4, cst);
+  u256 o = fr_add(fr_mul(x, x4), cst);  // mul_add(x, x4, Constant(c)): [c, x, x4, out]
+  g.c.push(cst, true, true); g.c.push(x, false); g.c.push(x4, false); g.c.push(o, false);
+  x = o;
 }
 __device__ void trace_dense(WCtx& c, const FpTables* T, u256 st[PSD_T], const u256 m[PSD_T][PSD_T]) {
   u256 r[PSD_T];
@@ -564,17 +624,17 @@ __device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const
   Gadgets g(c);
   {
     u256 v[2] = {st[0], sp->start[0][0]};
-    st[0] = trace_sum(c, T, v, 2);
+    st[0] = trace_sum(c, T, v, 2, 2u);
   }
   for (int i = 0; i < n_in; i++) {
     u256 v[3] = {st[1 + i], in[i], sp->start[0][1 + i]};
-    st[1 + i] = trace_sum(c, T, v, 3);
+    st[1 + i] = trace_sum(c, T, v, 3, 4u);
   }
   for (int i = n_in + 1, k = 0; i < PSD_T; i++, k++) {
     u256 cst = sp->start[0][i];
     if (k == 0) cst = fr_add(cst, T->one);
     u256 v[2] = {st[i], cst};
-    st[i] = trace_sum(c, T, v, 2);
+    st[i] = trace_sum(c, T, v, 2, 2u);
   }
   for (int r = 1; r < PSD_HALF; r++) {
     for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], sp->start[r][i]);
@@ -586,7 +646,10 @@ __device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const
     trace_sbox(g, st[0], sp->partial[p]);
     u256 r[PSD_T];
     r[0] = trace_ip_const(c, T, st, sp->sparse_row[p], PSD_T);
-    for (int i = 1; i < PSD_T; i++) r[i] = g.g_mul_add(st[0], sp->sparse_col[p][i - 1], st[i]);
+    for (int i = 1; i < PSD_T; i++) {  // mul_add(s0, Constant(e), s_i): [s_i, s0, e, out]
+      r[i] = fr_add(fr_mul(st[0], sp->sparse_col[p][i - 1]), st[i]);
+      c.push(st[i], true); c.push(st[0], false); c.push(sp->sparse_col[p][i - 1], false, true); c.push(r[i], false);
+    }
     for (int i = 0; i < PSD_T; i++) st[i] = r[i];
   }
   for (int r = 0; r < PSD_HALF - 1; r++) {
@@ -661,8 +724,8 @@ __global__ void k_layout_plan(const uint8_t* __restrict__ sel, uint64_t n_cells,
   const uint64_t M = max_rows;
   for (;;) {
     uint64_t r;
-    if (M >= 3 && S + M - 3 < n_cells && sel[S + M - 3]) r = M - 3;
-    else if (M >= 2 && S + M - 2 < n_cells && sel[S + M - 2]) r = M - 2;
+    if (M >= 3 && S + M - 3 < n_cells && (sel[S + M - 3] & 1)) r = M - 3;
+    else if (M >= 2 && S + M - 2 < n_cells && (sel[S + M - 2] & 1)) r = M - 2;
     else r = M - 1;
     if (S + r >= n_cells) break;
     if (cnt < cap) bp[cnt] = r;
@@ -708,6 +771,27 @@ __global__ __launch_bounds__(256) void k_layout_lookup(const u256* __restrict__ 
   st256(cols + idx, v);
 }
 
+// column-layout image of the constant-cell flags (bit 1 of the keygen flag byte): mask[col][row] = 1 when the cell
+// laid out there is a data-independent constant
+__global__ __launch_bounds__(256) void k_layout_const_mask(const uint8_t* __restrict__ flags, uint64_t n_cells, const uint64_t* __restrict__ starts,
+                                                           const uint64_t* __restrict__ bp, uint64_t n_bp, uint32_t k, uint8_t* __restrict__ mask) {
+  const uint64_t rows = 1ull << k;
+  uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (n_bp + 1) * rows) return;
+  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t start = starts[col];
+  uint64_t len = col < n_bp ? bp[col] + 1 : n_cells - start;
+  mask[idx] = row < len ? (flags[start + row] >> 1) & 1 : 0;
+}
+// scalars' = mask ? v : 0 (constant part) or mask ? 0 : v (variable part)
+__global__ __launch_bounds__(256) void k_mask_select(const u256* __restrict__ in, const uint8_t* __restrict__ mask, uint64_t n, int keep_const,
+                                                     u256* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool m = mask[i] != 0;
+  st256(out + i, (m == (keep_const != 0)) ? ld256(in + i) : u256_zero());
+}
+
 // ------------------------------------------------------------------ helpers for the host-pointer ABI
 struct DevBuf {
   void* p = nullptr;
@@ -744,10 +828,12 @@ int wit_distance_dev(FpEntry* fp, int metric, const u256* a, const u256* b, size
                      uint64_t lk_off, u256* result) {
   DistLayout dl;
   TRY(dist_layout(fp->host, metric, dim, &dl));
+  TRY(inv_list_attach(st, n_pairs * dl.total_cells));
   InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 1};
   u256* mid = (u256*)scratch_get(0, n_pairs * 3 * sizeof(u256) + 64);
   if (!mid) return VDB_ERR_OOM;
-  return run_distances(st, fp, dl, im, (uint32_t)n_pairs, a, b, mid, result);
+  TRY(run_distances(st, fp, dl, im, (uint32_t)n_pairs, a, b, mid, result));
+  return inv_list_fixup(st);
 }
 
 struct NvLayout {
@@ -770,6 +856,7 @@ int wit_nearest_dev(FpEntry* fp, int metric, const u256* query, const u256* vect
   DistLayout dl;
   NvLayout nl;
   TRY(nv_layout(fp, metric, n, dim, &dl, &nl));
+  TRY(inv_list_attach(st, nl.total));
   InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 0xffffffffu};  // (vector_i, query)
   u256* mid = (u256*)scratch_get(0, (n * 5 + 8) * sizeof(u256));
   if (!mid) return VDB_ERR_OOM;
@@ -802,7 +889,7 @@ int wit_nearest_dev(FpEntry* fp, int metric, const u256* query, const u256* vect
                      (uint32_t)n, (uint32_t)dim, result);
   }
   VDB_LAUNCH_CHECK();
-  return VDB_OK;
+  return inv_list_fixup(st);
 }
 
 static int km_layout(FpEntry* fp, int metric, size_t n, size_t dim, size_t K, DistLayout* dl, KmLayout* kl) {
@@ -827,6 +914,7 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
   DistLayout dl;
   KmLayout kl;
   TRY(km_layout(fp, metric, n, dim, K, &dl, &kl));
+  TRY(inv_list_attach(st, I * kl.iter));
   hipStream_t s = ctx().stream;
   size_t need = (n * K * 4 + K * dim * 2 + K + K * n * dim + 16) * sizeof(u256);
   u256* buf = (u256*)scratch_get(0, need);
@@ -879,7 +967,7 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
     lpos += kl.iter_l;
   }
   VDB_HIP(hipMemcpyAsync(cent_out, cent, K * dim * sizeof(u256), hipMemcpyDeviceToDevice, s));
-  return VDB_OK;
+  return inv_list_fixup(st);
 }
 
 struct MkLayout {
@@ -978,6 +1066,10 @@ struct HostStreams {
     st.sel = want_sel ? sel.as<uint8_t>() : nullptr;
     st.lk = lk.as<u256>();
     st.err = err.as<int>();
+    st.inv_pos = nullptr;
+    st.inv_val = nullptr;
+    st.inv_cnt = nullptr;
+    st.inv_cap = 0;
     return VDB_OK;
   }
   int finish(vdb_fr* stream_out, vdb_fr* lookup_out, uint8_t* sel_out, uint64_t cells, uint64_t lookups) {
@@ -1098,7 +1190,7 @@ int vdb_wit_kmeans_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* vectors
   int* derr = (int*)scratch_get(1, 64);
   if (!derr) return VDB_ERR_OOM;
   VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
-  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr};
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0};
   TRY(wit_kmeans_dev(fp, metric, as_u256(vectors_dev), n, dim, K, I, zero_cached, st, 0, 0, as_u256(centroids_dev), as_u256(indicators_dev)));
   return check_err_flag(derr);
 }
@@ -1132,7 +1224,7 @@ int vdb_wit_merkle_size(size_t n, size_t dim, int zero_cached, uint64_t* cells) 
 int vdb_wit_merkle_dev(const vdb_fr* vectors_dev, size_t n, size_t dim, int zero_cached, vdb_fr* stream_dev, uint8_t* selector_dev, vdb_fr* root_dev) {
   VDB_REQUIRE_INIT();
   VDB_ARG(vectors_dev && stream_dev && root_dev && n > 0, "null pointer");
-  Streams st{as_u256(stream_dev), selector_dev, nullptr, nullptr};
+  Streams st{as_u256(stream_dev), selector_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   return wit_merkle_dev(as_u256(vectors_dev), n, dim, zero_cached, st, 0, as_u256(root_dev));
 }
 int vdb_wit_merkle(const vdb_fr* vectors, size_t n, size_t dim, int zero_cached, vdb_fr* stream_out, uint8_t* selector_out, vdb_fr* root_out) {
@@ -1225,6 +1317,40 @@ int vdb_layout_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k
     VDB_PROF("k_layout_lookup");
     hipLaunchKernelGGL(k_layout_lookup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(lookup_dev), n_cells, max_rows, k, n_cols,
                      as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_layout_const_mask_dev(const uint8_t* flags_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, uint8_t* mask_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(flags_dev && mask_dev && (break_points || n_bp == 0) && k <= 28, "bad argument");
+  const uint64_t rows = 1ull << k;
+  uint64_t* d = (uint64_t*)scratch_get(1, (2 * n_bp + 2) * sizeof(uint64_t));
+  if (!d) return VDB_ERR_OOM;
+  uint64_t* dbp = d;
+  uint64_t* dst = d + n_bp;
+  if (n_bp) VDB_HIP(hipMemcpyAsync(dbp, break_points, n_bp * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
+  {
+    VDB_PROF("k_layout_starts");
+    hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
+  }
+  VDB_LAUNCH_CHECK();
+  uint64_t total = (n_bp + 1) * rows;
+  {
+    VDB_PROF("k_layout_const_mask");
+    hipLaunchKernelGGL(k_layout_const_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, flags_dev, n_cells, dst, dbp, n_bp, k, mask_dev);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_mask_select_dev(const vdb_fr* in_dev, const uint8_t* mask_dev, uint64_t n, int keep_const, vdb_fr* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(in_dev && mask_dev && out_dev, "null pointer");
+  if (n == 0) return VDB_OK;
+  {
+    VDB_PROF("k_mask_select");
+    hipLaunchKernelGGL(k_mask_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(in_dev), mask_dev, n, keep_const, as_u256(out_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

@@ -67,6 +67,7 @@ class KmeansHotPath:
         self.rank, self.world = col_shard
         self.seed = seed
         self.tau = tau
+        self.factor_constants = True
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self):
@@ -96,7 +97,6 @@ class KmeansHotPath:
         check(lib.vdb_layout_plan_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), self.k, MINIMUM_ROWS, api._p(self.bp), ctypes.c_uint64(self.bp.size),
                                       ctypes.byref(nbp)))
         self.bp = self.bp[:nbp.value]
-        d_sel.free()
         self.n_adv_cols = len(self.bp) + 1
         max_rows = self.rows - MINIMUM_ROWS
         self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
@@ -119,8 +119,40 @@ class KmeansHotPath:
         g, gl = api.srs_setup_unsafe(self.k, tau)
         self.g_lagrange = gl
         self.srs = api.Srs(self.k, None, gl)
+        # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
+        # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
+        self.d_mask = api.DeviceBuffer(self.n_cols * self.rows)
+        check(lib.vdb_memset_dev(self.d_mask.ptr, 0, ctypes.c_size_t(self.n_cols * self.rows)))
+        check(lib.vdb_layout_const_mask_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k, self.d_mask.ptr))
+        d_sel.free()
+        self._layout()
+        n_el = self.n_cols * self.rows
+        d_tmp = api.DeviceBuffer(n_el * B)
+        check(lib.vdb_mask_select_dev(self.d_cols.ptr, self.d_mask.ptr, ctypes.c_uint64(n_el), 1, d_tmp.ptr))
+        const_pts = np.zeros((self.n_cols, 8), dtype=np.uint64)
+        check(lib.vdb_msm_batch_dev(self.srs.h, 1, d_tmp.ptr, ctypes.c_size_t(self.n_cols), ctypes.c_size_t(self.rows), api._p(const_pts)))
+        d_tmp.free()
+        self.const_points = const_pts
+        self.d_cpts = api.DeviceBuffer(const_pts.nbytes)
+        self.d_cpts.upload(const_pts)
+        self.const_cell_fraction = float(self.d_mask.download((self.n_adv_cols * self.rows,), dtype=np.uint8).mean()) if self.n_adv_cols * self.rows <= (1 << 28) else None
         api.sync()
         return self
+
+    def set_vectors(self, vectors_f64):
+        """Prove for a different database of the same shape (the keygen-time data above stays untouched)."""
+        self.vectors_f64 = np.asarray(vectors_f64, dtype=np.float64)
+        self.qvec = api.quantize(self.vectors_f64, self.P)
+        self.d_vec.upload(self.qvec)
+
+    def _layout(self):
+        lib, B = self.lib, 32
+        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                         self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
+        if self.n_lk_cols:
+            check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
+                                            self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
+                                            self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
 
     def _witness(self, sel=None):
         lib = self.lib
@@ -143,20 +175,16 @@ class KmeansHotPath:
 
         stage("witness", self._witness)
 
-        def layout():
-            check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
-                                             self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
-            if self.n_lk_cols:
-                check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
-                                                self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
-                                                self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
-
-        stage("layout", layout)
+        stage("layout", self._layout)
         my = self.d_cols.at(self.col_lo * self.rows * B)
         self.commitments = np.zeros((self.my_cols, 8), dtype=np.uint64)
 
         def commit():
-            check(lib.vdb_msm_batch_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), api._p(self.commitments)))
+            if self.factor_constants:
+                check(lib.vdb_msm_batch_masked_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows),
+                                                   self.d_mask.at(self.col_lo * self.rows), self.d_cpts.at(self.col_lo * 64), api._p(self.commitments)))
+            else:
+                check(lib.vdb_msm_batch_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), api._p(self.commitments)))
 
         stage("commit_msm", commit)
 
@@ -177,17 +205,9 @@ class KmeansHotPath:
 
     def relayout(self):
         """Re-run witness + layout only (columns are overwritten in place by the NTT stage)."""
-        t = {}
         self._witness()
-        lib, B = self.lib, 32
-        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
-                                         self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
-        if self.n_lk_cols:
-            check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
-                                            self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
-                                            self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
+        self._layout()
         api.sync()
-        return t
 
     def results(self):
         cent = self.d_cent.download((self.K, self.dim, 4))
@@ -195,7 +215,7 @@ class KmeansHotPath:
         return cent, ind
 
     def free(self):
-        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext"):
+        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext", "d_mask", "d_cpts"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

@@ -91,9 +91,10 @@ int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr *x, double *out, siz
  *      halo2-base `Context.advice` (stream_out) and `cells_to_lookup` (lookup_out), in order, for
  *      already-assigned quantized inputs; sizes come from the matching *_size call.
  *      metric: 0 euclidean, 1 cosine, 2 manhattan (DistanceChip, src/gadget/distance.rs:97-195).
- *      selector_out (optional, 1 byte per advice cell) marks gate starts — the keygen-side information
+ *      selector_out (optional, 1 flag byte per advice cell): bit 0 marks gate starts — the keygen-side information
  *      from which vdb_layout_plan derives the break points that the reference pins in configs/*.json
- *      (src/scaffold/mod.rs:272, 285-287).  VDB_ERR_DOMAIN replaces the reference's panics. ---------- */
+ *      (src/scaffold/mod.rs:272, 285-287); bit 1 marks cells that hold a data-independent QuantumCell::Constant
+ *      of the gate templates (used by vdb_msm_batch_masked_dev).  VDB_ERR_DOMAIN replaces the reference's panics. ---------- */
 int vdb_wit_distance_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n_pairs, size_t dim, uint64_t *cells, uint64_t *lookups);
 /* DistanceChip::{euclidean,cosine,manhattan}_distance for n_pairs independent (a_i, b_i) */
 int vdb_wit_distance(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a, const vdb_fr *b, size_t n_pairs, size_t dim,
@@ -133,6 +134,10 @@ int vdb_layout_columns_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uin
                            const vdb_fr *blind_dev, uint32_t n_blind);
 int vdb_layout_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr *cols_dev, uint64_t n_cols,
                           const vdb_fr *blind_dev, uint32_t n_blind);
+/* keygen side: column-layout image ((n_bp + 1) x 2^k bytes) of the constant-cell flags (bit 1 of the flag bytes) */
+int vdb_layout_const_mask_dev(const uint8_t *flags_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, uint8_t *mask_dev);
+/* out = mask ? in : 0 (keep_const = 1) or mask ? 0 : in (keep_const = 0), elementwise over n field elements */
+int vdb_mask_select_dev(const vdb_fr *in_dev, const uint8_t *mask_dev, uint64_t n, int keep_const, vdb_fr *out_dev);
 
 /* ---- b1 SRS: replaces halo2 ParamsKZG::{get_g, g_lagrange} as consumed by commit / commit_lagrange;
  *      the reference obtains the params with gen_srs(k) (src/scaffold/mod.rs:260) ------------------ */
@@ -153,6 +158,11 @@ int vdb_msm(const vdb_srs *srs, int basis, const vdb_fr *scalars, size_t n, vdb_
 int vdb_msm_batch(const vdb_srs *srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
 /* scalars_dev: contiguous n_cols x n in HBM; out_host: n_cols points */
 int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, vdb_g1 *out_host);
+/* Prover-side commit with the constant cells factored out: cells flagged in skip_mask_dev (n_cols x n bytes, from
+ * vdb_layout_const_mask_dev) are skipped and const_points_dev[col] — the keygen-time MSM of exactly those cells
+ * (vdb_mask_select_dev(keep_const = 1) + vdb_msm_batch_dev) — is added.  Same group element as vdb_msm_batch_dev. */
+int vdb_msm_batch_masked_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, const uint8_t *skip_mask_dev,
+                             const vdb_g1 *const_points_dev, vdb_g1 *out_host);
 
 /* ---- b3 NTT: replaces halo2 arithmetic::best_fft / EvaluationDomain::{lagrange_to_coeff,
  *      coeff_to_extended} (reached from src/scaffold/mod.rs:296) ------------------------------ */

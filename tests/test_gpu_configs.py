@@ -85,3 +85,46 @@ def test_c4_msm_k16_closed_form(api, O):
     ks = [sum(x * h for x, h in zip(O.fr_to_ints(cc), hs)) % R for cc in cols]
     assert np.array_equal(got, O.g1_mul_generator(ks))
     srs.free()
+
+
+def test_constant_factoring_is_data_independent(api, O):
+    """Keygen with database A, prove database B: the commitments computed with the constant cells factored out
+    (vdb_msm_batch_masked_dev + keygen-time constant points) must equal the plain MSM of B's real columns."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    hp = KmeansHotPath(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11).setup()
+    assert hp.const_cell_fraction is not None and 0.15 < hp.const_cell_fraction < 0.6
+    rng = np.random.default_rng(999)
+    hp.set_vectors(rng.integers(0, 219, size=(14, 6)).astype(np.float64) + rng.random((14, 6)))
+    got = hp.step().copy()
+    hp.relayout()
+    cols = hp.download_columns(list(range(hp.n_cols)))
+    want = O.msm_batch(cols, hp.g_lagrange, threads=4)
+    assert np.array_equal(got, want)
+    hp.factor_constants = False
+    assert np.array_equal(hp.step(), want)
+    # the stream itself matches the oracle for database B
+    qv = O.quantize(hp.vectors_f64, 48)
+    c = O.Ctx(store=True)
+    c.assign_witnesses(qv)
+    c.kmeans("euclidean", qv, 3, 2, P=48, L=9)
+    assert np.array_equal(hp.d_stream.download((hp.n_cells, 4)), c.advice())
+    hp.free()
+
+
+def test_constant_flags_mark_only_constants(api, O):
+    """cells flagged constant must hold the same value for two different inputs of the same shape"""
+    rng = np.random.default_rng(5)
+    for metric in ("euclidean", "cosine", "manhattan"):
+        a1, b1 = O.quantize(rng.uniform(-3, 3, (2, 7))), O.quantize(rng.uniform(-3, 3, (2, 7)))
+        a2, b2 = O.quantize(rng.uniform(-300, 300, (2, 7))), O.quantize(rng.uniform(-300, 300, (2, 7)))
+        g1 = api.wit_distance(metric, a1, b1, selectors=True)
+        g2 = api.wit_distance(metric, a2, b2, selectors=True)
+        assert np.array_equal(g1["flags"], g2["flags"])
+        m = g1["const_mask"].astype(bool)
+        assert m.mean() > 0.15
+        assert np.array_equal(g1["stream"][m], g2["stream"][m])
+    v1, v2 = O.quantize(rng.random((5, 4)), 32), O.quantize(rng.random((5, 4)) * 7, 32)
+    m1, m2 = api.wit_merkle(v1, selectors=True), api.wit_merkle(v2, selectors=True)
+    m = m1["const_mask"].astype(bool)
+    assert np.array_equal(m1["flags"], m2["flags"]) and m.mean() > 0.15
+    assert np.array_equal(m1["stream"][m], m2["stream"][m])

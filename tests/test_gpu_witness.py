@@ -141,7 +141,7 @@ def test_layout_plan_and_columns(api, O):
     for x, y in zip(a, b):
         c.distance("euclidean", x, y)
     got = api.wit_distance("euclidean", a, b, selectors=True)
-    bp = api.layout_plan(got["selectors"], k)
+    bp = api.layout_plan(got["flags"], k)
     assert np.array_equal(bp, c.break_points())
     cols, lcols = api.layout_columns(got["stream"], bp, k, lookup=got["lookup"])
     want = O.layout_columns(c.advice(), c.break_points(), k, len(bp) + 1)

@@ -96,29 +96,64 @@ HD u256 u256_from_u64(uint64_t v) {
   z.w[1] = (uint32_t)(v >> 32);
   return z;
 }
+// Shifts by a runtime amount use static limb indices only: a runtime limb index (a.w[j]) would force the
+// register array into scratch memory on the GPU.  Word shift by conditional moves (4, 2, 1 words), then bits.
 // logical right shift by s in [0, 255]
 HD u256 u256_shr(const u256& a, unsigned s) {
-  u256 o;
-  unsigned ws = s >> 5, bs = s & 31;
+  u256 t = a;
+  const unsigned ws = s >> 5, bs = s & 31;
+  if (ws & 4) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    unsigned j = i + ws;
-    uint32_t lo = j < 8 ? a.w[j < 8 ? j : 0] : 0u;
-    uint32_t hi = j + 1 < 8 ? a.w[j + 1 < 8 ? j + 1 : 0] : 0u;
-    o.w[i] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
+    for (int i = 0; i < 8; i++) t.w[i] = i + 4 < 8 ? t.w[i + 4 < 8 ? i + 4 : 0] : 0u;
   }
-  return o;
+  if (ws & 2) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.w[i] = i + 2 < 8 ? t.w[i + 2 < 8 ? i + 2 : 0] : 0u;
+  }
+  if (ws & 1) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.w[i] = i + 1 < 8 ? t.w[i + 1 < 8 ? i + 1 : 0] : 0u;
+  }
+  if (bs) {
+    u256 o;
+#pragma unroll
+    for (int i = 0; i < 7; i++) o.w[i] = (t.w[i] >> bs) | (t.w[i + 1] << (32 - bs));
+    o.w[7] = t.w[7] >> bs;
+    return o;
+  }
+  return t;
 }
 HD u256 u256_shl(const u256& a, unsigned s) {
-  u256 o;
-  unsigned ws = s >> 5, bs = s & 31;
+  u256 t = a;
+  const unsigned ws = s >> 5, bs = s & 31;
+  if (ws & 4) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    int j = i - (int)ws;
-    uint32_t cur = j >= 0 ? a.w[j >= 0 ? j : 0] : 0u;
-    uint32_t prev = j - 1 >= 0 ? a.w[j - 1 >= 0 ? j - 1 : 0] : 0u;
-    o.w[i] = bs ? (cur << bs) | (prev >> (32 - bs)) : cur;
+    for (int i = 7; i >= 0; i--) t.w[i] = i - 4 >= 0 ? t.w[i - 4 >= 0 ? i - 4 : 0] : 0u;
   }
+  if (ws & 2) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) t.w[i] = i - 2 >= 0 ? t.w[i - 2 >= 0 ? i - 2 : 0] : 0u;
+  }
+  if (ws & 1) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) t.w[i] = i - 1 >= 0 ? t.w[i - 1 >= 0 ? i - 1 : 0] : 0u;
+  }
+  if (bs) {
+    u256 o;
+#pragma unroll
+    for (int i = 7; i >= 1; i--) o.w[i] = (t.w[i] << bs) | (t.w[i - 1] >> (32 - bs));
+    o.w[0] = t.w[0] << bs;
+    return o;
+  }
+  return t;
+}
+// a >> s for 0 < s < 32 with static limb indexing only (a runtime limb index would force the register array
+// into scratch memory); used to walk a scalar digit by digit
+HD u256 u256_shr_small(const u256& a, unsigned s) {
+  u256 o;
+#pragma unroll
+  for (int i = 0; i < 7; i++) o.w[i] = (a.w[i] >> s) | (a.w[i + 1] << (32 - s));
+  o.w[7] = a.w[7] >> s;
   return o;
 }
 // keep the low `bits` bits
@@ -142,11 +177,9 @@ HD unsigned u256_bits(const u256& a) {
 HD uint32_t u256_bit(const u256& a, unsigned i) { return (a.w[i >> 5] >> (i & 31)) & 1u; }
 // extract `len` (<= 32) bits starting at bit `pos`
 HD uint32_t u256_extract(const u256& a, unsigned pos, unsigned len) {
-  unsigned wi = pos >> 5, bi = pos & 31;
-  uint64_t v = wi < 8 ? a.w[wi] : 0u;
-  if (wi + 1 < 8) v |= (uint64_t)a.w[wi + 1] << 32;
-  v >>= bi;
-  return (uint32_t)(v & ((len >= 32) ? 0xffffffffull : ((1ull << len) - 1ull)));
+  if (pos >= 256) return 0u;
+  u256 t = u256_shr(a, pos);
+  return len >= 32 ? t.w[0] : (t.w[0] & ((1u << len) - 1u));
 }
 
 template <class M>
@@ -251,6 +284,125 @@ HD u256 mont_mul(const u256& a, const u256& b) {
   uint32_t borrow = u256_sub(s, r, p);
   return borrow ? r : s;
 }
+// ---- lazy-reduction variants for the NTT butterflies -------------------------------------------------------
+// Values live in [0, 2p) (any 256-bit pattern below 4p is a valid multiplier input).  The constant operand (a
+// twiddle w) is pre-split into the nine 29-bit limbs of 32*w mod p, so a * Bp * 2^-261 = a * w * 2^-256 needs no
+// operand shift, and because a * Bp / 2^261 + p < 1.03 p the final conditional subtraction is dropped.
+template <class M>
+HD void mont_pre_limbs(const u256& w, uint32_t Bp[9]) {
+  u256 x = w;
+#pragma unroll
+  for (int i = 0; i < 5; i++) x = mod_add<M>(x, x);  // 32 * w mod p
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
+    uint32_t lo = x.w[wb];
+    uint32_t hi = wb + 1 < 8 ? x.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
+    Bp[k] = (ob ? ((lo >> ob) | (hi << (32 - ob))) : lo) & 0x1fffffffu;
+  }
+}
+template <class M>
+HD u256 mont_mul_lazy_pre(const u256& a, const uint32_t Bp[9], const uint32_t* A_limbs = nullptr) {
+  constexpr uint32_t MASK = 0x1fffffffu;
+  uint32_t A[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    if (A_limbs) {
+      A[k] = A_limbs[k];
+    } else {
+      int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
+      uint32_t lo = a.w[wb];
+      uint32_t hi = wb + 1 < 8 ? a.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
+      A[k] = ob ? ((lo >> ob) | (hi << (32 - ob))) : lo;
+      if (k < 8) A[k] &= MASK;  // top limb keeps every remaining bit (a < 2^256)
+    }
+  }
+  uint64_t T[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) T[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) T[i + j] += (uint64_t)A[i] * Bp[j];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    uint32_t m = ((uint32_t)T[k] * M::INV29) & MASK;
+#pragma unroll
+    for (int j = 0; j < 9; j++) T[k + j] += (uint64_t)m * M::P29[j];
+    T[k + 1] += T[k] >> 29;
+  }
+  uint32_t L[9];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    uint64_t v = T[9 + k] + carry;
+    L[k] = (uint32_t)v & MASK;
+    carry = v >> 29;
+  }
+  u256 r;
+  r.w[0] = L[0] | (L[1] << 29);
+  r.w[1] = (L[1] >> 3) | (L[2] << 26);
+  r.w[2] = (L[2] >> 6) | (L[3] << 23);
+  r.w[3] = (L[3] >> 9) | (L[4] << 20);
+  r.w[4] = (L[4] >> 12) | (L[5] << 17);
+  r.w[5] = (L[5] >> 15) | (L[6] << 14);
+  r.w[6] = (L[6] >> 18) | (L[7] << 11);
+  r.w[7] = (L[7] >> 21) | (L[8] << 8);
+  return r;  // < 2p
+}
+// a (any value below 4p) times a canonical b: result in [0, 2p), no final subtraction
+// (a * b / 2^256 + p < 4p * 0.19 + p < 2p)
+template <class M>
+HD u256 mont_mul_lazy(const u256& a, const u256& b) {
+  constexpr uint32_t MASK = 0x1fffffffu;
+  uint32_t A[9], B[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int pos = 29 * k - 5;  // limb k of (a << 5)
+    if (pos < 0) {
+      A[k] = (a.w[0] << 5) & MASK;
+    } else {
+      int w = pos >> 5, o = pos & 31;
+      uint32_t lo = w < 8 ? a.w[w < 8 ? w : 0] : 0u;
+      uint32_t hi = w + 1 < 8 ? a.w[w + 1 < 8 ? w + 1 : 0] : 0u;
+      A[k] = o ? ((lo >> o) | (hi << (32 - o))) : lo;
+      if (k < 8) A[k] &= MASK;
+    }
+    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
+    uint32_t lob = b.w[wb];
+    uint32_t hib = wb + 1 < 8 ? b.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
+    B[k] = (ob ? ((lob >> ob) | (hib << (32 - ob))) : lob) & MASK;
+  }
+  return mont_mul_lazy_pre<M>(u256_zero(), B, A);
+}
+// u + v for u, v in [0, 2p): result in [0, 2p)
+template <class M>
+HD u256 lazy_add(const u256& u, const u256& v) {
+  u256 r, s, p2;
+  u256 p = mod_p<M>();
+  u256_add(p2, p, p);
+  u256_add(r, u, v);  // < 4p < 2^256
+  uint32_t borrow = u256_sub(s, r, p2);
+  return borrow ? r : s;
+}
+// u - v + 2p for u, v in [0, 2p): result in (0, 4p), a valid lazy multiplier input
+template <class M>
+HD u256 lazy_sub(const u256& u, const u256& v) {
+  u256 t, r, p2;
+  u256 p = mod_p<M>();
+  u256_add(p2, p, p);
+  u256_add(t, u, p2);
+  u256_sub(r, t, v);
+  return r;
+}
+// [0, 2p) -> [0, p)
+template <class M>
+HD u256 lazy_canon(const u256& a) {
+  u256 s, p = mod_p<M>();
+  uint32_t borrow = u256_sub(s, a, p);
+  return borrow ? a : s;
+}
+
 template <class M>
 HD u256 mont_sqr(const u256& a) {
   return mont_mul<M>(a, a);
@@ -308,9 +460,16 @@ template <class M>
 HD u256 mont_pow(const u256& a, const u256& e) {
   u256 acc = mont_one<M>();
   int nb = (int)u256_bits(e);
-  for (int i = nb - 1; i >= 0; i--) {
+  if (nb == 0) return acc;
+  u256 ee = u256_shl(e, 256u - (unsigned)nb);  // top exponent bit at bit 255; then shift left one bit per step
+  for (int i = 0; i < nb; i++) {
     acc = mont_sqr<M>(acc);
-    if (u256_bit(e, (unsigned)i)) acc = mont_mul<M>(acc, a);
+    if (ee.w[7] >> 31) acc = mont_mul<M>(acc, a);
+    u256 t;
+#pragma unroll
+    for (int k = 7; k >= 1; k--) t.w[k] = (ee.w[k] << 1) | (ee.w[k - 1] >> 31);
+    t.w[0] = ee.w[0] << 1;
+    ee = t;
   }
   return acc;
 }

@@ -206,18 +206,25 @@ struct Gadgets {
     } else {
       // inner_product(limbs, [1, 2^L, 2^2L, ...]) starting with the constant 1:
       // [l0, l1, B1, s1, l2, B2, s2, ...] then the k limbs are queued for lookup
-      uint32_t l0 = u256_extract(ac, 0, L);
-      u256 s = limb_mont(l0);
+      // limbs are peeled off a running right shift (static register indexing only)
+      const uint32_t lmask = (1u << L) - 1u;
+      u256 rem = ac;
+      u256 s = limb_mont(rem.w[0] & lmask);
       c.push(s, true);
       for (uint32_t i = 1; i < k; i++) {
-        u256 lm = limb_mont(u256_extract(ac, i * L, L));
+        rem = u256_shr_small(rem, L);
+        u256 lm = limb_mont(rem.w[0] & lmask);
         s = fr_add(s, fr_mul(lm, T.pow2[i * L]));
         c.push(lm, false);
         c.push(T.pow2[i * L], false, true);
         c.push(s, i + 1 < k);
         last = lm;
       }
-      for (uint32_t i = 0; i < k; i++) c.lookup(limb_mont(u256_extract(ac, i * L, L)));
+      rem = ac;
+      for (uint32_t i = 0; i < k; i++) {
+        c.lookup(limb_mont(rem.w[0] & lmask));
+        rem = u256_shr_small(rem, L);
+      }
     }
     if (rem == 1) {
       g_assert_bit(last);
@@ -289,14 +296,26 @@ struct Gadgets {
     q = u256_zero();
     r = u256_zero();
     int nb = (int)u256_bits(a);
-    for (int i = nb - 1; i >= 0; i--) {
-      r = u256_shl(r, 1);
-      r.w[0] |= u256_bit(a, (unsigned)i);
-      if (u256_geq(r, b)) {
-        u256 t;
-        u256_sub(t, r, b);
-        r = t;
-        q.w[i >> 5] |= 1u << (i & 31);
+    if (nb == 0) return;
+    u256 cur = u256_shl(a, 256u - (unsigned)nb);  // dividend bits leave through bit 255 (static indexing only)
+    for (int i = 0; i < nb; i++) {
+      u256 t;
+#pragma unroll
+      for (int k = 7; k >= 1; k--) t.w[k] = (r.w[k] << 1) | (r.w[k - 1] >> 31);
+      t.w[0] = (r.w[0] << 1) | (cur.w[7] >> 31);
+      r = t;
+#pragma unroll
+      for (int k = 7; k >= 1; k--) t.w[k] = (cur.w[k] << 1) | (cur.w[k - 1] >> 31);
+      t.w[0] = cur.w[0] << 1;
+      cur = t;
+#pragma unroll
+      for (int k = 7; k >= 1; k--) t.w[k] = (q.w[k] << 1) | (q.w[k - 1] >> 31);
+      t.w[0] = q.w[0] << 1;
+      q = t;
+      u256 d;
+      if (!u256_sub(d, r, b)) {  // r >= b
+        r = d;
+        q.w[0] |= 1u;
       }
     }
   }
@@ -540,25 +559,33 @@ struct Gadgets {
     // num_to_bits: inner_product(bits, pow2) starting with constant 1, then nb assert_bit
     uint32_t nset = 0;
     {
-      u256 s = u256_bit(pc, 0) ? T.one : zero();
-      nset += u256_bit(pc, 0);
+      u256 rem = pc;  // bits are peeled off a running right shift (static register indexing only)
+      u256 s = (rem.w[0] & 1u) ? T.one : zero();
+      nset += rem.w[0] & 1u;
       c.push(s, true);
       for (uint32_t i = 1; i < nb; i++) {
-        uint32_t bit = u256_bit(pc, i);
+        rem = u256_shr_small(rem, 1);
+        uint32_t bit = rem.w[0] & 1u;
         nset += bit;
         if (bit) s = fr_add(s, T.pow2[i]);
         c.push(bit ? T.one : zero(), false);
         c.push(T.pow2[i], false, true);
         c.push(s, i + 1 < nb);
       }
-      for (uint32_t i = 0; i < nb; i++) g_assert_bit(u256_bit(pc, i) ? T.one : zero());
+      rem = pc;
+      for (uint32_t i = 0; i < nb; i++) {
+        g_assert_bit((rem.w[0] & 1u) ? T.one : zero());
+        rem = u256_shr_small(rem, 1);
+      }
     }
     // sum(bits): [b0, b1, 1, s1, b2, 1, s2, ...]
     {
-      uint32_t run = u256_bit(pc, 0);
+      u256 rem = pc;
+      uint32_t run = rem.w[0] & 1u;
       c.push(run ? T.one : zero(), nb > 1);
       for (uint32_t i = 1; i < nb; i++) {
-        uint32_t bit = u256_bit(pc, i);
+        rem = u256_shr_small(rem, 1);
+        uint32_t bit = rem.w[0] & 1u;
         run += bit;
         c.push(bit ? T.one : zero(), false);
         c.push(T.one, false, true);
@@ -568,7 +595,12 @@ struct Gadgets {
     u256 sum = small(nset);
     u256 sm1 = g_sub(sum, T.one);
     g_is_zero_inv(sm1, signed_small_inv(sm1, (int64_t)nset - 1));
-    u256 bit = g_select_from_idx(nb, e, e_small, [&](uint32_t i) { return u256_bit(pc, i) ? T.one : u256_zero(); });
+    u256 walk = pc;  // the cell callback is invoked for i = 0, 1, 2, ... in order
+    u256 bit = g_select_from_idx(nb, e, e_small, [&](uint32_t) {
+      u256 v = (walk.w[0] & 1u) ? T.one : u256_zero();
+      walk = u256_shr_small(walk, 1);
+      return v;
+    });
     u256 bm1 = g_sub(bit, T.one);
     g_is_zero_inv(bm1, u256_is_zero(bm1) ? T.one : fr_neg(T.one));
   }

@@ -73,8 +73,8 @@ __device__ __forceinline__ bool fold_scalar(u256& s) {
 
 template <class F>
 __device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t c, uint32_t W, F&& f) {
+  if (u256_is_zero(mont_scalar)) return;  // Montgomery form of zero is zero: skip the product for the ~1/3 zero cells
   u256 s = from_mont<Fr>(mont_scalar);
-  if (u256_is_zero(s)) return;
   bool neg = fold_scalar(s);
   uint32_t carry = 0;
   const uint32_t half = 1u << (c - 1), full = 1u << c;
@@ -82,7 +82,8 @@ __device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t
   uint32_t wend = u256_bits(s) / c + 2;
   if (wend > W) wend = W;
   for (uint32_t j = 0; j < wend; j++) {
-    uint32_t d = u256_extract(s, c * j, c) + carry;
+    uint32_t d = (s.w[0] & (full - 1)) + carry;
+    s = u256_shr_small(s, c);
     bool dneg = false;
     if (d > half) {
       d = full - d;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
                                                                uint32_t* __restrict__ entries, size_t ent_cap,
                                                                uint32_t* __restrict__ task_off, MsmTask* __restrict__ tasks,
                                                                uint32_t* __restrict__ counters /* [0]=tasks, [1]=overflow */, uint32_t task_cap,
-                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */) {
+                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
     for_each_digit(ld256(sc + i), c, W, [&](uint32_t, uint32_t d, bool) { atomicAdd(&hist[d - 1], 1u); });
   }
   __syncthreads();
+  if (dbg == 1) return;
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
   const uint32_t ipt = (B + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS;
   uint32_t cnt_local = 0, task_local = 0;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   }
   if (tid == 0) toff[B] = base + total_tasks;
   __syncthreads();
+  if (dbg == 2) return;
   uint32_t* ent = entries + (size_t)col * ent_cap;
   for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
     if (mk && mk[i]) continue;
@@ -390,7 +393,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     {
       VDB_PROF("k_msm_sort");
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
-                       ent_cap, task_off, tasks, counters, task_cap, skip_mask ? skip_mask + c0 * n : nullptr);
+                       ent_cap, task_off, tasks, counters, task_cap, skip_mask ? skip_mask + c0 * n : nullptr, getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0);
     }
     VDB_LAUNCH_CHECK();
     {

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     lds_put(lo, hi, g * row + j, v);
   }
   __syncthreads();
-  // DIF stages: natural order in, bit-reversed order out
+  // DIF stages: natural order in, bit-reversed order out.  Lazy reduction: every value stays in [0, 2p); the
+  // difference u - v + 2p feeds the multiplier unreduced and the product needs no final subtraction.
   for (uint32_t s = 0; s < S; s++) {
     uint32_t logh = S - 1 - s, h = 1u << logh;
     for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
@@ -133,9 +134,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       uint32_t r = pj & (h - 1), j0 = ((pj >> logh) << (logh + 1)) + r;
       uint32_t a0 = g * row + j0, a1 = a0 + h;
       u256 u = lds_get(lo, hi, a0), v = lds_get(lo, hi, a1);
-      u256 d = fr_sub(u, v);
-      if (h > 1) d = fr_mul(d, lds_get(twlo, twhi, r << s));
-      lds_put(lo, hi, a0, fr_add(u, v));
+      u256 d = lazy_sub<Fr>(u, v);
+      if (h > 1) {
+        d = mont_mul_lazy<Fr>(d, lds_get(twlo, twhi, r << s));
+      } else {  // last stage: twiddle 1; bring (0, 4p) back to [0, 2p)
+        u256 p2, t, pp = mod_p<Fr>();
+        u256_add(p2, pp, pp);
+        const uint32_t keep = u256_sub(t, d, p2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.w[i] = keep ? d.w[i] : t.w[i];
+      }
+      lds_put(lo, hi, a0, lazy_add<Fr>(u, v));
       lds_put(lo, hi, a1, d);
     }
     __syncthreads();
@@ -147,7 +156,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     if (!LAST) {
       uint64_t i = (uint64_t)i0 + g;
       uint64_t ex = ((uint64_t)q * i) << (p.log_n - S - p.log_inner);
-      if (ex) v = fr_mul(v, ld256(tw + ex));
+      if (ex) v = fr_mul(v, ld256(tw + ex));  // canonical result for any 256-bit input
+      else v = lazy_canon<Fr>(v);
       st256(cout + base + (uint64_t)q * jstride + g, v);
     } else {
       uint64_t pos;
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         pos += (uint64_t)q << (p.log_n - S);
       }
       if (p.scale) v = fr_mul(v, p.ninv);
+      else v = lazy_canon<Fr>(v);
       st256(cout + pos, v);
     }
   }

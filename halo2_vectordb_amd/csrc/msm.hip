@@ -12,9 +12,10 @@
 //  * Scalars are sign-folded (s > r/2 -> r - s with the point negated) so the many "negative" witness
 //    values become short; zero digits cost nothing.
 //  * k_msm_sort: one workgroup per column does a counting sort of the (digit -> table index) pairs
-//    entirely in LDS (histogram, scan, scatter) and cuts every bucket into tasks of <= LCAP points, which
-//    removes the skew of witness columns (e.g. ~10 % of all cells are the constant 1).
-//  * k_msm_accum: one thread per task, XYZZ accumulator in VGPRs, mixed additions from the table.
+//    entirely in LDS (histogram, scan, scatter) and cuts the sorted list into ranges of LCAP entries; bucket
+//    changes inside a range open new segments (one partial sum each), which removes the skew of witness columns.
+//  * k_msm_accum: one thread per range (every lane does exactly LCAP mixed additions), XYZZ accumulator in VGPRs.
+//  * k_msm_combine: segmented tree reduction of the partials of every bucket.
 //  * k_msm_reduce: one wavefront per column; each lane folds its slice of buckets with the running-sum
 //    trick, lanes are combined with wavefront shuffles, lane 0 normalises to affine.
 // Roofline: algorithmic HBM traffic is 32 B per scalar (+ bases once); the kernels are bound by 32-bit
@@ -34,8 +35,14 @@ namespace vdb {
 #define MSM_SORT_THREADS 1024
 #define MSM_LCAP 32
 
-struct MsmTask {
-  uint32_t col, bucket, start, len;
+// A range is MSM_LCAP consecutive entries of one column's bucket-sorted entry list.  Inside a range every change of
+// bucket starts a new *segment*; each segment produces one partial sum.  Segment numbering follows the sorted order,
+// so the partials of one bucket are contiguous: [seg_off[b], seg_off[b + 1]).
+struct MsmRange {
+  uint32_t col, bucket, start, len, seg0, pad;
+};
+struct MsmSegInfo {
+  uint32_t col, bucket;
 };
 
 // ---------------------------------------------------------------- table precompute
@@ -126,18 +133,20 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return res;
 }
 
-// One workgroup per column: counting sort of (bucket -> table index|sign) and task cutting.
+// One workgroup per column: counting sort of (bucket -> table index|sign), segment numbering and range cutting.
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, size_t n, size_t table_n, uint32_t c, uint32_t W,
                                                                uint32_t* __restrict__ entries, size_t ent_cap,
-                                                               uint32_t* __restrict__ task_off, MsmTask* __restrict__ tasks,
-                                                               uint32_t* __restrict__ counters /* [0]=tasks, [1]=overflow */, uint32_t task_cap,
+                                                               uint32_t* __restrict__ seg_off, uint32_t* __restrict__ bucket_off, MsmRange* __restrict__ ranges,
+                                                               uint32_t* __restrict__ counters /* [0]=segments, [1]=overflow, [2]=max segs/bucket, [3]=ranges */,
+                                                               uint32_t seg_cap, uint32_t range_cap,
                                                                const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
   uint32_t* cursor = sh + B;      // B
-  uint32_t* wave_sums = sh + 2 * B;  // 18
-  __shared__ uint32_t s_base;
+  uint32_t* ucnt = sh + 2 * B;    // B
+  uint32_t* wave_sums = sh + 3 * B;  // 18
+  __shared__ uint32_t s_base, s_rbase;
   const uint32_t col = blockIdx.x, tid = threadIdx.x;
   const u256* sc = scalars + (size_t)col * n;
   const uint8_t* mk = skip_mask ? skip_mask + (size_t)col * n : nullptr;
@@ -151,53 +160,91 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   if (dbg == 1) return;
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
   const uint32_t ipt = (B + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS;
-  uint32_t cnt_local = 0, task_local = 0;
+  uint32_t cnt_local = 0;
   for (uint32_t q = 0; q < ipt; q++) {
     uint32_t b = tid * ipt + q;
-    if (b < B) {
-      cnt_local += hist[b];
-      task_local += (hist[b] + MSM_LCAP - 1) / MSM_LCAP;
+    if (b < B) cnt_local += hist[b];
+  }
+  uint32_t total_cnt, total_ua;
+  const uint32_t cnt_pre0 = block_exclusive_scan(cnt_local, wave_sums, &total_cnt);
+  // buckets whose first entry is not LCAP-aligned open one extra segment
+  uint32_t ua_local = 0;
+  {
+    uint32_t off = cnt_pre0;
+    for (uint32_t q = 0; q < ipt; q++) {
+      uint32_t b = tid * ipt + q;
+      if (b < B) {
+        if (hist[b] && (off % MSM_LCAP)) ua_local++;
+        off += hist[b];
+      }
     }
   }
-  uint32_t total_cnt, total_tasks;
-  uint32_t cnt_pre = block_exclusive_scan(cnt_local, wave_sums, &total_cnt);
-  uint32_t task_pre = block_exclusive_scan(task_local, wave_sums, &total_tasks);
+  const uint32_t ua_pre0 = block_exclusive_scan(ua_local, wave_sums, &total_ua);
+  const uint32_t nranges = (total_cnt + MSM_LCAP - 1) / MSM_LCAP, nseg = nranges + total_ua;
   if (tid == 0) {
-    uint32_t base = atomicAdd(&counters[0], total_tasks);
-    if (base + total_tasks > task_cap || total_cnt > ent_cap) {
+    uint32_t base = atomicAdd(&counters[0], nseg);
+    uint32_t rb = atomicAdd(&counters[3], nranges);
+    if (base + nseg > seg_cap || rb + nranges > range_cap || total_cnt > ent_cap) {
       atomicExch(&counters[1], 1u);
       base = 0xffffffffu;
     }
     s_base = base;
+    s_rbase = rb;
   }
   __syncthreads();
-  const uint32_t base = s_base;
-  uint32_t* toff = task_off + (size_t)col * (B + 1);
+  const uint32_t base = s_base, rbase = s_rbase;
+  uint32_t* soff = seg_off + (size_t)col * (B + 1);
+  uint32_t* boff = bucket_off + (size_t)col * (B + 1);
   if (base == 0xffffffffu) {  // overflow: publish an empty column so later kernels stay in bounds
-    for (uint32_t b = tid; b <= B; b += MSM_SORT_THREADS) toff[b] = 0;
+    for (uint32_t b = tid; b <= B; b += MSM_SORT_THREADS) {
+      soff[b] = 0;
+      boff[b] = 0;
+    }
     return;
   }
-  for (uint32_t q = 0; q < ipt; q++) {
-    uint32_t b = tid * ipt + q;
-    if (b < B) {
-      uint32_t cnt = hist[b];
-      cursor[b] = cnt_pre;
-      toff[b] = base + task_pre;
-      uint32_t nt = (cnt + MSM_LCAP - 1) / MSM_LCAP;
-      for (uint32_t t = 0; t < nt; t++) {
-        MsmTask tk;
-        tk.col = col;
-        tk.bucket = b + 1;
-        tk.start = cnt_pre + t * MSM_LCAP;
-        uint32_t rem = cnt - t * MSM_LCAP;
-        tk.len = rem < MSM_LCAP ? rem : MSM_LCAP;
-        tasks[base + task_pre + t] = tk;
+  {
+    uint32_t off = cnt_pre0, ua = ua_pre0;
+    for (uint32_t q = 0; q < ipt; q++) {
+      uint32_t b = tid * ipt + q;
+      if (b < B) {
+        uint32_t cnt = hist[b];
+        cursor[b] = off;
+        ucnt[b] = ua;
+        boff[b] = off;
+        soff[b] = base + (off + MSM_LCAP - 1) / MSM_LCAP + ua;
+        if (cnt) {
+          uint32_t segs = (off + cnt + MSM_LCAP - 1) / MSM_LCAP - off / MSM_LCAP;
+          if (segs > 1) atomicMax(&counters[2], segs);  // lets k_msm_combine skip passes nobody needs
+          if (off % MSM_LCAP) ua++;
+        }
+        off += cnt;
       }
-      cnt_pre += cnt;
-      task_pre += nt;
     }
   }
-  if (tid == 0) toff[B] = base + total_tasks;
+  if (tid == 0) {
+    soff[B] = base + nseg;
+    boff[B] = total_cnt;
+  }
+  __syncthreads();
+  // range descriptors: starting bucket by binary search over the (monotone) bucket offsets in LDS
+  for (uint32_t r = tid; r < nranges; r += MSM_SORT_THREADS) {
+    const uint32_t x = r * MSM_LCAP;
+    uint32_t lo_b = 0, hi_b = B;  // last b with cursor[b] <= x
+    while (hi_b - lo_b > 1) {
+      uint32_t mid = (lo_b + hi_b) >> 1;
+      if (cursor[mid] <= x) lo_b = mid;
+      else hi_b = mid;
+    }
+    const uint32_t bo = cursor[lo_b];
+    MsmRange rg;
+    rg.col = col;
+    rg.bucket = lo_b;
+    rg.start = x;
+    rg.len = total_cnt - x < MSM_LCAP ? total_cnt - x : MSM_LCAP;
+    rg.seg0 = base + r + ucnt[lo_b] + ((bo % MSM_LCAP) && bo < x ? 1u : 0u);
+    rg.pad = 0;
+    ranges[rbase + r] = rg;
+  }
   __syncthreads();
   if (dbg == 2) return;
   uint32_t* ent = entries + (size_t)col * ent_cap;
@@ -210,47 +257,65 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   }
 }
 
-// One thread per task: sum of <= LCAP table points
+// One thread per range: exactly MSM_LCAP mixed additions per lane (full lane utilisation); the accumulator is
+// flushed to the next segment slot whenever the sorted entry list moves on to another bucket.
 __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ table, const uint32_t* __restrict__ entries, size_t ent_cap,
-                                                   const MsmTask* __restrict__ tasks, const uint32_t* __restrict__ counters,
-                                                   XYZZ* __restrict__ partials, uint32_t task_cap) {
+                                                   const MsmRange* __restrict__ ranges, const uint32_t* __restrict__ bucket_off, uint32_t B,
+                                                   const uint32_t* __restrict__ counters, XYZZ* __restrict__ partials, MsmSegInfo* __restrict__ seginfo,
+                                                   uint32_t range_cap) {
   if (counters[1]) return;  // sort overflowed (never expected: capacities are worst-case)
-  const uint32_t total = counters[0] < task_cap ? counters[0] : task_cap;
+  const uint32_t total = counters[3] < range_cap ? counters[3] : range_cap;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    MsmTask tk = tasks[t];
-    const uint32_t* e = entries + (size_t)tk.col * ent_cap + tk.start;
+    MsmRange rg = ranges[t];
+    const uint32_t* e = entries + (size_t)rg.col * ent_cap;
+    const uint32_t* bo = bucket_off + (size_t)rg.col * (B + 1);
+    uint32_t b = rg.bucket, seg = rg.seg0, next = bo[b + 1];
     XYZZ acc = xyzz_identity();
     // software prefetch: the gather of the next table point is in flight during the current addition
-    uint32_t v = e[0];
+    uint32_t v = e[rg.start];
     Affine nxt = ld_affine(table + (v & 0x7fffffffu));
-    for (uint32_t q = 0; q < tk.len; q++) {
+    for (uint32_t q = 0; q < rg.len; q++) {
+      const uint32_t pos = rg.start + q;
+      if (pos == next) {  // bucket boundary: close the segment
+        st_xyzz(partials + seg, acc);
+        seginfo[seg].col = rg.col;
+        seginfo[seg].bucket = b;
+        seg++;
+        acc = xyzz_identity();
+        do {
+          b++;
+          next = bo[b + 1];
+        } while (next == pos);  // skip empty buckets
+      }
       Affine p = nxt;
       bool neg = (v >> 31) != 0;
-      if (q + 1 < tk.len) {
-        v = e[q + 1];
+      if (q + 1 < rg.len) {
+        v = e[pos + 1];
         nxt = ld_affine(table + (v & 0x7fffffffu));
       }
       xyzz_add_mixed(acc, p, neg);
     }
-    st_xyzz(partials + t, acc);
+    st_xyzz(partials + seg, acc);
+    seginfo[seg].col = rg.col;
+    seginfo[seg].bucket = b;
   }
 }
-
 
 // Segmented tree reduction of the partial sums of every bucket: in pass p a bucket that still holds
 // len_p > 1 partials folds its upper half onto its lower half (len_{p+1} = ceil(len_p / 2)).  One
 // thread per task slot; after ceil(log2(max tasks per bucket)) passes the sum of bucket b sits in the
 // first slot of its segment.  This is what removes the witness-column skew from the reduce kernel.
-__global__ __launch_bounds__(256) void k_msm_combine(XYZZ* __restrict__ partials, const MsmTask* __restrict__ tasks, const uint32_t* __restrict__ task_off,
+__global__ __launch_bounds__(256) void k_msm_combine(XYZZ* __restrict__ partials, const MsmSegInfo* __restrict__ seginfo, const uint32_t* __restrict__ task_off,
                                                      const uint32_t* __restrict__ counters, uint32_t B, uint32_t pass, uint32_t task_cap) {
   if (counters[1]) return;
+  if ((1u << pass) >= counters[2]) return;  // every bucket is already folded to one partial
   const uint32_t total = counters[0] < task_cap ? counters[0] : task_cap;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    MsmTask tk = tasks[t];
+    MsmSegInfo tk = seginfo[t];
     const uint32_t* toff = task_off + (size_t)tk.col * (B + 1);
-    uint32_t s = toff[tk.bucket - 1], len = toff[tk.bucket] - s;
+    uint32_t s = toff[tk.bucket], len = toff[tk.bucket + 1] - s;
     for (uint32_t q = 0; q < pass && len > 1; q++) len = (len + 1) >> 1;
     if (len <= 1) continue;
     uint32_t half = (len + 1) >> 1, i = t - s;
@@ -369,52 +434,57 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   const Affine* table = srs->table[basis];
   const uint32_t c = srs->c, W = srs->W, B = srs->B;
   const size_t ent_cap = n * W;
-  const size_t task_cap_col = B + (ent_cap + MSM_LCAP - 1) / MSM_LCAP;
+  const size_t range_cap_col = (ent_cap + MSM_LCAP - 1) / MSM_LCAP;  // worst case: every digit non-zero
+  const size_t seg_cap_col = B + range_cap_col;
   // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
   // thousands of independent column reductions in flight
-  size_t per_col = ent_cap * 4 + task_cap_col * (sizeof(MsmTask) + sizeof(XYZZ)) + (B + 1) * 4;
+  size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ)) + 2 * (B + 1) * 4;
   size_t nb = ((size_t)40 << 30) / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;
   if (nb > 4096) nb = 4096;
-  if (nb * task_cap_col > 0x7fffffffull) nb = 0x7fffffffull / task_cap_col;
+  if (nb * seg_cap_col > 0x7fffffffull) nb = 0x7fffffffull / seg_cap_col;
   uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 256);
   if (!buf) return VDB_ERR_OOM;
   uint32_t* entries = (uint32_t*)buf;
-  MsmTask* tasks = (MsmTask*)(buf + nb * ent_cap * 4);
-  XYZZ* partials = (XYZZ*)((uint8_t*)tasks + nb * task_cap_col * sizeof(MsmTask));
-  uint32_t* task_off = (uint32_t*)((uint8_t*)partials + nb * task_cap_col * sizeof(XYZZ));
-  uint32_t* counters = task_off + nb * (B + 1);
-  const uint32_t task_cap = (uint32_t)(nb * task_cap_col);
-  size_t lds = (2 * (size_t)B + 32) * sizeof(uint32_t);
+  XYZZ* partials = (XYZZ*)(buf + nb * ent_cap * 4);
+  MsmRange* ranges = (MsmRange*)((uint8_t*)partials + nb * seg_cap_col * sizeof(XYZZ));
+  MsmSegInfo* seginfo = (MsmSegInfo*)((uint8_t*)ranges + nb * range_cap_col * sizeof(MsmRange));
+  uint32_t* seg_off = (uint32_t*)((uint8_t*)seginfo + nb * seg_cap_col * sizeof(MsmSegInfo));
+  uint32_t* bucket_off = seg_off + nb * (B + 1);
+  uint32_t* counters = bucket_off + nb * (B + 1);
+  const uint32_t seg_cap = (uint32_t)(nb * seg_cap_col), range_cap = (uint32_t)(nb * range_cap_col);
+  size_t lds = (3 * (size_t)B + 32) * sizeof(uint32_t);
   for (size_t c0 = 0; c0 < n_cols; c0 += nb) {
     size_t nc = n_cols - c0 < nb ? n_cols - c0 : nb;
-    VDB_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), cx.stream));
+    VDB_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), cx.stream));
     {
       VDB_PROF("k_msm_sort");
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
-                       ent_cap, task_off, tasks, counters, task_cap, skip_mask ? skip_mask + c0 * n : nullptr, getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0);
+                       ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
+                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0);
     }
     VDB_LAUNCH_CHECK();
     {
       VDB_PROF("k_msm_accum");
-      hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, tasks, counters,
-                       partials, task_cap);
+      hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, ranges, bucket_off, B,
+                       counters, partials, seginfo, range_cap);
     }
     VDB_LAUNCH_CHECK();
     {
-      // ceil(log2(max tasks per bucket)) <= ceil(log2(n * W / LCAP)) passes; later passes exit immediately
-      uint32_t max_nt = (uint32_t)((ent_cap + MSM_LCAP - 1) / MSM_LCAP), passes = 0;
+      // at most ceil(log2(max segments per bucket)) passes do work; the rest exit on the device-side maximum.
+      // (A one-thread-per-bucket sequential fold was measured 8x slower: serial tails of the heavy buckets.)
+      uint32_t max_nt = (uint32_t)range_cap_col + 1, passes = 0;
       while ((1u << passes) < max_nt) passes++;
       for (uint32_t ps = 0; ps < passes; ps++) {
         VDB_PROF("k_msm_combine");
-        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, tasks, task_off, counters, B, ps, task_cap);
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, seginfo, seg_off, counters, B, ps, seg_cap);
       }
       VDB_LAUNCH_CHECK();
     }
     {
       VDB_PROF("k_msm_reduce");
-      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, task_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, seg_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
     }
     VDB_LAUNCH_CHECK();
   }

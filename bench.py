@@ -9,8 +9,9 @@ advice / lookup-advice column (MSM, Lagrange basis) -> lagrange_to_coeff (iNTT 2
 "next" rows and are NOT part of this number.
 
 metric = constraints/sec where a constraint is one advice cell or one lookup cell of the halo2-base
-flat stream.  Multi-GPU: columns are sharded over ranks (strong scaling, witness
-generation replicated), commitments all-gathered over RCCL.
+flat stream.  Multi-GPU: columns are sharded over ranks (strong scaling; every rank walks the
+cheap value-only path of the whole circuit but emits only the cells of its own columns), commitments
+all-gathered over RCCL.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -149,7 +150,7 @@ def main():
         elapsed = float(t.item())
         # the one real exchange step: gather the 64-byte commitments of every rank's column shard
         from halo2_vectordb_amd.pipeline import gather_commitments
-        commitments = gather_commitments(dist, commitments, hp.n_cols, rank, world, dev)
+        commitments = gather_commitments(dist, commitments, hp.n_adv_cols, hp.n_lk_cols, rank, world, dev)
 
     total_cells = hp.n_cells + hp.n_lookup
     ms_per_step = elapsed / args.steps * 1e3
@@ -204,7 +205,7 @@ def main():
             "config": {"workload": "kmeans K=4 I=8 over 256x128-dim SIFT-shaped vectors, P=48, LOOKUP_BITS=15, euclidean, k=16 (BASELINE configs[3])"
                        if not args.small else "SMALL functional check (invalid as a bench line)",
                        "advice_cells": hp.n_cells, "lookup_cells": hp.n_lookup, "advice_columns": hp.n_adv_cols,
-                       "lookup_columns": hp.n_lk_cols, "rows": hp.rows, "parallelism": f"columns sharded over {world} GPU(s), witness replicated",
+                       "lookup_columns": hp.n_lk_cols, "rows": hp.rows, "parallelism": f"advice/lookup columns sharded over {world} GPU(s); each rank emits only its columns' witness cells",
                        "seed": hp.seed},
             "proof_stage_ms": stage_ms,
             "roofline": roofline, "cpu_baseline": cpu,

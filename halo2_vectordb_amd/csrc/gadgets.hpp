@@ -49,7 +49,10 @@ struct WCtx {
   uint8_t* sel;       // optional gate-start bits (keygen run), may be null
   u256* lk;           // lookup stream base
   uint64_t pos, lpos; // absolute positions of the next advice / lookup cell
-  uint64_t lo, hi;    // emit window over advice positions
+  uint64_t lo, hi;    // emit window over advice positions (the slice of a sequential gadget this wavefront owns)
+  // rank window (multi-GPU): only cells of the columns this rank commits are stored; everything else runs
+  // through the value-only paths.  Advice positions [rlo, rhi), lookup positions [rllo, rlhi).
+  uint64_t rlo, rhi, rllo, rlhi;
   bool count_only;    // host sizing run: count cells, store nothing, never skip
   int err;
   const FpTables* T;
@@ -61,10 +64,11 @@ struct WCtx {
   uint32_t inv_cap;
 
   HD bool in_window(uint64_t p) const { return p >= lo && p < hi; }
+  HD bool in_rank(uint64_t p) const { return p >= rlo && p < rhi; }
   // `cst`: the cell holds a data-independent constant of the gate template (QuantumCell::Constant); recorded in
   // bit 1 of the keygen-side flag byte so the prover's MSM can take those cells from a precomputed point
   HD void push(const u256& v, bool gate, bool cst = false) {
-    if (!count_only && in_window(pos)) {
+    if (!count_only && in_window(pos) && in_rank(pos)) {
       adv[pos] = v;
       if (sel) sel[pos] = (uint8_t)((gate ? 1 : 0) | (cst ? 2 : 0));
     }
@@ -72,11 +76,17 @@ struct WCtx {
   }
   // a lookup cell belongs to the window that owns the advice cell pushed just before it
   HD void lookup(const u256& v) {
-    if (!count_only && pos > 0 && in_window(pos - 1)) lk[lpos] = v;
+    if (!count_only && pos > 0 && in_window(pos - 1) && lpos >= rllo && lpos < rlhi) lk[lpos] = v;
     lpos++;
   }
-  // true when a sub-gadget of `cells` advice cells starting here cannot touch the window
-  HD bool skip(uint32_t cells) const { return !count_only && (pos + cells <= lo || pos > hi); }
+  // true when a sub-gadget of `cells` advice cells (and `lks` lookup cells) starting here cannot touch the windows
+  HD bool skip(uint32_t cells, uint32_t lks = 0) const {
+    if (count_only) return false;
+    const bool seg_out = pos + cells <= lo || pos > hi;
+    const bool rank_out = (pos + cells <= rlo || pos >= rhi) && (lks == 0 || lpos + lks <= rllo || lpos >= rlhi);
+    return seg_out || rank_out;
+  }
+  HD bool skip2(const uint32_t sz[2]) const { return skip(sz[0], sz[1]); }
   HD void advance(const uint32_t sz[2]) {
     pos += sz[0];
     lpos += sz[1];
@@ -103,7 +113,7 @@ struct Gadgets {
   HD u256 inv_cell(const u256& x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (c.inv_cnt) {
-      if (!c.in_window(c.pos + 2)) return T.one;  // this window does not store the cell at all
+      if (!c.in_window(c.pos + 2) || !c.in_rank(c.pos + 2)) return T.one;  // this window does not store the cell at all
       uint32_t i = atomicAdd(c.inv_cnt, 1u);
       if (i < c.inv_cap) {
         c.inv_pos[i] = c.pos + 2;
@@ -237,7 +247,7 @@ struct Gadgets {
   }
   HD u256 r_range_check_skippable(const u256& a, uint32_t bits) {
     uint32_t sz[2] = {rc_cells(bits, T.L), rc_lookups(bits, T.L)};
-    if (c.skip(sz[0])) {
+    if (c.skip2(sz)) {
       c.advance(sz);
       return zero();
     }
@@ -246,7 +256,7 @@ struct Gadgets {
   HD void r_check_less_than(const u256& a, const u256& b, uint32_t bits, bool b_const = false) {
     // [a + 2^n - b, b, 1, a + 2^n, -2^n, 1, a] gates 0,3 ; then range_check(first, bits)
     uint32_t sz[2] = {7 + rc_cells(bits, T.L), rc_lookups(bits, T.L)};
-    if (c.skip(sz[0])) {
+    if (c.skip2(sz)) {
       c.advance(sz);
       return;
     }
@@ -373,7 +383,7 @@ struct Gadgets {
   // Skipped sub-gadgets never make a call: the window test and the value-only path are inline, only real
   // emission goes through the out-of-line *_emit generators.
   HD u256 fp_is_neg(const u256& a) {  // fixed_point.rs:523-539
-    if (c.skip(T.sz.is_neg[0])) {
+    if (c.skip2(T.sz.is_neg)) {
       c.advance(T.sz.is_neg);
       return v_is_neg(from_mont<Fr>(a)) ? T.one : zero();
     }
@@ -386,7 +396,7 @@ struct Gadgets {
     return g_not(is_pos);
   }
   HD u256 fp_qabs(const u256& a) {  // :511-521
-    if (c.skip(T.sz.qabs[0])) {
+    if (c.skip2(T.sz.qabs)) {
       c.advance(T.sz.qabs);
       return v_qabs(a);
     }
@@ -402,7 +412,7 @@ struct Gadgets {
     return g_select(na, a, flag);
   }
   HD u256 fp_signed_div_scale(const u256& a) {  // :974-1016, returns the quotient
-    if (c.skip(T.sz.sds[0])) {
+    if (c.skip2(T.sz.sds)) {
       c.advance(T.sz.sds);
       return v_signed_div_scale(a);
     }
@@ -435,7 +445,7 @@ struct Gadgets {
     return div;
   }
   HD u256 fp_qmul(const u256& a, const u256& b) {  // :588-604
-    if (c.skip(T.sz.qmul[0])) {
+    if (c.skip2(T.sz.qmul)) {
       c.advance(T.sz.qmul);
       return v_qmul(a, b);
     }
@@ -458,7 +468,7 @@ struct Gadgets {
     return g_is_zero_inv(d, inv);
   }
   HD u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
-    if (c.skip(T.sz.qdiv[0])) {
+    if (c.skip2(T.sz.qdiv)) {
       c.advance(T.sz.qdiv);
       return v_qdiv(a, b, c.err);
     }
@@ -477,7 +487,7 @@ struct Gadgets {
     return fp_cond_neg(q, sx);
   }
   HD u256 fp_qmin(const u256& a, const u256& b) {  // :936-952
-    if (c.skip(T.sz.qmin[0])) {
+    if (c.skip2(T.sz.qmin)) {
       c.advance(T.sz.qmin);
       return v_is_neg(from_mont<Fr>(fr_sub(a, b))) ? a : b;
     }
@@ -487,7 +497,7 @@ struct Gadgets {
   }
   template <int M>
   HD u256 fp_polynomial(const u256& x, const u256 (&coef)[M], const uint32_t (&sz)[2]) {  // :658-686
-    if (c.skip(sz[0])) {
+    if (c.skip2(sz)) {
       c.advance(sz);
       u256 y = zero();
       for (int i = 0; i < M; i++) {
@@ -547,7 +557,7 @@ struct Gadgets {
     return inv_cell(x);
   }
   HD void fp_check_power_of_two(const u256& p2, const u256& e, uint64_t e_small) {  // :688-708
-    if (c.skip(T.sz.cpow2[0])) {
+    if (c.skip2(T.sz.cpow2)) {
       c.advance(T.sz.cpow2);
       return;
     }
@@ -617,7 +627,7 @@ struct Gadgets {
   }
   HD u256 small_or_mont(uint64_t v) const { return v < 260 ? T.small[v] : to_mont<Fr>(u256_from_u64(v)); }
   HD u256 fp_qlog2(const u256& a) {  // :736-795
-    if (c.skip(T.sz.qlog2[0])) {
+    if (c.skip2(T.sz.qlog2)) {
       uint64_t p0 = c.pos, l0 = c.lpos;
       u256 v = v_qlog2(a);
       c.pos = p0 + T.sz.qlog2[0];
@@ -678,7 +688,7 @@ struct Gadgets {
     return res_pos;
   }
   HD u256 fp_qexp2(const u256& a) {  // :710-734
-    if (c.skip(T.sz.qexp2[0])) {
+    if (c.skip2(T.sz.qexp2)) {
       uint64_t p0 = c.pos, l0 = c.lpos;
       u256 v = v_qexp2(a);
       c.pos = p0 + T.sz.qexp2[0];
@@ -728,6 +738,8 @@ inline void compute_sizes(FpTables& T) {
     WCtx c{};
     c.count_only = true;
     c.hi = ~0ull;
+    c.rhi = ~0ull;
+    c.rlhi = ~0ull;
     c.T = &T;
     Gadgets g(c);
     fn(g);

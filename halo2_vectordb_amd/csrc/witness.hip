@@ -184,6 +184,11 @@ struct Streams {
   u256* inv_val;
   uint32_t* inv_cnt;
   uint32_t inv_cap;
+  // rank window in the coordinates of adv / lk (see WCtx); full range by default
+  uint64_t rlo, rhi, rllo, rlhi;
+  __device__ __forceinline__ bool touches(uint64_t a0, uint64_t a1, uint64_t l0, uint64_t l1) const {
+    return (a0 < rhi && a1 > rlo) || (l0 < rlhi && l1 > rllo && l1 > l0);
+  }
 };
 
 __device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, uint64_t pos, uint64_t lpos) {
@@ -202,6 +207,10 @@ __device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, ui
   c.inv_val = s.inv_val;
   c.inv_cnt = s.inv_cnt;
   c.inv_cap = s.inv_cap;
+  c.rlo = s.rlo;
+  c.rhi = s.rhi;
+  c.rllo = s.rllo;
+  c.rlhi = s.rlhi;
   return c;
 }
 
@@ -328,6 +337,9 @@ __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __
   if (!live) t = n_inst - 1;
   const uint32_t S = gridDim.y, s = blockIdx.y;
   const uint64_t tb = im.adv(t, dl) + dl.head_cells, tlb = im.lk(t, dl) + dl.head_lk;
+  // segment S-1 carries the result every rank needs; the other segments only emit cells and leave at once
+  // when none of the wavefront's instances lies in this rank's window
+  if (s != S - 1 && !__any((int)(live && st.touches(tb, tb + dl.tail_cells, tlb, tlb + dl.tail_lk)))) return;
   WCtx c = make_ctx(st, T, tb, tlb);
   c.lo = tb + dl.tail_cells * s / S;
   c.hi = tb + dl.tail_cells * (s + 1) / S;
@@ -489,7 +501,9 @@ __global__ __launch_bounds__(64) void k_km_assign(Streams st, const FpTables* __
   const uint32_t K = kl.K, S = gridDim.y, s = blockIdx.y;
   const uint64_t base = ibase + (uint64_t)v * kl.per_vec + (uint64_t)K * dl.total_cells;
   const uint64_t cells = (uint64_t)(K - 1) * T->sz.qmin[0] + 20ull * K;
-  WCtx c = make_ctx(st, T, base, ilbase + (uint64_t)v * kl.per_vec_l + (uint64_t)K * dl.total_lk);
+  const uint64_t lbase_v = ilbase + (uint64_t)v * kl.per_vec_l + (uint64_t)K * dl.total_lk;
+  if (s != S - 1 && !__any((int)(live && st.touches(base, base + cells, lbase_v, lbase_v + (uint64_t)(K - 1) * T->sz.qmin[1])))) return;
+  WCtx c = make_ctx(st, T, base, lbase_v);
   c.lo = base + cells * s / S;
   c.hi = base + cells * (s + 1) / S;
   if (!live) c.lo = c.hi = base;
@@ -550,6 +564,7 @@ __global__ __launch_bounds__(64) void k_km_div(Streams st, const FpTables* __res
   const uint32_t S = gridDim.y, s = blockIdx.y;
   const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D) + (uint64_t)(kl.N - 1) * kl.D * 4 + (uint64_t)j * T->sz.qdiv[0];
   const uint64_t lbase = clbase0 + (uint64_t)k * kl.per_cluster_l + (uint64_t)j * T->sz.qdiv[1];
+  if (s != S - 1 && !__any((int)(live && st.touches(base, base + T->sz.qdiv[0], lbase, lbase + T->sz.qdiv[1])))) return;
   WCtx c = make_ctx(st, T, base, lbase);
   c.lo = base + (uint64_t)T->sz.qdiv[0] * s / S;
   c.hi = base + (uint64_t)T->sz.qdiv[0] * (s + 1) / S;
@@ -745,12 +760,12 @@ __global__ void k_layout_starts(const uint64_t* __restrict__ bp, uint64_t n_bp, 
 }
 __global__ __launch_bounds__(256) void k_layout_columns(const u256* __restrict__ stream, uint64_t n_cells, const uint64_t* __restrict__ starts,
                                                         const uint64_t* __restrict__ bp, uint64_t n_bp, uint32_t k, u256* __restrict__ cols,
-                                                        const u256* __restrict__ blind, uint32_t n_blind) {
+                                                        const u256* __restrict__ blind, uint32_t n_blind, uint64_t col_lo, uint64_t col_hi) {
   const uint64_t rows = 1ull << k;
   uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t total = (n_bp + 1) * rows;
+  uint64_t total = (col_hi - col_lo) * rows;
   if (idx >= total) return;
-  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t col = col_lo + (idx >> k), row = idx & (rows - 1);
   uint64_t start = starts[col];
   uint64_t len = col < n_bp ? bp[col] + 1 : n_cells - start;  // cells held by this column
   u256 v = u256_zero();
@@ -759,11 +774,11 @@ __global__ __launch_bounds__(256) void k_layout_columns(const u256* __restrict__
   st256(cols + idx, v);
 }
 __global__ __launch_bounds__(256) void k_layout_lookup(const u256* __restrict__ lk, uint64_t n_cells, uint64_t max_rows, uint32_t k, uint64_t n_cols,
-                                                       u256* __restrict__ cols, const u256* __restrict__ blind, uint32_t n_blind) {
+                                                       u256* __restrict__ cols, const u256* __restrict__ blind, uint32_t n_blind, uint64_t col_lo) {
   const uint64_t rows = 1ull << k;
   uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_cols * rows) return;
-  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t col = col_lo + (idx >> k), row = idx & (rows - 1);
   uint64_t src = col * max_rows + row;
   u256 v = u256_zero();
   if (row < max_rows && src < n_cells) v = ld256(lk + src);
@@ -1043,6 +1058,9 @@ int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, S
 
 using namespace vdb;
 
+// rank window applied by the *_dev witness entry points (vdb_wit_set_window); full range by default
+static uint64_t g_win[4] = {0, ~0ull, 0, ~0ull};
+
 // upload helper for the host-pointer entry points
 static int upload(DevBuf& d, const void* src, size_t bytes) {
   TRY(d.alloc(bytes));
@@ -1070,6 +1088,10 @@ struct HostStreams {
     st.inv_val = nullptr;
     st.inv_cnt = nullptr;
     st.inv_cap = 0;
+    st.rlo = 0;
+    st.rhi = ~0ull;
+    st.rllo = 0;
+    st.rlhi = ~0ull;
     return VDB_OK;
   }
   int finish(vdb_fr* stream_out, vdb_fr* lookup_out, uint8_t* sel_out, uint64_t cells, uint64_t lookups) {
@@ -1179,6 +1201,14 @@ int vdb_wit_kmeans_size(int metric, uint32_t P, uint32_t L, size_t n, size_t dim
   if (lookups) *lookups = I * kl.iter_l;
   return VDB_OK;
 }
+int vdb_wit_set_window(uint64_t adv_lo, uint64_t adv_hi, uint64_t lookup_lo, uint64_t lookup_hi) {
+  VDB_ARG(adv_lo <= adv_hi && lookup_lo <= lookup_hi, "empty or inverted window");
+  g_win[0] = adv_lo;
+  g_win[1] = adv_hi;
+  g_win[2] = lookup_lo;
+  g_win[3] = lookup_hi;
+  return VDB_OK;
+}
 int vdb_wit_kmeans_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* vectors_dev, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
                        vdb_fr* stream_dev, vdb_fr* lookup_dev, uint8_t* selector_dev, vdb_fr* centroids_dev, vdb_fr* indicators_dev) {
   VDB_REQUIRE_INIT();
@@ -1190,7 +1220,7 @@ int vdb_wit_kmeans_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* vectors
   int* derr = (int*)scratch_get(1, 64);
   if (!derr) return VDB_ERR_OOM;
   VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
-  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0};
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], g_win[2], g_win[3]};
   TRY(wit_kmeans_dev(fp, metric, as_u256(vectors_dev), n, dim, K, I, zero_cached, st, 0, 0, as_u256(centroids_dev), as_u256(indicators_dev)));
   return check_err_flag(derr);
 }
@@ -1224,7 +1254,7 @@ int vdb_wit_merkle_size(size_t n, size_t dim, int zero_cached, uint64_t* cells) 
 int vdb_wit_merkle_dev(const vdb_fr* vectors_dev, size_t n, size_t dim, int zero_cached, vdb_fr* stream_dev, uint8_t* selector_dev, vdb_fr* root_dev) {
   VDB_REQUIRE_INIT();
   VDB_ARG(vectors_dev && stream_dev && root_dev && n > 0, "null pointer");
-  Streams st{as_u256(stream_dev), selector_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  Streams st{as_u256(stream_dev), selector_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], 0, ~0ull};
   return wit_merkle_dev(as_u256(vectors_dev), n, dim, zero_cached, st, 0, as_u256(root_dev));
 }
 int vdb_wit_merkle(const vdb_fr* vectors, size_t n, size_t dim, int zero_cached, vdb_fr* stream_out, uint8_t* selector_out, vdb_fr* root_out) {
@@ -1276,8 +1306,13 @@ int vdb_layout_plan(const uint8_t* selector, uint64_t n_cells, uint32_t k, uint3
 }
 int vdb_layout_columns_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, vdb_fr* cols_dev,
                            const vdb_fr* blind_dev, uint32_t n_blind) {
+  return vdb_layout_columns_range_dev(stream_dev, n_cells, break_points, n_bp, k, 0, n_bp + 1, cols_dev, blind_dev, n_blind);
+}
+int vdb_layout_columns_range_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, uint64_t col_lo,
+                                 uint64_t col_hi, vdb_fr* cols_dev, const vdb_fr* blind_dev, uint32_t n_blind) {
   VDB_REQUIRE_INIT();
-  VDB_ARG(stream_dev && cols_dev && (break_points || n_bp == 0) && k <= 28, "bad argument");
+  VDB_ARG(stream_dev && cols_dev && (break_points || n_bp == 0) && k <= 28 && col_lo <= col_hi && col_hi <= n_bp + 1, "bad argument");
+  if (col_lo == col_hi) return VDB_OK;
   const uint64_t rows = 1ull << k;
   uint64_t sum = 0;
   for (uint64_t i = 0; i < n_bp; i++) {
@@ -1295,11 +1330,11 @@ int vdb_layout_columns_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uin
     hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
   }
   VDB_LAUNCH_CHECK();
-  uint64_t total = (n_bp + 1) * rows;
+  uint64_t total = (col_hi - col_lo) * rows;
   {
     VDB_PROF("k_layout_columns");
     hipLaunchKernelGGL(k_layout_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(stream_dev), n_cells, dst, dbp, n_bp, k,
-                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind, col_lo, col_hi);
   }
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipStreamSynchronize(ctx().stream));  // break_points is a host buffer the caller may free
@@ -1307,16 +1342,21 @@ int vdb_layout_columns_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uin
 }
 int vdb_layout_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr* cols_dev, uint64_t n_cols,
                           const vdb_fr* blind_dev, uint32_t n_blind) {
+  VDB_ARG(n_cols * ((((uint64_t)1 << k)) - minimum_rows) >= n_cells, "not enough lookup columns");
+  return vdb_layout_lookup_range_dev(lookup_dev, n_cells, k, minimum_rows, 0, n_cols, cols_dev, blind_dev, n_blind);
+}
+int vdb_layout_lookup_range_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t col_lo, uint64_t col_hi,
+                                vdb_fr* cols_dev, const vdb_fr* blind_dev, uint32_t n_blind) {
   VDB_REQUIRE_INIT();
-  VDB_ARG(cols_dev && (lookup_dev || n_cells == 0) && k <= 28, "bad argument");
+  VDB_ARG(cols_dev && (lookup_dev || n_cells == 0) && k <= 28 && col_lo <= col_hi, "bad argument");
   uint64_t max_rows = ((uint64_t)1 << k) - minimum_rows;
-  VDB_ARG(n_cols * max_rows >= n_cells, "not enough lookup columns");
+  const uint64_t n_cols = col_hi - col_lo;
   if (n_cols == 0) return VDB_OK;
   uint64_t total = n_cols << k;
   {
     VDB_PROF("k_layout_lookup");
     hipLaunchKernelGGL(k_layout_lookup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(lookup_dev), n_cells, max_rows, k, n_cols,
-                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind);
+                     as_u256(cols_dev), blind_dev ? as_u256(blind_dev) : nullptr, n_blind, col_lo);
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

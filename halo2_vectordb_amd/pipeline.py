@@ -36,22 +36,34 @@ def sift_like_vectors(seed, n, dim, k_distinct=0):
 
 
 def shard_range(n_cols, rank, world):
-    """Contiguous block of the concatenated [advice | lookup] column list owned by `rank`."""
+    """Contiguous block [lo, hi) of a list of `n_cols` columns owned by `rank`."""
     return n_cols * rank // world, n_cols * (rank + 1) // world
 
 
-def gather_commitments(dist, local, n_cols, rank, world, device):
+def column_shards(n_adv, n_lk, world):
+    """Per rank: (advice block, lookup block).  Advice and lookup columns are split separately so that every rank's
+    blocks cover about the same stretch of the witness stream (lookup cells are emitted alongside the advice cells
+    that are range-checked), which is what lets each rank generate only its part of the witness."""
+    return [(shard_range(n_adv, r, world), shard_range(n_lk, r, world)) for r in range(world)]
+
+
+def gather_commitments(dist, local, n_adv, n_lk, rank, world, device):
     """The one real exchange step of the path: all_gather of the 64-byte commitments of every rank's column
-    shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64.  Returns (n_cols, 8)."""
+    shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64, [advice block | lookup block].
+    Returns (n_adv + n_lk, 8) in the unsharded order [all advice | all lookup]."""
     import torch
-    counts = [shard_range(n_cols, r, world)[1] - shard_range(n_cols, r, world)[0] for r in range(world)]
+    shards = column_shards(n_adv, n_lk, world)
+    counts = [(a[1] - a[0]) + (l[1] - l[0]) for a, l in shards]
     mx = max(counts)
     mine = torch.zeros((mx, 8), dtype=torch.int64, device=device)
     if len(local):
         mine[: len(local)] = torch.from_numpy(np.ascontiguousarray(local).view(np.int64)).to(device)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    return np.concatenate([g[:c].cpu().numpy().view(np.uint64) for g, c in zip(gathered, counts)])
+    parts = [g.cpu().numpy().view(np.uint64) for g in gathered]
+    adv = [p[: a[1] - a[0]] for p, (a, l) in zip(parts, shards)]
+    lk = [p[a[1] - a[0]: (a[1] - a[0]) + (l[1] - l[0])] for p, (a, l) in zip(parts, shards)]
+    return np.concatenate(adv + lk)
 
 
 class KmeansHotPath:
@@ -68,6 +80,7 @@ class KmeansHotPath:
         self.seed = seed
         self.tau = tau
         self.factor_constants = True
+        self.shard_witness = True   # generate only the witness cells this rank's columns hold (values are computed everywhere)
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self):
@@ -101,10 +114,18 @@ class KmeansHotPath:
         max_rows = self.rows - MINIMUM_ROWS
         self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
         self.n_cols = self.n_adv_cols + self.n_lk_cols
-        # column sharding over ranks (contiguous blocks of the concatenated [advice | lookup] column list)
-        lo, hi = shard_range(self.n_cols, self.rank, self.world)
-        self.col_lo, self.col_hi = lo, hi
-        self.my_cols = hi - lo
+        # column sharding over ranks: a block of the advice columns and a block of the lookup columns each
+        (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = column_shards(self.n_adv_cols, self.n_lk_cols, self.world)[self.rank]
+        self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
+        self.my_cols = self.my_adv + self.my_lk
+        # the stretch of the flat stream / lookup stream those columns hold (column c = stream[starts[c] : starts[c] + bp[c] + 1])
+        starts = np.concatenate([[0], np.cumsum(self.bp, dtype=np.uint64)]).astype(np.uint64)
+        if self.my_adv:
+            s_hi = int(starts[self.a_hi - 1]) + int(self.bp[self.a_hi - 1]) + 1 if self.a_hi - 1 < len(self.bp) else self.n_cells
+            self.win_adv = (int(starts[self.a_lo]), s_hi)
+        else:
+            self.win_adv = (0, 0)
+        self.win_lk = (self.l_lo * max_rows, min(self.l_hi * max_rows, self.n_lookup)) if self.my_lk else (0, 0)
         rng = np.random.default_rng(self.seed + 7)
         from_ints = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
         R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
@@ -113,29 +134,37 @@ class KmeansHotPath:
         self.blind = blind  # treated as Montgomery representatives: any value < r is a valid field element
         self.d_blind = api.DeviceBuffer(blind.nbytes)
         self.d_blind.upload(blind)
-        self.d_cols = api.DeviceBuffer(self.n_cols * self.rows * B)
-        self.d_ext = api.DeviceBuffer(self.my_cols * self.rows * 4 * B)
+        self.d_cols = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * B)
+        self.d_ext = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * 4 * B)
         tau = from_ints([self.tau * (1 << 256) % R])[0]
         g, gl = api.srs_setup_unsafe(self.k, tau)
         self.g_lagrange = gl
         self.srs = api.Srs(self.k, None, gl)
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
-        self.d_mask = api.DeviceBuffer(self.n_cols * self.rows)
-        check(lib.vdb_memset_dev(self.d_mask.ptr, 0, ctypes.c_size_t(self.n_cols * self.rows)))
-        check(lib.vdb_layout_const_mask_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k, self.d_mask.ptr))
+        # (lookup columns hold no constants: their mask stays zero and their constant point is the identity)
+        n_el = self.n_adv_cols * self.rows
+        d_fmask = api.DeviceBuffer(n_el)
+        check(lib.vdb_layout_const_mask_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k, d_fmask.ptr))
         d_sel.free()
-        self._layout()
-        n_el = self.n_cols * self.rows
-        d_tmp = api.DeviceBuffer(n_el * B)
-        check(lib.vdb_mask_select_dev(self.d_cols.ptr, self.d_mask.ptr, ctypes.c_uint64(n_el), 1, d_tmp.ptr))
+        d_full = api.DeviceBuffer(n_el * B)
+        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                         d_full.ptr, None, 0))
+        check(lib.vdb_mask_select_dev(d_full.ptr, d_fmask.ptr, ctypes.c_uint64(n_el), 1, d_full.ptr))
         const_pts = np.zeros((self.n_cols, 8), dtype=np.uint64)
-        check(lib.vdb_msm_batch_dev(self.srs.h, 1, d_tmp.ptr, ctypes.c_size_t(self.n_cols), ctypes.c_size_t(self.rows), api._p(const_pts)))
-        d_tmp.free()
+        check(lib.vdb_msm_batch_dev(self.srs.h, 1, d_full.ptr, ctypes.c_size_t(self.n_adv_cols), ctypes.c_size_t(self.rows), api._p(const_pts)))
+        d_full.free()
         self.const_points = const_pts
-        self.d_cpts = api.DeviceBuffer(const_pts.nbytes)
-        self.d_cpts.upload(const_pts)
-        self.const_cell_fraction = float(self.d_mask.download((self.n_adv_cols * self.rows,), dtype=np.uint8).mean()) if self.n_adv_cols * self.rows <= (1 << 28) else None
+        mine = np.concatenate([const_pts[self.a_lo:self.a_hi], const_pts[self.n_adv_cols + self.l_lo: self.n_adv_cols + self.l_hi]])
+        self.d_cpts = api.DeviceBuffer(max(mine.nbytes, 64))
+        if mine.nbytes:
+            self.d_cpts.upload(np.ascontiguousarray(mine))
+        self.d_mask = api.DeviceBuffer(max(self.my_cols, 1) * self.rows)
+        check(lib.vdb_memset_dev(self.d_mask.ptr, 0, ctypes.c_size_t(max(self.my_cols, 1) * self.rows)))
+        if self.my_adv:
+            check(lib.vdb_memcpy_d2d(self.d_mask.ptr, d_fmask.at(self.a_lo * self.rows), ctypes.c_size_t(self.my_adv * self.rows)))
+        self.const_cell_fraction = float(d_fmask.download((n_el,), dtype=np.uint8).mean()) if n_el <= (1 << 28) else None
+        d_fmask.free()
         api.sync()
         return self
 
@@ -146,21 +175,32 @@ class KmeansHotPath:
         self.d_vec.upload(self.qvec)
 
     def _layout(self):
+        """My block of advice columns followed by my block of lookup columns, compact in d_cols."""
         lib, B = self.lib, 32
-        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
-                                         self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
-        if self.n_lk_cols:
-            check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS,
-                                            self.d_cols.at(self.n_adv_cols * self.rows * B), ctypes.c_uint64(self.n_lk_cols),
-                                            self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
+        if self.my_adv:
+            check(lib.vdb_layout_columns_range_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                                   ctypes.c_uint64(self.a_lo), ctypes.c_uint64(self.a_hi), self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
+        if self.my_lk:
+            check(lib.vdb_layout_lookup_range_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, ctypes.c_uint64(self.l_lo),
+                                                  ctypes.c_uint64(self.l_hi), self.d_cols.at(self.my_adv * self.rows * B),
+                                                  self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
 
     def _witness(self, sel=None):
         lib = self.lib
         # [assign_witnesses(vectors)] [kmeans cells]
         check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
-        check(lib.vdb_wit_kmeans_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.n, self.dim, self.K, self.I, 0, self.d_stream.at(self.n_in * 32),
-                                     self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_cent.ptr,
-                                     self.d_ind.ptr))
+        windowed = sel is None and self.shard_witness and self.world > 1
+        if windowed:
+            # window in the coordinates of the pointers handed to the call (the kmeans cells start n_in cells into the stream)
+            lo, hi = (max(0, x - self.n_in) for x in self.win_adv)
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(self.win_lk[0]), ctypes.c_uint64(self.win_lk[1])))
+        try:
+            check(lib.vdb_wit_kmeans_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.n, self.dim, self.K, self.I, 0, self.d_stream.at(self.n_in * 32),
+                                         self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_cent.ptr,
+                                         self.d_ind.ptr))
+        finally:
+            if windowed:
+                check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
     # ------------------------------------------------------------------ one pass of the hot path
     def step(self, timings=None):
@@ -176,13 +216,13 @@ class KmeansHotPath:
         stage("witness", self._witness)
 
         stage("layout", self._layout)
-        my = self.d_cols.at(self.col_lo * self.rows * B)
+        my = self.d_cols.ptr
         self.commitments = np.zeros((self.my_cols, 8), dtype=np.uint64)
 
         def commit():
             if self.factor_constants:
                 check(lib.vdb_msm_batch_masked_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows),
-                                                   self.d_mask.at(self.col_lo * self.rows), self.d_cpts.at(self.col_lo * 64), api._p(self.commitments)))
+                                                   self.d_mask.ptr, self.d_cpts.ptr, api._p(self.commitments)))
             else:
                 check(lib.vdb_msm_batch_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), api._p(self.commitments)))
 
@@ -196,11 +236,24 @@ class KmeansHotPath:
         api.sync()
         return self.commitments
 
+    def local_index(self, col):
+        """Position in this rank's compact column buffer of global column `col` ([all advice | all lookup] numbering)."""
+        if col < self.n_adv_cols:
+            assert self.a_lo <= col < self.a_hi, "column not held by this rank"
+            return col - self.a_lo
+        c = col - self.n_adv_cols
+        assert self.l_lo <= c < self.l_hi, "column not held by this rank"
+        return self.my_adv + c - self.l_lo
+
+    def global_columns(self):
+        """Global numbers of the columns this rank holds, in buffer order."""
+        return list(range(self.a_lo, self.a_hi)) + [self.n_adv_cols + c for c in range(self.l_lo, self.l_hi)]
+
     def download_columns(self, col_indices):
-        """Lagrange-basis columns as laid out (call right after `layout`, i.e. use relayout())."""
+        """Lagrange-basis columns as laid out (call right after `layout`, i.e. use relayout()); global column numbers."""
         out = np.zeros((len(col_indices), self.rows, 4), dtype=np.uint64)
         for j, c in enumerate(col_indices):
-            out[j] = self.d_cols.download((self.rows, 4), offset=c * self.rows * 32)
+            out[j] = self.d_cols.download((self.rows, 4), offset=self.local_index(c) * self.rows * 32)
         return out
 
     def relayout(self):

@@ -109,6 +109,11 @@ int vdb_wit_kmeans_size(int metric, uint32_t precision_bits, uint32_t lookup_bit
                         uint64_t *cells, uint64_t *lookups);
 int vdb_wit_kmeans(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors, size_t n, size_t dim, size_t K, size_t I,
                    int zero_cached, vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *centroids_out, vdb_fr *indicators_out);
+/* Multi-GPU: restricts what the following *_dev witness calls STORE to the advice cells [adv_lo, adv_hi) and lookup
+ * cells [lookup_lo, lookup_hi) (coordinates of the stream / lookup pointers passed to the call): a rank that commits a
+ * block of columns only needs those cells; all values (distances, centroids, ...) are still computed everywhere.
+ * Pass (0, UINT64_MAX, 0, UINT64_MAX) to restore the full range. */
+int vdb_wit_set_window(uint64_t adv_lo, uint64_t adv_hi, uint64_t lookup_lo, uint64_t lookup_hi);
 int vdb_wit_kmeans_dev(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors_dev, size_t n, size_t dim, size_t K, size_t I,
                        int zero_cached, vdb_fr *stream_dev, vdb_fr *lookup_dev, uint8_t *selector_dev, vdb_fr *centroids_dev, vdb_fr *indicators_dev);
 /* VectorDBChip::merkle_commitment with PoseidonChip<F,3,2>(R_F=8, R_P=57) (src/gadget/vectordb.rs:165-223):
@@ -134,6 +139,12 @@ int vdb_layout_columns_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uin
                            const vdb_fr *blind_dev, uint32_t n_blind);
 int vdb_layout_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr *cols_dev, uint64_t n_cols,
                           const vdb_fr *blind_dev, uint32_t n_blind);
+/* same, restricted to columns [col_lo, col_hi) (multi-GPU column shards); cols_dev holds just that range; blind_dev is
+ * still indexed by absolute column */
+int vdb_layout_columns_range_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, uint64_t col_lo,
+                                 uint64_t col_hi, vdb_fr *cols_dev, const vdb_fr *blind_dev, uint32_t n_blind);
+int vdb_layout_lookup_range_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t col_lo, uint64_t col_hi,
+                                vdb_fr *cols_dev, const vdb_fr *blind_dev, uint32_t n_blind);
 /* keygen side: column-layout image ((n_bp + 1) x 2^k bytes) of the constant-cell flags (bit 1 of the flag bytes) */
 int vdb_layout_const_mask_dev(const uint8_t *flags_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, uint8_t *mask_dev);
 /* out = mask ? in : 0 (keep_const = 1) or mask ? 0 : in (keep_const = 0), elementwise over n field elements */

@@ -1,5 +1,6 @@
 """N > 1 plumbing on the CPU (gloo, world_size 2): column sharding covers every column exactly once and
-the commitment all_gather reassembles the per-rank shards in column order.  No GPU compute here."""
+the commitment all_gather reassembles the per-rank [advice block | lookup block] shards in the unsharded
+[all advice | all lookup] column order.  No GPU compute here."""
 import os
 import socket
 
@@ -7,22 +8,24 @@ import numpy as np
 import pytest
 
 
-def _worker(rank, world, port, n_cols, q):
+def _worker(rank, world, port, n_adv, n_lk, q):
     import torch.distributed as dist
-    from halo2_vectordb_amd.pipeline import gather_commitments, shard_range
+    from halo2_vectordb_amd.pipeline import column_shards, gather_commitments
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = shard_range(n_cols, rank, world)
-    local = np.arange(lo * 8, hi * 8, dtype=np.uint64).reshape(hi - lo, 8) * np.uint64(0x9E3779B97F4A7C15)
-    out = gather_commitments(dist, local, n_cols, rank, world, "cpu")
-    q.put((rank, lo, hi, out))
+    (a_lo, a_hi), (l_lo, l_hi) = column_shards(n_adv, n_lk, world)[rank]
+    mine = list(range(a_lo, a_hi)) + [n_adv + c for c in range(l_lo, l_hi)]     # global column numbers, buffer order
+    local = (np.array(mine, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :]) * np.uint64(0x9E3779B97F4A7C15)
+    out = gather_commitments(dist, local.reshape(len(mine), 8), n_adv, n_lk, rank, world, "cpu")
+    q.put((rank, mine, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_cols", [7, 8146])
-def test_shard_and_gather_world2(n_cols):
+@pytest.mark.parametrize("n_adv,n_lk", [(7, 0), (1, 1), (8146, 25), (3, 5)])
+def test_shard_and_gather_world2(n_adv, n_lk):
+    n_cols = n_adv + n_lk
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -30,7 +33,7 @@ def test_shard_and_gather_world2(n_cols):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_cols, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_adv, n_lk, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -39,10 +42,10 @@ def test_shard_and_gather_world2(n_cols):
         assert p.exitcode == 0
     want = np.arange(n_cols * 8, dtype=np.uint64).reshape(n_cols, 8) * np.uint64(0x9E3779B97F4A7C15)
     covered = []
-    for rank, lo, hi, out in sorted(res, key=lambda r: r[0]):
+    for rank, mine, out in sorted(res, key=lambda r: r[0]):
         assert np.array_equal(out, want)
-        covered += list(range(lo, hi))
-    assert covered == list(range(n_cols))
+        covered += mine
+    assert sorted(covered) == list(range(n_cols))
 
 
 def test_shard_ranges_partition():

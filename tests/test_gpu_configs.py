@@ -128,3 +128,37 @@ def test_constant_flags_mark_only_constants(api, O):
     m = m1["const_mask"].astype(bool)
     assert np.array_equal(m1["flags"], m2["flags"]) and m.mean() > 0.15
     assert np.array_equal(m1["stream"][m], m2["stream"][m])
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_sharded_ranks_reproduce_the_unsharded_job(api, O, world, metric):
+    """every rank commits its block of advice / lookup columns from a witness it generated only for those
+    columns (vdb_wit_set_window).  Emulated here rank by rank on one GPU: the columns and commitments of all ranks,
+    reassembled in the order gather_commitments uses, are exactly those of the unsharded job, and the k-means results
+    (computed on the value-only path everywhere) are the same on every rank."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    cfg = dict(n=20, dim=9, K=3, I=3, k=10, P=48, L=9, seed=17, metric=metric)
+    full = KmeansHotPath(**cfg).setup()
+    want_commit = full.step().copy()
+    full.relayout()
+    want_cols = full.download_columns(list(range(full.n_cols)))
+    want_cent, want_ind = full.results()
+    assert full.n_adv_cols >= world and full.n_lk_cols >= 1
+    full.free()
+    adv, lk = [], []
+    for r in range(world):
+        hp = KmeansHotPath(col_shard=(r, world), **cfg).setup()
+        # poison the stream so that a column reading a cell its rank did not emit cannot pass by accident
+        assert hp.lib.vdb_memset_dev(hp.d_stream.ptr, 0xA5, hp.n_cells * 32) == 0
+        assert hp.lib.vdb_memset_dev(hp.d_lookup.ptr, 0xA5, max(hp.n_lookup, 1) * 32) == 0
+        got = hp.step().copy()
+        adv.append(got[: hp.my_adv])
+        lk.append(got[hp.my_adv:])
+        hp.relayout()
+        mine = hp.global_columns()
+        assert np.array_equal(hp.download_columns(mine), want_cols[mine]), f"rank {r} columns"
+        cent, ind = hp.results()
+        assert np.array_equal(cent, want_cent) and np.array_equal(ind, want_ind)
+        hp.free()
+    assert np.array_equal(np.concatenate(adv + lk), want_commit)

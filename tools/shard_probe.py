@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Single-GPU emulation of one rank of an N-GPU job: per-stage times of rank r of w (no collectives)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from halo2_vectordb_amd import api
+from halo2_vectordb_amd.pipeline import KmeansHotPath
+
+api.init(0)
+for w in (1, 2, 4, 8):
+    for r in sorted({0, w // 2, w - 1}):
+        hp = KmeansHotPath(col_shard=(r, w)).setup()
+        hp.step()
+        t = {}
+        for _ in range(2):
+            hp.step(t)
+        print(json.dumps({"world": w, "rank": r, "my_cols": hp.my_cols, **{k: round(v / 2, 2) for k, v in t.items()}}), flush=True)
+        hp.free()

@@ -30,35 +30,127 @@ struct NttPass {
   uint32_t first;                 // this is pass 0 (input staging rules apply)
   uint32_t coset;                 // multiply input element e by zeta^(e mod 3)
   uint32_t scale;                 // multiply output by n^{-1}
+  uint32_t s0;                    // first butterfly stage to run (2 when the top three quarters of every row are zero padding)
   uint64_t in_len;                // elements >= in_len of the input column read as zero
   uint64_t in_stride, out_stride; // column strides (elements)
-  u256 zeta1, zeta2, ninv;
+  u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, and the last pass' output factor (32/n or 32) — all mod r, Montgomery
+  uint32_t c2p[9];                // 2r as limbs that dominate any normalised operand (see lsub)
 };
 
 __device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-__device__ __forceinline__ u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
-  uint4 a = lo[idx], b = hi[idx];
-  u256 r;
-  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
-  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+// ---- nine 29-bit limbs ("L9"): the form field elements take inside a tile ------------------------------------
+// value = sum l[k] * 2^(29k).  "Normalised": l[0..7] < 2^29 (+ a few units after a carry pass).  Between
+// normalisations limbs may grow to 7 * 2^29 (sums of a few normalised values); the multiplier accepts limbs
+// below 6 * 2^29 (mont_core29).  No carries are propagated by add / sub: 9 (resp. 18) plain 32-bit operations.
+struct L9 {
+  uint32_t l[9];
+};
+__device__ __forceinline__ L9 l9_split(const u256& a) {
+  L9 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
+    uint32_t lo = a.w[wb];
+    uint32_t hi = wb + 1 < 8 ? a.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
+    r.l[k] = ob ? ((lo >> ob) | (hi << (32 - ob))) : lo;
+    if (k < 8) r.l[k] &= 0x1fffffffu;
+  }
   return r;
 }
-__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t idx, const u256& v) {
-  lo[idx] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
-  hi[idx] = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+// normalised limbs of a value below 2^256 -> eight words
+__device__ __forceinline__ u256 l9_pack(const L9& L) {
+  u256 r;
+  r.w[0] = L.l[0] | (L.l[1] << 29);
+  r.w[1] = (L.l[1] >> 3) | (L.l[2] << 26);
+  r.w[2] = (L.l[2] >> 6) | (L.l[3] << 23);
+  r.w[3] = (L.l[3] >> 9) | (L.l[4] << 20);
+  r.w[4] = (L.l[4] >> 12) | (L.l[5] << 17);
+  r.w[5] = (L.l[5] >> 15) | (L.l[6] << 14);
+  r.w[6] = (L.l[6] >> 18) | (L.l[7] << 11);
+  r.w[7] = (L.l[7] >> 21) | (L.l[8] << 8);
+  return r;
+}
+// one parallel carry pass: limbs below 2^32 in, limbs below 2^29 + 8 out (top limb takes what is left)
+__device__ __forceinline__ void l9_renorm(L9& x) {
+  uint32_t c[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = x.l[k] >> 29;
+#pragma unroll
+  for (int k = 0; k < 8; k++) x.l[k] &= 0x1fffffffu;
+#pragma unroll
+  for (int k = 1; k < 9; k++) x.l[k] += c[k - 1];
+}
+// full carry propagation (only before packing)
+__device__ __forceinline__ void l9_carry(L9& x) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    x.l[k + 1] += x.l[k] >> 29;
+    x.l[k] &= 0x1fffffffu;
+  }
+}
+__device__ __forceinline__ L9 l9_add(const L9& a, const L9& b) {
+  L9 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + b.l[k];
+  return r;
+}
+// a - t + 2r, limb-wise: c2p is 2r written with limbs c[0] = v0 + 2^29, c[k] = v_k + 2^29 - 1, c[8] = v_8 - 1, which
+// dominate the limbs of any normalised t below 1.9 r, so no limb ever goes negative
+__device__ __forceinline__ L9 l9_sub(const L9& a, const L9& t, const uint32_t (&c2p)[9]) {
+  L9 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + (c2p[k] - t.l[k]);
+  return r;
+}
+// a * w * 2^-256 for the pre-scaled constant W = limbs(32 w mod r): normalised, below a * 2^-7.4 + r
+__device__ __forceinline__ L9 l9_mul(const L9& a, const L9& W) {
+  L9 r;
+  mont_core29<Fr>(r.l, a.l, W.l);
+  return r;
+}
+// normalised limbs of a value below 2r -> canonical eight words
+__device__ __forceinline__ u256 l9_canon(const L9& t) {
+  return lazy_canon<Fr>(l9_pack(t));
 }
 
+struct L9Planes {
+  uint4* a;      // limbs 0..3
+  uint4* b;      // limbs 4..7
+  uint32_t* c;   // limb 8
+};
+__device__ __forceinline__ L9 lds_get(const L9Planes& P, uint32_t idx) {
+  uint4 a = P.a[idx], b = P.b[idx];
+  L9 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = P.c[idx];
+  return r;
+}
+__device__ __forceinline__ void lds_put(const L9Planes& P, uint32_t idx, const L9& v) {
+  P.a[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  P.b[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  P.c[idx] = v.l[8];
+}
+
+// One pass = a size-2^S DFT along one digit of the index for a tile of 2^S x G elements held in LDS as L9.
+// Cooley-Tukey butterflies, natural order in, bit-reversed order out: (u, v) -> (u + w v, u - w v) with one twiddle
+// per block, w = omega_m^(bitrev(block)).  Stage 0 has w = 1 everywhere (no product).  Values stay lazy: a product
+// is normalised and below 1.2 r, sums and differences just add limbs; every third stage starts with a carry pass so
+// multiplier inputs stay below 6 * 2^29 per limb and nothing reaches 2^32.  Values stay below 22 r over ten stages.
 template <bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict__ in, u256* __restrict__ out,
                                                          const u256* __restrict__ tw, NttPass p, uint32_t tiles_per_col) {
   extern __shared__ uint4 smem[];
   const uint32_t S = p.S, m = 1u << S, G = 1u << p.logG, T = m * G;
-  const uint32_t row = m + 1;
-  uint4* lo = smem;
-  uint4* hi = smem + G * row;
-  uint4* twlo = hi + G * row;
-  uint4* twhi = twlo + (m / 2 ? m / 2 : 1);
+  const uint32_t row = m + 1, NE = G * row, NW = m / 2 ? m / 2 : 1;
+  L9Planes D, W;
+  D.a = smem;
+  D.b = D.a + NE;
+  W.a = D.b + NE;
+  W.b = W.a + NW;
+  D.c = reinterpret_cast<uint32_t*>(W.b + NW);
+  W.c = D.c + NE;
   const uint32_t tid = threadIdx.x;
   const uint32_t col = blockIdx.x / tiles_per_col, tile = blockIdx.x % tiles_per_col;
   const u256* cin = in + (size_t)col * p.in_stride;
@@ -91,74 +183,71 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     }
   }
 
-  // stage twiddles omega_m^e = tw[e * n/m]
-  for (uint32_t e = tid; e < m / 2; e += NTT_THREADS) {
-    u256 w = ld256(tw + ((size_t)e << (p.log_n - S)));
-    lds_put(twlo, twhi, e, w);
+  // stage twiddles 32 * omega_m^e = tw[e * n/m], as limbs
+  for (uint32_t e = tid; e < m / 2; e += NTT_THREADS) lds_put(W, e, l9_split(ld256(tw + ((size_t)e << (p.log_n - S)))));
+  // load tile.  With s0 == 2 only the first quarter of every row is data; the two skipped stages would just copy
+  // it into the other three quarters.
+  const uint32_t mload = m >> p.s0, Tload = mload * G;
+  L9 Z1, Z2;
+  if (p.coset) {
+    Z1 = l9_split(p.zeta1);
+    Z2 = l9_split(p.zeta2);
   }
-  // load tile
-  for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+  for (uint32_t e = tid; e < Tload; e += NTT_THREADS) {
     uint32_t j, g;
     if (!LAST) {
       g = e & (G - 1);
       j = e >> p.logG;
     } else {
-      j = e & (m - 1);
-      g = e >> S;
+      j = e & (mload - 1);
+      g = e / mload;
     }
     uint64_t idx = base + j * jstride + g * gstride;
-    u256 v;
-    if (p.first) {
-      if (idx < p.in_len) {
-        v = ld256(cin + idx);
-        if (p.coset) {
-          uint32_t r3 = (uint32_t)(idx % 3);
-          if (r3 == 1) v = fr_mul(v, p.zeta1);
-          else if (r3 == 2) v = fr_mul(v, p.zeta2);
-        }
-      } else {
-        v = u256_zero();
+    L9 v;
+    if (!p.first || idx < p.in_len) {
+      v = l9_split(ld256(cin + idx));
+      if (p.coset) {
+        uint32_t r3 = (uint32_t)(idx % 3);
+        if (r3 == 1) v = l9_mul(v, Z1);
+        else if (r3 == 2) v = l9_mul(v, Z2);
       }
     } else {
-      v = ld256(cin + idx);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.l[k] = 0;
     }
-    lds_put(lo, hi, g * row + j, v);
+    for (uint32_t rep = 0; rep < (1u << p.s0); rep++) lds_put(D, g * row + j + rep * mload, v);
   }
   __syncthreads();
-  // DIF stages: natural order in, bit-reversed order out.  Lazy reduction: every value stays in [0, 2p); the
-  // difference u - v + 2p feeds the multiplier unreduced and the product needs no final subtraction.
-  for (uint32_t s = 0; s < S; s++) {
-    uint32_t logh = S - 1 - s, h = 1u << logh;
+  for (uint32_t s = p.s0; s < S; s++) {
+    const uint32_t logh = S - 1 - s, h = 1u << logh;
+    const bool ren = s != p.s0 && (s - p.s0) % 3 == 0;
     for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
       uint32_t g = b >> (S - 1), pj = b & ((m >> 1) - 1);
-      uint32_t r = pj & (h - 1), j0 = ((pj >> logh) << (logh + 1)) + r;
+      uint32_t r = pj & (h - 1), blk = pj >> logh, j0 = (blk << (logh + 1)) + r;
       uint32_t a0 = g * row + j0, a1 = a0 + h;
-      u256 u = lds_get(lo, hi, a0), v = lds_get(lo, hi, a1);
-      u256 d = lazy_sub<Fr>(u, v);
-      if (h > 1) {
-        d = mont_mul_lazy<Fr>(d, lds_get(twlo, twhi, r << s));
-      } else {  // last stage: twiddle 1; bring (0, 4p) back to [0, 2p)
-        u256 p2, t, pp = mod_p<Fr>();
-        u256_add(p2, pp, pp);
-        const uint32_t keep = u256_sub(t, d, p2);
-#pragma unroll
-        for (int i = 0; i < 8; i++) d.w[i] = keep ? d.w[i] : t.w[i];
+      L9 u = lds_get(D, a0), v = lds_get(D, a1);
+      if (ren) {
+        l9_renorm(u);
+        l9_renorm(v);
       }
-      lds_put(lo, hi, a0, lazy_add<Fr>(u, v));
-      lds_put(lo, hi, a1, d);
+      if (s) v = l9_mul(v, lds_get(W, bitrev_s(blk, s) << logh));
+      lds_put(D, a0, l9_add(u, v));
+      lds_put(D, a1, l9_sub(u, v, p.c2p));
     }
     __syncthreads();
   }
-  // write out
+  // write out: one more product (inter-pass twiddle, or the last pass' constant factor) brings the value below 2r
+  L9 FIN;
+  if (LAST) FIN = l9_split(p.fin);
   for (uint32_t e = tid; e < T; e += NTT_THREADS) {
     uint32_t g = e & (G - 1), q = e >> p.logG;
-    u256 v = lds_get(lo, hi, g * row + bitrev_s(q, S));
+    L9 v = lds_get(D, g * row + bitrev_s(q, S));
+    l9_renorm(v);
     if (!LAST) {
       uint64_t i = (uint64_t)i0 + g;
       uint64_t ex = ((uint64_t)q * i) << (p.log_n - S - p.log_inner);
-      if (ex) v = fr_mul(v, ld256(tw + ex));  // canonical result for any 256-bit input
-      else v = lazy_canon<Fr>(v);
-      st256(cout + base + (uint64_t)q * jstride + g, v);
+      v = l9_mul(v, l9_split(ld256(tw + ex)));
+      st256(cout + base + (uint64_t)q * jstride + g, l9_canon(v));
     } else {
       uint64_t pos;
       if (p.nprev == 0) {
@@ -177,21 +266,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         }
         pos += (uint64_t)q << (p.log_n - S);
       }
-      if (p.scale) v = fr_mul(v, p.ninv);
-      else v = lazy_canon<Fr>(v);
-      st256(cout + pos, v);
+      v = l9_mul(v, FIN);
+      st256(cout + pos, l9_canon(v));
     }
   }
 }
 
-// tw[e] = omega^e for e < n
-__global__ __launch_bounds__(256) void k_twiddles(u256* __restrict__ tw, u256 omega, uint64_t n, uint32_t chunk) {
+// tw[e] = 32 * omega^e for e < n (the factor 32 = 2^261 / 2^256 makes a 9 x 29-bit product with the table entry an
+// ordinary Montgomery product, see mont_core29); `m32` is 32 in Montgomery form
+__global__ __launch_bounds__(256) void k_twiddles(u256* __restrict__ tw, u256 omega, u256 m32, uint64_t n, uint32_t chunk) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t lo = t * chunk;
   if (lo >= n) return;
   u256 w = mont_pow<Fr>(omega, u256_from_u64(lo));
   for (uint32_t i = 0; i < chunk && lo + i < n; i++) {
-    st256(tw + lo + i, w);
+    st256(tw + lo + i, fr_mul(w, m32));
     w = fr_mul(w, omega);
   }
 }
@@ -212,7 +301,7 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, int* err) {
   uint64_t threads = (n + chunk - 1) / chunk;
   {
     VDB_PROF("k_twiddles");
-    hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, n, chunk);
+    hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, host_fr_from_u64(32), n, chunk);
   }
   e = hipGetLastError();
   if (e != hipSuccess) {
@@ -257,8 +346,25 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     L = (log_n + ms - 1) / ms;  // passes of up to 512 points: 2^16 = 256 x 256, 2^18 = 512 x 512
     for (uint32_t l = 0; l < L; l++) S[l] = log_n / L + (l < log_n % L ? 1 : 0);
   }
-  u256 ninv = mont_inv<Fr>(host_fr_from_u64(n));
+  const u256 m32 = host_fr_from_u64(32);
+  const u256 fin = scale_ninv ? fr_mul(mont_inv<Fr>(host_fr_from_u64(n)), m32) : m32;
   u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
+  z1 = fr_mul(z1, m32);
+  z2 = fr_mul(z2, m32);
+  // 2r with limbs that dominate a normalised subtrahend (l9_sub)
+  uint32_t c2p[9];
+  {
+    uint64_t carry = 0;
+    for (int k = 0; k < 9; k++) {
+      uint64_t v = 2ull * FrParams::P29[k] + carry;
+      c2p[k] = (uint32_t)(v & 0x1fffffffu);
+      carry = v >> 29;
+    }
+    c2p[8] += (uint32_t)(carry << 29);
+    c2p[0] += 1u << 29;
+    for (int k = 1; k < 8; k++) c2p[k] += (1u << 29) - 1;
+    c2p[8] -= 1;
+  }
 
   // column chunking bounds the scratch buffer (<= ~2 GiB)
   size_t chunk_cols = n_cols;
@@ -284,9 +390,13 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.in_len = in_len;
       p.zeta1 = z1;
       p.zeta2 = z2;
-      p.ninv = ninv;
+      p.fin = fin;
+      memcpy(p.c2p, c2p, sizeof(c2p));
       bool last = (l == L - 1);
       p.scale = last && scale_ninv;
+      // zero-padded input (coeff_to_extended): when rows of pass 0 run along the top digit and only their first
+      // quarter is data, stages 0 and 1 are pure replication
+      p.s0 = (l == 0 && !last && S[0] >= 3 && in_len * 4 <= n) ? 2 : 0;
       const u256* src;
       u256* out;
       if (l == 0) {
@@ -314,9 +424,9 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       }
       uint32_t G = 1u << p.logG;
       uint32_t tiles = (uint32_t)(n / ((uint64_t)m * G));
-      size_t lds = (size_t)(2 * G * (m + 1) + 2 * (m / 2 ? m / 2 : 1)) * sizeof(uint4);
+      size_t lds = (size_t)(G * (m + 1) + (m / 2 ? m / 2 : 1)) * (2 * sizeof(uint4) + sizeof(uint32_t));
       dim3 grid((unsigned)(nc * tiles));
-      if (lds > 64 * 1024) {  // 512-point tiles need 74 KiB of the CU's 160 KiB LDS
+      if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
           VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

@@ -226,27 +226,34 @@ HD u256 mont_mul32(const u256& a, const u256& b) {
 // one 64-bit shift (plus the two instructions that derive the reduction digit m_k in the low half).
 // A: limbs below 6 * 2^29, B: limbs below 2^29  =>  every column stays below 2^64.  Returns (A * B + m * p) / 2^261
 // as nine limbs (the top limb keeps all remaining bits).
+// (Forcing each column into one dependent chain with inline-asm v_mad_u64_u32 was tried: the assembler pads every
+// asm statement with an s_nop, which costs more than the 64-bit add per column the compiler spends on joining the
+// two chains it builds to hide the latency of the reduction digit.)
+HD void mad64(uint64_t& acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
 template <class M>
 HD void mont_core29(uint32_t out[9], const uint32_t A[9], const uint32_t B[9]) {
   constexpr uint32_t MASK = 0x1fffffffu;
   uint32_t mq[9];
+  uint32_t P[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) P[j] = M::P29[j];
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) acc += (uint64_t)A[i] * B[k - i];
+    for (int i = 0; i <= k; i++) mad64(acc, A[i], B[k - i]);
 #pragma unroll
-    for (int j = 1; j <= k; j++) acc += (uint64_t)mq[k - j] * M::P29[j];
+    for (int j = 1; j <= k; j++) mad64(acc, mq[k - j], P[j]);
     mq[k] = ((uint32_t)acc * M::INV29) & MASK;
-    acc += (uint64_t)mq[k] * M::P29[0];
+    mad64(acc, mq[k], P[0]);
     acc >>= 29;
   }
 #pragma unroll
   for (int k = 9; k < 18; k++) {
 #pragma unroll
-    for (int i = k - 8; i <= 8; i++) acc += (uint64_t)A[i] * B[k - i];
+    for (int i = k - 8; i <= 8; i++) mad64(acc, A[i], B[k - i]);
 #pragma unroll
-    for (int j = k - 8; j <= 8; j++) acc += (uint64_t)mq[k - j] * M::P29[j];
+    for (int j = k - 8; j <= 8; j++) mad64(acc, mq[k - j], P[j]);
     out[k - 9] = k < 17 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
     acc >>= 29;
   }

@@ -33,8 +33,9 @@ struct NttPass {
   uint32_t s0;                    // first butterfly stage to run (2 when the top three quarters of every row are zero padding)
   uint64_t in_len;                // elements >= in_len of the input column read as zero
   uint64_t in_stride, out_stride; // column strides (elements)
-  u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, and the last pass' output factor (32/n or 32) — all mod r, Montgomery
-  uint32_t c2p[9];                // 2r as limbs that dominate any normalised operand (see lsub)
+  uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
+  u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery
+  uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
 };
 
 __device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -95,13 +96,37 @@ __device__ __forceinline__ L9 l9_add(const L9& a, const L9& b) {
   for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + b.l[k];
   return r;
 }
-// a - t + 2r, limb-wise: c2p is 2r written with limbs c[0] = v0 + 2^29, c[k] = v_k + 2^29 - 1, c[8] = v_8 - 1, which
-// dominate the limbs of any normalised t below 1.9 r, so no limb ever goes negative
-__device__ __forceinline__ L9 l9_sub(const L9& a, const L9& t, const uint32_t (&c2p)[9]) {
+// a - t + 14r, limb-wise: ckp is 14r written with limbs c[0] = v0 + 2^29, c[k] = v_k + 2^29 - 1, c[8] = v_8 - 1, which
+// dominate the limbs of any t with limbs below 2^29 and value below 13 r, so no limb ever goes negative.  The multiple
+// 14 is the one whose middle limbs v_1..v_7 are smallest (all below 0.59 * 2^29): a difference then grows a limb by at
+// most 1.59 * 2^29, which is what lets two radix-4 steps run between carry passes.
+__device__ __forceinline__ L9 l9_sub(const L9& a, const L9& t, const uint32_t (&ckp)[9]) {
   L9 r;
 #pragma unroll
-  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + (c2p[k] - t.l[k]);
+  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + (ckp[k] - t.l[k]);
   return r;
+}
+// limbs after l9_renorm, value below 2^261 -> canonical eight words without a multiplication: subtract q r with
+// q = floor(top limb / (r_8 + 1)) (never too large, at most 2 too small), then two conditional subtractions
+__device__ __forceinline__ u256 l9_canon_wide(L9 x) {
+  l9_carry(x);
+  constexpr uint32_t MU = 2840127191u;  // floor(2^53 / (0x30644e + 1))
+  const uint32_t q = __umulhi(x.l[8] << 3, MU) >> 24;
+  // x + q (2^261 - r) mod 2^261
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint32_t nk = (k == 0 ? 0x20000000u : 0x1fffffffu) - FrParams::P29[k];  // limbs of 2^261 - r
+    acc += (uint64_t)x.l[k] + (uint64_t)q * nk;
+    x.l[k] = (uint32_t)acc & 0x1fffffffu;
+    acc >>= 29;
+  }
+  u256 v = l9_pack(x), t, p2, pp = mod_p<Fr>();
+  u256_add(p2, pp, pp);
+  uint32_t keep = u256_sub(t, v, p2);
+#pragma unroll
+  for (int i = 0; i < 8; i++) v.w[i] = keep ? v.w[i] : t.w[i];
+  return lazy_canon<Fr>(v);
 }
 // a * w * 2^-256 for the pre-scaled constant W = limbs(32 w mod r): normalised, below a * 2^-7.4 + r
 __device__ __forceinline__ L9 l9_mul(const L9& a, const L9& W) {
@@ -218,27 +243,76 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     for (uint32_t rep = 0; rep < (1u << p.s0); rep++) lds_put(D, g * row + j + rep * mload, v);
   }
   __syncthreads();
-  for (uint32_t s = p.s0; s < S; s++) {
+  // butterfly steps: two stages at a time on four elements held in registers (one LDS round trip and one barrier
+  // per two stages), a single radix-2 stage at the end when the number of stages is odd
+  uint32_t step = 0;
+  for (uint32_t s = p.s0; s < S; step++) {
     const uint32_t logh = S - 1 - s, h = 1u << logh;
-    const bool ren = s != p.s0 && (s - p.s0) % 3 == 0;
-    for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
-      uint32_t g = b >> (S - 1), pj = b & ((m >> 1) - 1);
-      uint32_t r = pj & (h - 1), blk = pj >> logh, j0 = (blk << (logh + 1)) + r;
-      uint32_t a0 = g * row + j0, a1 = a0 + h;
-      L9 u = lds_get(D, a0), v = lds_get(D, a1);
-      if (ren) {
-        l9_renorm(u);
-        l9_renorm(v);
+    const bool ren = (p.ren_mask >> step) & 1;
+    if (s + 1 < S) {
+      const uint32_t h2 = h >> 1;
+      for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
+        const uint32_t g = t >> (S - 2), gi = t & ((m >> 2) - 1);
+        const uint32_t r = gi & (h2 - 1), blk = gi >> (logh - 1);
+        const uint32_t j0 = g * row + (blk << (logh + 1)) + r;
+        L9 x0 = lds_get(D, j0), x1 = lds_get(D, j0 + h2), x2 = lds_get(D, j0 + h), x3 = lds_get(D, j0 + h + h2);
+        if (ren) {
+          l9_renorm(x0);
+          l9_renorm(x1);
+          l9_renorm(x2);
+          l9_renorm(x3);
+        }
+        if (s == 0) {
+          // stage 0: every twiddle is 1.  stage 1: block 0 has twiddle 1, block 1 has omega_4.
+          L9 a0 = l9_add(x0, x2), a2 = l9_sub(x0, x2, p.ckp);
+          L9 a1 = l9_add(x1, x3), a3 = l9_sub(x1, x3, p.ckp);
+          l9_carry(a1);  // a1 is subtracted below: its limbs must be below 2^29 again
+          const L9 t3 = l9_mul(a3, lds_get(W, m >> 2));
+          x0 = l9_add(a0, a1);
+          x1 = l9_sub(a0, a1, p.ckp);
+          x2 = l9_add(a2, t3);
+          x3 = l9_sub(a2, t3, p.ckp);
+        } else {
+          const uint32_t e = bitrev_s(blk, s) << logh;
+          const L9 w = lds_get(W, e);
+          const L9 t2 = l9_mul(x2, w), t3 = l9_mul(x3, w);
+          const L9 a0 = l9_add(x0, t2), a2 = l9_sub(x0, t2, p.ckp);
+          const L9 a1 = l9_add(x1, t3), a3 = l9_sub(x1, t3, p.ckp);
+          const L9 u1 = l9_mul(a1, lds_get(W, e >> 1));
+          const L9 u3 = l9_mul(a3, lds_get(W, (e >> 1) + (m >> 2)));
+          x0 = l9_add(a0, u1);
+          x1 = l9_sub(a0, u1, p.ckp);
+          x2 = l9_add(a2, u3);
+          x3 = l9_sub(a2, u3, p.ckp);
+        }
+        lds_put(D, j0, x0);
+        lds_put(D, j0 + h2, x1);
+        lds_put(D, j0 + h, x2);
+        lds_put(D, j0 + h + h2, x3);
       }
-      if (s) v = l9_mul(v, lds_get(W, bitrev_s(blk, s) << logh));
-      lds_put(D, a0, l9_add(u, v));
-      lds_put(D, a1, l9_sub(u, v, p.c2p));
+      s += 2;
+    } else {
+      for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
+        const uint32_t g = b >> (S - 1), pj = b & ((m >> 1) - 1);
+        const uint32_t r = pj & (h - 1), blk = pj >> logh, j0 = (blk << (logh + 1)) + r;
+        const uint32_t a0 = g * row + j0, a1 = a0 + h;
+        L9 u = lds_get(D, a0), v = lds_get(D, a1);
+        if (ren) {
+          l9_renorm(u);
+          l9_renorm(v);
+        }
+        if (s) v = l9_mul(v, lds_get(W, bitrev_s(blk, s) << logh));
+        lds_put(D, a0, l9_add(u, v));
+        lds_put(D, a1, l9_sub(u, v, p.ckp));
+      }
+      s += 1;
     }
     __syncthreads();
   }
-  // write out: one more product (inter-pass twiddle, or the last pass' constant factor) brings the value below 2r
+  // write out: the inter-pass twiddle product (or the 1/n product of an inverse transform) brings the value below 2r
+  // on its own; a forward transform's last pass reduces without a product (l9_canon_wide)
   L9 FIN;
-  if (LAST) FIN = l9_split(p.fin);
+  if (LAST && p.scale) FIN = l9_split(p.fin);
   for (uint32_t e = tid; e < T; e += NTT_THREADS) {
     uint32_t g = e & (G - 1), q = e >> p.logG;
     L9 v = lds_get(D, g * row + bitrev_s(q, S));
@@ -266,8 +340,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         }
         pos += (uint64_t)q << (p.log_n - S);
       }
-      v = l9_mul(v, FIN);
-      st256(cout + pos, l9_canon(v));
+      st256(cout + pos, p.scale ? l9_canon(l9_mul(v, FIN)) : l9_canon_wide(v));
     }
   }
 }
@@ -351,19 +424,21 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
   z1 = fr_mul(z1, m32);
   z2 = fr_mul(z2, m32);
-  // 2r with limbs that dominate a normalised subtrahend (l9_sub)
-  uint32_t c2p[9];
+  // 14 r with limbs that dominate a normalised subtrahend (l9_sub)
+  uint32_t ckp[9];
+  double cmax = 0;
   {
     uint64_t carry = 0;
     for (int k = 0; k < 9; k++) {
-      uint64_t v = 2ull * FrParams::P29[k] + carry;
-      c2p[k] = (uint32_t)(v & 0x1fffffffu);
+      uint64_t v = 14ull * FrParams::P29[k] + carry;
+      ckp[k] = (uint32_t)(v & 0x1fffffffu);
       carry = v >> 29;
     }
-    c2p[8] += (uint32_t)(carry << 29);
-    c2p[0] += 1u << 29;
-    for (int k = 1; k < 8; k++) c2p[k] += (1u << 29) - 1;
-    c2p[8] -= 1;
+    ckp[8] += (uint32_t)(carry << 29);
+    ckp[0] += 1u << 29;
+    for (int k = 1; k < 8; k++) ckp[k] += (1u << 29) - 1;
+    ckp[8] -= 1;
+    for (int k = 0; k < 8; k++) cmax = fmax(cmax, (double)ckp[k] / (double)(1u << 29));
   }
 
   // column chunking bounds the scratch buffer (<= ~2 GiB)
@@ -391,12 +466,43 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.zeta1 = z1;
       p.zeta2 = z2;
       p.fin = fin;
-      memcpy(p.c2p, c2p, sizeof(c2p));
+      memcpy(p.ckp, ckp, sizeof(ckp));
       bool last = (l == L - 1);
       p.scale = last && scale_ninv;
       // zero-padded input (coeff_to_extended): when rows of pass 0 run along the top digit and only their first
       // quarter is data, stages 0 and 1 are pure replication
       p.s0 = (l == 0 && !last && S[0] >= 3 && in_len * 4 <= n) ? 2 : 0;
+      // carry-pass schedule: limb bounds in units of 2^29 (a sum adds the operands' bounds, a difference adds cmax);
+      // products need operands below 6.1, nothing may reach 8
+      {
+        double b = 1.0001;
+        uint32_t step = 0;
+        for (uint32_t st = p.s0; st < S[l]; step++) {
+          if (st + 1 < S[l]) {
+            if (st == 0) {
+              b = 1.0 + 2.0 * cmax;
+            } else {
+              if (b + cmax >= 6.1 || b + 2.0 * cmax >= 7.95) {
+                p.ren_mask |= 1u << step;
+                b = 1.0001;
+              }
+              b += 2.0 * cmax;
+            }
+            st += 2;
+          } else {
+            if (st == 0) {
+              b = 1.0 + cmax;
+            } else {
+              if (b >= 6.1 || b + cmax >= 7.95) {
+                p.ren_mask |= 1u << step;
+                b = 1.0001;
+              }
+              b += cmax;
+            }
+            st += 1;
+          }
+        }
+      }
       const u256* src;
       u256* out;
       if (l == 0) {

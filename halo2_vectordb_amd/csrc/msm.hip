@@ -22,6 +22,7 @@
 // integer multiply-add throughput (v_mad_u64_u32), see DESIGN.md.
 #include "common.hpp"
 #include "ec.hpp"
+#include "limb9.hpp"
 
 struct vdb_srs {
   uint32_t k;
@@ -50,8 +51,14 @@ __global__ __launch_bounds__(256) void k_srs_table(const Affine* __restrict__ ba
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine p = ld_affine(bases + i);
+  // table entries are stored times 32, i.e. in Montgomery form with R' = 2^261: the form k_msm_accum computes in
+  // (the identity (0, 0) is unaffected)
+  const u256 m32 = to_mont<Fq>(u256_from_u64(32));
   for (uint32_t j = 0; j < W; j++) {
-    st_affine(table + (size_t)j * n + i, p);
+    Affine ps;
+    ps.x = fq_mul(p.x, m32);
+    ps.y = fq_mul(p.y, m32);
+    st_affine(table + (size_t)j * n + i, ps);
     if (j + 1 < W) {
       XYZZ q = xyzz_double_affine(p);
       for (uint32_t d = 1; d < c; d++) q = xyzz_double(q);
@@ -257,12 +264,152 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   }
 }
 
+// ---- accumulation in nine-limb form ------------------------------------------------------------------------------
+// Inside k_msm_accum coordinates are L9 values in Montgomery form with R' = 2^261 (what a 9 x 29-bit product divides
+// by), so products need no operand shift, additions and subtractions are carry-free, and nothing is packed / split
+// between the ten products of a mixed addition.  Bounds (multiples of q) are tracked in the comments of madd_l9.
+struct MsmL9Consts {
+  uint32_t c2[9], c8[9];  // 2q and 8q with dominating limbs (l9_sub)
+  u256 one_rp;            // 2^261 mod q            (1 in R' form)
+  u256 to_std;            // 2^256 mod q: x R' form -> standard Montgomery form (R = 2^256)
+  u256 to_rp;             // 2^266 mod q: standard form -> R' form
+};
+struct AccL9 {
+  L9 x, y, zz, zzz;  // exactly normalised; x < 7.5 q, y < 3.6 q, zz, zzz < 1.1 q
+};
+
+// rare exact path, acc == p as points: acc = 2p from the affine point   [mdbl-2008-s-1, 5M + 2S]
+// x, y exactly normalised, x < q, y <= 2q
+__device__ __forceinline__ void mdbl_l9(AccL9& acc, bool& ident, const L9& x, const L9& y, const MsmL9Consts& K) {
+  if (l9_is_zero_mod<Fq>(y)) {  // 2-torsion (not on BN254 G1; kept for exactness of the group law)
+    ident = true;
+    return;
+  }
+  const L9 u = l9_add(y, y);               // limbs < 2 * 2^29, value <= 4q
+  L9 un = u;
+  l9_renorm(un);
+  const L9 v = l9_mul<Fq>(u, un);          // < 1.1 q
+  const L9 w = l9_mul<Fq>(u, v);           // < 1.03 q
+  const L9 sv = l9_mul<Fq>(x, v);          // < 1.01 q
+  const L9 xx = l9_mul<Fq>(x, x);          // < 1.01 q
+  const L9 m = l9_add(l9_add(xx, xx), xx); // limbs < 3 * 2^29, value < 3.1 q
+  L9 mn = m;
+  l9_renorm(mn);
+  const L9 mm = l9_mul<Fq>(m, mn);         // < 1.06 q
+  const L9 ns = l9_neg(sv, K.c2);
+  L9 x3 = l9_add(l9_add(mm, ns), ns);      // mm - 2 sv + 4q: limbs < 5 * 2^29, value < 5.1 q
+  l9_carry(x3);
+  const L9 td = l9_sub(sv, x3, K.c8);      // value < 9.1 q
+  const L9 m1 = l9_mul<Fq>(td, mn);        // < 1.2 q
+  const L9 m2 = l9_mul<Fq>(w, y);          // < 1.02 q
+  L9 y3 = l9_sub(m1, m2, K.c2);
+  l9_carry(y3);
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = v;
+  acc.zzz = w;
+}
+
+// acc += (neg ? -p : p), p affine in R' form and not the identity   [madd-2008-s, 8M + 2S]
+__device__ __forceinline__ void madd_l9(AccL9& acc, bool& ident, const Affine& p, bool neg, const MsmL9Consts& K) {
+  L9 x2 = l9_split(p.x), y2 = l9_split(p.y);  // canonical: exactly normalised, below q
+  if (neg) {
+    y2 = l9_neg(y2, K.c2);  // 2q - y: limbs below 2 * 2^29
+    l9_carry(y2);
+  }
+  if (ident) {
+    acc.x = x2;
+    acc.y = y2;
+    acc.zz = l9_split(K.one_rp);
+    acc.zzz = acc.zz;
+    ident = false;
+    return;
+  }
+  const L9 u2 = l9_mul<Fq>(acc.zz, x2);    // < 1.01 q
+  const L9 s2 = l9_mul<Fq>(acc.zzz, y2);   // < 1.02 q
+  L9 pd = l9_sub(u2, acc.x, K.c8);         // u2 - x1 + 8q: limbs < 3 * 2^29, value < 9.1 q
+  L9 rd = l9_sub(s2, acc.y, K.c8);         // s2 - y1 + 8q: same bounds
+  L9 pn = pd, rn = rd;
+  l9_renorm(pn);
+  l9_renorm(rn);
+  const L9 pp = l9_mul<Fq>(pd, pn);        // < 1.5 q
+  const L9 r2 = l9_mul<Fq>(rd, rn);        // < 1.5 q
+  if (l9_is_zero_mod<Fq>(pp)) {            // same x (exact test on the product: q is prime)
+    if (l9_is_zero_mod<Fq>(r2)) mdbl_l9(acc, ident, x2, y2, K);  // same point
+    else ident = true;                                            // opposite points
+    return;
+  }
+  const L9 ppp = l9_mul<Fq>(pd, pp);       // < 1.09 q
+  const L9 qq = l9_mul<Fq>(acc.x, pp);     // < 1.07 q
+  const L9 nq = l9_neg(qq, K.c2);          // 2q - qq
+  L9 x3 = l9_add(l9_add(l9_sub(r2, ppp, K.c2), nq), nq);  // r2 - ppp - 2 qq + 6q: limbs < 6.9 * 2^29, value < 7.5 q
+  l9_carry(x3);
+  const L9 td = l9_sub(qq, x3, K.c8);      // qq - x3 + 8q: limbs < 3 * 2^29, value < 9.1 q
+  const L9 m1 = l9_mul<Fq>(td, rn);        // < 1.5 q
+  const L9 m2 = l9_mul<Fq>(acc.y, ppp);    // < 1.03 q
+  L9 y3 = l9_sub(m1, m2, K.c2);            // < 3.5 q
+  l9_carry(y3);
+  acc.zz = l9_mul<Fq>(acc.zz, pp);
+  acc.zzz = l9_mul<Fq>(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+}
+// A segment's partial sum leaves k_msm_accum as raw limbs (36 words; zz = 0 encodes the identity): the conversion to
+// the standard form costs four products, and inside the accumulation loop a flush by ANY lane of a wavefront makes the
+// whole wavefront walk the flush code, so it has to be cheap.  k_msm_partials converts all segments afterwards.
+#define MSM_RAW_WORDS 36
+__device__ __forceinline__ void flush_l9(uint4* dst, const AccL9& acc, bool ident) {
+  const uint32_t z = ident ? 0u : 0xffffffffu;
+  dst[0] = make_uint4(acc.x.l[0], acc.x.l[1], acc.x.l[2], acc.x.l[3]);
+  dst[1] = make_uint4(acc.x.l[4], acc.x.l[5], acc.x.l[6], acc.x.l[7]);
+  dst[2] = make_uint4(acc.y.l[0], acc.y.l[1], acc.y.l[2], acc.y.l[3]);
+  dst[3] = make_uint4(acc.y.l[4], acc.y.l[5], acc.y.l[6], acc.y.l[7]);
+  dst[4] = make_uint4(acc.zz.l[0] & z, acc.zz.l[1] & z, acc.zz.l[2] & z, acc.zz.l[3] & z);
+  dst[5] = make_uint4(acc.zz.l[4] & z, acc.zz.l[5] & z, acc.zz.l[6] & z, acc.zz.l[7] & z);
+  dst[6] = make_uint4(acc.zzz.l[0], acc.zzz.l[1], acc.zzz.l[2], acc.zzz.l[3]);
+  dst[7] = make_uint4(acc.zzz.l[4], acc.zzz.l[5], acc.zzz.l[6], acc.zzz.l[7]);
+  dst[8] = make_uint4(acc.x.l[8], acc.y.l[8], acc.zz.l[8] & z, acc.zzz.l[8]);
+}
+__global__ __launch_bounds__(256) void k_msm_partials(const uint4* __restrict__ raw, XYZZ* __restrict__ partials, const uint32_t* __restrict__ counters,
+                                                      uint32_t seg_cap, u256 to_std) {
+  if (counters[1]) return;
+  const uint32_t total = counters[0] < seg_cap ? counters[0] : seg_cap;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const L9 ts = l9_split(to_std);
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint4* src = raw + (size_t)t * (MSM_RAW_WORDS / 4);
+    uint4 w[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) w[i] = src[i];
+    L9 c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c[j].l[0] = w[2 * j].x; c[j].l[1] = w[2 * j].y; c[j].l[2] = w[2 * j].z; c[j].l[3] = w[2 * j].w;
+      c[j].l[4] = w[2 * j + 1].x; c[j].l[5] = w[2 * j + 1].y; c[j].l[6] = w[2 * j + 1].z; c[j].l[7] = w[2 * j + 1].w;
+    }
+    c[0].l[8] = w[8].x; c[1].l[8] = w[8].y; c[2].l[8] = w[8].z; c[3].l[8] = w[8].w;
+    uint32_t zz_any = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) zz_any |= c[2].l[k];
+    XYZZ a;
+    if (!zz_any) {
+      a = xyzz_identity();
+    } else {
+      a.x = l9_canon<Fq>(l9_mul<Fq>(c[0], ts));
+      a.y = l9_canon<Fq>(l9_mul<Fq>(c[1], ts));
+      a.zz = l9_canon<Fq>(l9_mul<Fq>(c[2], ts));
+      a.zzz = l9_canon<Fq>(l9_mul<Fq>(c[3], ts));
+    }
+    st_xyzz(partials + t, a);
+  }
+}
+
 // One thread per range: exactly MSM_LCAP mixed additions per lane (full lane utilisation); the accumulator is
 // flushed to the next segment slot whenever the sorted entry list moves on to another bucket.
 __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ table, const uint32_t* __restrict__ entries, size_t ent_cap,
                                                    const MsmRange* __restrict__ ranges, const uint32_t* __restrict__ bucket_off, uint32_t B,
-                                                   const uint32_t* __restrict__ counters, XYZZ* __restrict__ partials, MsmSegInfo* __restrict__ seginfo,
-                                                   uint32_t range_cap) {
+                                                   const uint32_t* __restrict__ counters, uint4* __restrict__ raw, MsmSegInfo* __restrict__ seginfo,
+                                                   uint32_t range_cap, MsmL9Consts K) {
   if (counters[1]) return;  // sort overflowed (never expected: capacities are worst-case)
   const uint32_t total = counters[3] < range_cap ? counters[3] : range_cap;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -271,18 +418,19 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
     const uint32_t* e = entries + (size_t)rg.col * ent_cap;
     const uint32_t* bo = bucket_off + (size_t)rg.col * (B + 1);
     uint32_t b = rg.bucket, seg = rg.seg0, next = bo[b + 1];
-    XYZZ acc = xyzz_identity();
+    AccL9 acc;
+    bool ident = true;
     // software prefetch: the gather of the next table point is in flight during the current addition
     uint32_t v = e[rg.start];
     Affine nxt = ld_affine(table + (v & 0x7fffffffu));
     for (uint32_t q = 0; q < rg.len; q++) {
       const uint32_t pos = rg.start + q;
       if (pos == next) {  // bucket boundary: close the segment
-        st_xyzz(partials + seg, acc);
+        flush_l9(raw + (size_t)seg * (MSM_RAW_WORDS / 4), acc, ident);
         seginfo[seg].col = rg.col;
         seginfo[seg].bucket = b;
         seg++;
-        acc = xyzz_identity();
+        ident = true;
         do {
           b++;
           next = bo[b + 1];
@@ -294,9 +442,9 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
         v = e[pos + 1];
         nxt = ld_affine(table + (v & 0x7fffffffu));
       }
-      xyzz_add_mixed(acc, p, neg);
+      if (!affine_is_identity(p)) madd_l9(acc, ident, p, neg, K);
     }
-    st_xyzz(partials + seg, acc);
+    flush_l9(raw + (size_t)seg * (MSM_RAW_WORDS / 4), acc, ident);
     seginfo[seg].col = rg.col;
     seginfo[seg].bucket = b;
   }
@@ -438,7 +586,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   const size_t seg_cap_col = B + range_cap_col;
   // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
   // thousands of independent column reductions in flight
-  size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ)) + 2 * (B + 1) * 4;
+  size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ) + MSM_RAW_WORDS * 4) + 2 * (B + 1) * 4;
   size_t nb = ((size_t)40 << 30) / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;
@@ -448,13 +596,20 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   if (!buf) return VDB_ERR_OOM;
   uint32_t* entries = (uint32_t*)buf;
   XYZZ* partials = (XYZZ*)(buf + nb * ent_cap * 4);
-  MsmRange* ranges = (MsmRange*)((uint8_t*)partials + nb * seg_cap_col * sizeof(XYZZ));
+  uint4* raw = (uint4*)((uint8_t*)partials + nb * seg_cap_col * sizeof(XYZZ));
+  MsmRange* ranges = (MsmRange*)((uint8_t*)raw + nb * seg_cap_col * MSM_RAW_WORDS * 4);
   MsmSegInfo* seginfo = (MsmSegInfo*)((uint8_t*)ranges + nb * range_cap_col * sizeof(MsmRange));
   uint32_t* seg_off = (uint32_t*)((uint8_t*)seginfo + nb * seg_cap_col * sizeof(MsmSegInfo));
   uint32_t* bucket_off = seg_off + nb * (B + 1);
   uint32_t* counters = bucket_off + nb * (B + 1);
   const uint32_t seg_cap = (uint32_t)(nb * seg_cap_col), range_cap = (uint32_t)(nb * range_cap_col);
   size_t lds = (3 * (size_t)B + 32) * sizeof(uint32_t);
+  MsmL9Consts l9k;
+  l9_offset_limbs<FqParams>(2, l9k.c2);
+  l9_offset_limbs<FqParams>(8, l9k.c8);
+  l9k.one_rp = to_mont<Fq>(u256_from_u64(32));
+  l9k.to_std = mont_one<Fq>();
+  l9k.to_rp = to_mont<Fq>(u256_from_u64(1024));
   for (size_t c0 = 0; c0 < n_cols; c0 += nb) {
     size_t nc = n_cols - c0 < nb ? n_cols - c0 : nb;
     VDB_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), cx.stream));
@@ -468,7 +623,12 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     {
       VDB_PROF("k_msm_accum");
       hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, ranges, bucket_off, B,
-                       counters, partials, seginfo, range_cap);
+                       counters, raw, seginfo, range_cap, l9k);
+    }
+    VDB_LAUNCH_CHECK();
+    {
+      VDB_PROF("k_msm_partials");
+      hipLaunchKernelGGL(k_msm_partials, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, raw, partials, counters, seg_cap, l9k.to_std);
     }
     VDB_LAUNCH_CHECK();
     {

@@ -16,6 +16,7 @@
 // Roofline: 64 B/element algorithmic HBM traffic per transform; the kernel is integer-ALU bound
 // (one 254-bit Montgomery product per butterfly), see DESIGN.md.
 #include "common.hpp"
+#include "limb9.hpp"
 
 namespace vdb {
 
@@ -40,72 +41,6 @@ struct NttPass {
 
 __device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// ---- nine 29-bit limbs ("L9"): the form field elements take inside a tile ------------------------------------
-// value = sum l[k] * 2^(29k).  "Normalised": l[0..7] < 2^29 (+ a few units after a carry pass).  Between
-// normalisations limbs may grow to 7 * 2^29 (sums of a few normalised values); the multiplier accepts limbs
-// below 6 * 2^29 (mont_core29).  No carries are propagated by add / sub: 9 (resp. 18) plain 32-bit operations.
-struct L9 {
-  uint32_t l[9];
-};
-__device__ __forceinline__ L9 l9_split(const u256& a) {
-  L9 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
-    uint32_t lo = a.w[wb];
-    uint32_t hi = wb + 1 < 8 ? a.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
-    r.l[k] = ob ? ((lo >> ob) | (hi << (32 - ob))) : lo;
-    if (k < 8) r.l[k] &= 0x1fffffffu;
-  }
-  return r;
-}
-// normalised limbs of a value below 2^256 -> eight words
-__device__ __forceinline__ u256 l9_pack(const L9& L) {
-  u256 r;
-  r.w[0] = L.l[0] | (L.l[1] << 29);
-  r.w[1] = (L.l[1] >> 3) | (L.l[2] << 26);
-  r.w[2] = (L.l[2] >> 6) | (L.l[3] << 23);
-  r.w[3] = (L.l[3] >> 9) | (L.l[4] << 20);
-  r.w[4] = (L.l[4] >> 12) | (L.l[5] << 17);
-  r.w[5] = (L.l[5] >> 15) | (L.l[6] << 14);
-  r.w[6] = (L.l[6] >> 18) | (L.l[7] << 11);
-  r.w[7] = (L.l[7] >> 21) | (L.l[8] << 8);
-  return r;
-}
-// one parallel carry pass: limbs below 2^32 in, limbs below 2^29 + 8 out (top limb takes what is left)
-__device__ __forceinline__ void l9_renorm(L9& x) {
-  uint32_t c[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) c[k] = x.l[k] >> 29;
-#pragma unroll
-  for (int k = 0; k < 8; k++) x.l[k] &= 0x1fffffffu;
-#pragma unroll
-  for (int k = 1; k < 9; k++) x.l[k] += c[k - 1];
-}
-// full carry propagation (only before packing)
-__device__ __forceinline__ void l9_carry(L9& x) {
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    x.l[k + 1] += x.l[k] >> 29;
-    x.l[k] &= 0x1fffffffu;
-  }
-}
-__device__ __forceinline__ L9 l9_add(const L9& a, const L9& b) {
-  L9 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + b.l[k];
-  return r;
-}
-// a - t + 14r, limb-wise: ckp is 14r written with limbs c[0] = v0 + 2^29, c[k] = v_k + 2^29 - 1, c[8] = v_8 - 1, which
-// dominate the limbs of any t with limbs below 2^29 and value below 13 r, so no limb ever goes negative.  The multiple
-// 14 is the one whose middle limbs v_1..v_7 are smallest (all below 0.59 * 2^29): a difference then grows a limb by at
-// most 1.59 * 2^29, which is what lets two radix-4 steps run between carry passes.
-__device__ __forceinline__ L9 l9_sub(const L9& a, const L9& t, const uint32_t (&ckp)[9]) {
-  L9 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + (ckp[k] - t.l[k]);
-  return r;
-}
 // limbs after l9_renorm, value below 2^261 -> canonical eight words without a multiplication: subtract q r with
 // q = floor(top limb / (r_8 + 1)) (never too large, at most 2 too small), then two conditional subtractions
 __device__ __forceinline__ u256 l9_canon_wide(L9 x) {
@@ -128,16 +63,9 @@ __device__ __forceinline__ u256 l9_canon_wide(L9 x) {
   for (int i = 0; i < 8; i++) v.w[i] = keep ? v.w[i] : t.w[i];
   return lazy_canon<Fr>(v);
 }
-// a * w * 2^-256 for the pre-scaled constant W = limbs(32 w mod r): normalised, below a * 2^-7.4 + r
-__device__ __forceinline__ L9 l9_mul(const L9& a, const L9& W) {
-  L9 r;
-  mont_core29<Fr>(r.l, a.l, W.l);
-  return r;
-}
-// normalised limbs of a value below 2r -> canonical eight words
-__device__ __forceinline__ u256 l9_canon(const L9& t) {
-  return lazy_canon<Fr>(l9_pack(t));
-}
+// products and the final conditional subtraction are over Fr in this file
+__device__ __forceinline__ L9 l9_mul(const L9& a, const L9& W) { return l9_mul<Fr>(a, W); }
+__device__ __forceinline__ u256 l9_canon(const L9& t) { return l9_canon<Fr>(t); }
 
 struct L9Planes {
   uint4* a;      // limbs 0..3
@@ -426,20 +354,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   z2 = fr_mul(z2, m32);
   // 14 r with limbs that dominate a normalised subtrahend (l9_sub)
   uint32_t ckp[9];
-  double cmax = 0;
-  {
-    uint64_t carry = 0;
-    for (int k = 0; k < 9; k++) {
-      uint64_t v = 14ull * FrParams::P29[k] + carry;
-      ckp[k] = (uint32_t)(v & 0x1fffffffu);
-      carry = v >> 29;
-    }
-    ckp[8] += (uint32_t)(carry << 29);
-    ckp[0] += 1u << 29;
-    for (int k = 1; k < 8; k++) ckp[k] += (1u << 29) - 1;
-    ckp[8] -= 1;
-    for (int k = 0; k < 8; k++) cmax = fmax(cmax, (double)ckp[k] / (double)(1u << 29));
-  }
+  const double cmax = l9_offset_limbs<FrParams>(14, ckp);
 
   // column chunking bounds the scratch buffer (<= ~2 GiB)
   size_t chunk_cols = n_cols;

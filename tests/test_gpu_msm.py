@@ -76,6 +76,37 @@ def test_msm_degenerate_bases(api, O):
     srs.free()
 
 
+def test_msm_accumulator_exceptional_cases(api, O):
+    """buckets that hold exactly {P, P}, {P, -P}, {P, P, -P}, {P, -P, P}: the accumulator's doubling and cancellation
+    paths (k_msm_accum works in a lazy nine-limb form and detects them on a product), each window of the scalar"""
+    k = 8
+    n = 1 << k
+    g, _ = O.srs_from_tau(k, 0x77AA55)
+    g[17] = g[3]
+    g[18, :4] = g[3, :4]
+    neg_y = (O.Q_MOD - O.fq_to_ints(g[3, 4:].reshape(1, 4))[0]) % O.Q_MOD
+    g[18, 4:] = O.fq_from_ints([neg_y])[0]
+    g[40] = g[3]
+    srs = api.Srs(k, g, None)
+    rng = np.random.default_rng(77)
+    s = int(O.fr_to_ints(O.random_fr(rng, 1))[0])
+    cols = []
+    for idx in ([3, 17], [3, 18], [3, 17, 18], [3, 18, 40], [3, 17, 40], [17, 18]):
+        v = [0] * n
+        for i in idx:
+            v[i] = s
+        cols.append(O.fr_from_ints(v))
+    for small in (1, 5):                       # single-window scalars as well
+        v = [0] * n
+        v[3] = v[17] = small
+        cols.append(O.fr_from_ints(v))
+    cols = np.stack(cols)
+    got = api.msm_batch(srs, cols, basis=0)
+    assert np.array_equal(got, O.msm_batch(cols, g, threads=4))
+    assert not got[1].any() and not got[5].any()          # P - P = identity, encoded (0, 0)
+    srs.free()
+
+
 def test_msm_linearity_k14(api, O):
     """size-independent property at a larger size: MSM(a + b) == MSM(a) + MSM(b) and against the
     closed form when the discrete logs of the bases are known."""

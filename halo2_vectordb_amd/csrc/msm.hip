@@ -34,16 +34,20 @@ struct vdb_srs {
 namespace vdb {
 
 #define MSM_SORT_THREADS 1024
-#define MSM_LCAP 32
+// Range length (entries one thread of k_msm_accum adds up) is chosen per batch: long ranges mean fewer segments, i.e.
+// less work for k_msm_partials / k_msm_combine (256: 4 ms of combine on the k = 16 kmeans workload against 20 ms at
+// 32), short ranges keep small jobs parallel (a single 2^16 column has only ~130 k entries).
+#define MSM_LCAP_MIN 32
+#define MSM_LCAP_MAX 256
 
-// A range is MSM_LCAP consecutive entries of one column's bucket-sorted entry list.  Inside a range every change of
+// A range is `lcap` consecutive entries of one column's bucket-sorted entry list.  Inside a range every change of
 // bucket starts a new *segment*; each segment produces one partial sum.  Segment numbering follows the sorted order,
 // so the partials of one bucket are contiguous: [seg_off[b], seg_off[b + 1]).
 struct MsmRange {
   uint32_t col, bucket, start, len, seg0, pad;
 };
 struct MsmSegInfo {
-  uint32_t col, bucket;
+  uint32_t idx, len;  // position of the segment among its bucket's segments, and how many the bucket has
 };
 
 // ---------------------------------------------------------------- table precompute
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
                                                                uint32_t* __restrict__ seg_off, uint32_t* __restrict__ bucket_off, MsmRange* __restrict__ ranges,
                                                                uint32_t* __restrict__ counters /* [0]=segments, [1]=overflow, [2]=max segs/bucket, [3]=ranges */,
                                                                uint32_t seg_cap, uint32_t range_cap,
-                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg) {
+                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg,
+                                                               uint32_t lcap /* range length, a power of two */) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
@@ -181,13 +186,13 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
     for (uint32_t q = 0; q < ipt; q++) {
       uint32_t b = tid * ipt + q;
       if (b < B) {
-        if (hist[b] && (off % MSM_LCAP)) ua_local++;
+        if (hist[b] && (off % lcap)) ua_local++;
         off += hist[b];
       }
     }
   }
   const uint32_t ua_pre0 = block_exclusive_scan(ua_local, wave_sums, &total_ua);
-  const uint32_t nranges = (total_cnt + MSM_LCAP - 1) / MSM_LCAP, nseg = nranges + total_ua;
+  const uint32_t nranges = (total_cnt + lcap - 1) / lcap, nseg = nranges + total_ua;
   if (tid == 0) {
     uint32_t base = atomicAdd(&counters[0], nseg);
     uint32_t rb = atomicAdd(&counters[3], nranges);
@@ -218,11 +223,11 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
         cursor[b] = off;
         ucnt[b] = ua;
         boff[b] = off;
-        soff[b] = base + (off + MSM_LCAP - 1) / MSM_LCAP + ua;
+        soff[b] = base + (off + lcap - 1) / lcap + ua;
         if (cnt) {
-          uint32_t segs = (off + cnt + MSM_LCAP - 1) / MSM_LCAP - off / MSM_LCAP;
+          uint32_t segs = (off + cnt + lcap - 1) / lcap - off / lcap;
           if (segs > 1) atomicMax(&counters[2], segs);  // lets k_msm_combine skip passes nobody needs
-          if (off % MSM_LCAP) ua++;
+          if (off % lcap) ua++;
         }
         off += cnt;
       }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __syncthreads();
   // range descriptors: starting bucket by binary search over the (monotone) bucket offsets in LDS
   for (uint32_t r = tid; r < nranges; r += MSM_SORT_THREADS) {
-    const uint32_t x = r * MSM_LCAP;
+    const uint32_t x = r * lcap;
     uint32_t lo_b = 0, hi_b = B;  // last b with cursor[b] <= x
     while (hi_b - lo_b > 1) {
       uint32_t mid = (lo_b + hi_b) >> 1;
@@ -247,8 +252,8 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
     rg.col = col;
     rg.bucket = lo_b;
     rg.start = x;
-    rg.len = total_cnt - x < MSM_LCAP ? total_cnt - x : MSM_LCAP;
-    rg.seg0 = base + r + ucnt[lo_b] + ((bo % MSM_LCAP) && bo < x ? 1u : 0u);
+    rg.len = total_cnt - x < lcap ? total_cnt - x : lcap;
+    rg.seg0 = base + r + ucnt[lo_b] + ((bo % lcap) && bo < x ? 1u : 0u);
     rg.pad = 0;
     ranges[rbase + r] = rg;
   }
@@ -404,12 +409,12 @@ __global__ __launch_bounds__(256) void k_msm_partials(const uint4* __restrict__ 
   }
 }
 
-// One thread per range: exactly MSM_LCAP mixed additions per lane (full lane utilisation); the accumulator is
+// One thread per range: exactly `lcap` mixed additions per lane (full lane utilisation); the accumulator is
 // flushed to the next segment slot whenever the sorted entry list moves on to another bucket.
 __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ table, const uint32_t* __restrict__ entries, size_t ent_cap,
                                                    const MsmRange* __restrict__ ranges, const uint32_t* __restrict__ bucket_off, uint32_t B,
-                                                   const uint32_t* __restrict__ counters, uint4* __restrict__ raw, MsmSegInfo* __restrict__ seginfo,
-                                                   uint32_t range_cap, MsmL9Consts K) {
+                                                   const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ counters, uint4* __restrict__ raw,
+                                                   MsmSegInfo* __restrict__ seginfo, uint32_t range_cap, MsmL9Consts K) {
   if (counters[1]) return;  // sort overflowed (never expected: capacities are worst-case)
   const uint32_t total = counters[3] < range_cap ? counters[3] : range_cap;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -417,6 +422,7 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
     MsmRange rg = ranges[t];
     const uint32_t* e = entries + (size_t)rg.col * ent_cap;
     const uint32_t* bo = bucket_off + (size_t)rg.col * (B + 1);
+    const uint32_t* so = seg_off + (size_t)rg.col * (B + 1);
     uint32_t b = rg.bucket, seg = rg.seg0, next = bo[b + 1];
     AccL9 acc;
     bool ident = true;
@@ -427,8 +433,11 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
       const uint32_t pos = rg.start + q;
       if (pos == next) {  // bucket boundary: close the segment
         flush_l9(raw + (size_t)seg * (MSM_RAW_WORDS / 4), acc, ident);
-        seginfo[seg].col = rg.col;
-        seginfo[seg].bucket = b;
+        {
+          const uint32_t s0 = so[b];
+          seginfo[seg].idx = seg - s0;
+          seginfo[seg].len = so[b + 1] - s0;
+        }
         seg++;
         ident = true;
         do {
@@ -445,33 +454,34 @@ __global__ __launch_bounds__(256) void k_msm_accum(const Affine* __restrict__ ta
       if (!affine_is_identity(p)) madd_l9(acc, ident, p, neg, K);
     }
     flush_l9(raw + (size_t)seg * (MSM_RAW_WORDS / 4), acc, ident);
-    seginfo[seg].col = rg.col;
-    seginfo[seg].bucket = b;
+    {
+      const uint32_t s0 = so[b];
+      seginfo[seg].idx = seg - s0;
+      seginfo[seg].len = so[b + 1] - s0;
+    }
   }
 }
 
 // Segmented tree reduction of the partial sums of every bucket: in pass p a bucket that still holds
-// len_p > 1 partials folds its upper half onto its lower half (len_{p+1} = ceil(len_p / 2)).  One
-// thread per task slot; after ceil(log2(max tasks per bucket)) passes the sum of bucket b sits in the
-// first slot of its segment.  This is what removes the witness-column skew from the reduce kernel.
-__global__ __launch_bounds__(256) void k_msm_combine(XYZZ* __restrict__ partials, const MsmSegInfo* __restrict__ seginfo, const uint32_t* __restrict__ task_off,
-                                                     const uint32_t* __restrict__ counters, uint32_t B, uint32_t pass, uint32_t task_cap) {
+// len_p = ceil(len / 2^p) > 1 partials folds its upper half onto its lower half.  A thread needs only its own
+// (idx, len) record — no lookups — so a pass in which a segment has nothing to do costs one coalesced 8-byte read, and
+// the lanes that do work are contiguous.  After ceil(log2(max segments per bucket)) passes the sum of bucket b sits in
+// its first segment slot.  This is what removes the witness-column skew from the reduce kernel.
+// (Measured alternatives: radix-8 in-place folding — 2x slower, one active lane in eight; one thread per bucket — 8x
+// slower, serial tails of the heavy buckets.)
+__global__ __launch_bounds__(256) void k_msm_combine(XYZZ* __restrict__ partials, const MsmSegInfo* __restrict__ seginfo, const uint32_t* __restrict__ counters,
+                                                     uint32_t pass, uint32_t task_cap) {
   if (counters[1]) return;
   if ((1u << pass) >= counters[2]) return;  // every bucket is already folded to one partial
   const uint32_t total = counters[0] < task_cap ? counters[0] : task_cap;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    MsmSegInfo tk = seginfo[t];
-    const uint32_t* toff = task_off + (size_t)tk.col * (B + 1);
-    uint32_t s = toff[tk.bucket], len = toff[tk.bucket + 1] - s;
-    for (uint32_t q = 0; q < pass && len > 1; q++) len = (len + 1) >> 1;
-    if (len <= 1) continue;
-    uint32_t half = (len + 1) >> 1, i = t - s;
-    if (i + half < len) {
-      XYZZ a = ld_xyzz(partials + t), b = ld_xyzz(partials + t + half);
-      xyzz_add(a, b);
-      st_xyzz(partials + t, a);
-    }
+    const MsmSegInfo si = seginfo[t];
+    const uint32_t len = (si.len + (1u << pass) - 1) >> pass, half = (len + 1) >> 1;
+    if (len <= 1 || si.idx + half >= len) continue;
+    XYZZ a = ld_xyzz(partials + t), b = ld_xyzz(partials + t + half);
+    xyzz_add(a, b);
+    st_xyzz(partials + t, a);
   }
 }
 
@@ -582,7 +592,9 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   const Affine* table = srs->table[basis];
   const uint32_t c = srs->c, W = srs->W, B = srs->B;
   const size_t ent_cap = n * W;
-  const size_t range_cap_col = (ent_cap + MSM_LCAP - 1) / MSM_LCAP;  // worst case: every digit non-zero
+  uint32_t lcap = MSM_LCAP_MIN;
+  while (lcap < MSM_LCAP_MAX && (n_cols * n) / lcap >= ((size_t)1 << 19)) lcap <<= 1;  // keep >= ~2^20 ranges in a large job
+  const size_t range_cap_col = (ent_cap + lcap - 1) / lcap;  // worst case: every digit non-zero
   const size_t seg_cap_col = B + range_cap_col;
   // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
   // thousands of independent column reductions in flight
@@ -617,13 +629,13 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       VDB_PROF("k_msm_sort");
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
                        ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
-                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0);
+                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0, lcap);
     }
     VDB_LAUNCH_CHECK();
     {
       VDB_PROF("k_msm_accum");
       hipLaunchKernelGGL(k_msm_accum, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, table, entries, ent_cap, ranges, bucket_off, B,
-                       counters, raw, seginfo, range_cap, l9k);
+                       seg_off, counters, raw, seginfo, range_cap, l9k);
     }
     VDB_LAUNCH_CHECK();
     {
@@ -632,13 +644,12 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     }
     VDB_LAUNCH_CHECK();
     {
-      // at most ceil(log2(max segments per bucket)) passes do work; the rest exit on the device-side maximum.
-      // (A one-thread-per-bucket sequential fold was measured 8x slower: serial tails of the heavy buckets.)
+      // at most ceil(log2(max segments per bucket)) passes do work; the rest exit on the device-side maximum
       uint32_t max_nt = (uint32_t)range_cap_col + 1, passes = 0;
       while ((1u << passes) < max_nt) passes++;
       for (uint32_t ps = 0; ps < passes; ps++) {
         VDB_PROF("k_msm_combine");
-        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, seginfo, seg_off, counters, B, ps, seg_cap);
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, seginfo, counters, ps, seg_cap);
       }
       VDB_LAUNCH_CHECK();
     }

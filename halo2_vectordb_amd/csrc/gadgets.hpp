@@ -20,7 +20,9 @@
 #include "field.hpp"
 
 // mid-level generators are real functions on the device: the call tree is deep (qsqrt -> qlog2 -> qmul
-// -> signed_div_scale -> qabs -> is_neg -> range checks) and full inlining would explode code size
+// -> signed_div_scale -> qabs -> is_neg -> range checks) and full inlining would explode code size.
+// Each `X` below is a thin inline member that calls the out-of-line `X__ool(context by value, args by value)`,
+// which runs the inlined body `X__body` on its private copy of the context (see EmitOut).
 #define HDN __host__ __device__ __noinline__
 
 namespace vdb {
@@ -90,6 +92,40 @@ struct WCtx {
   HD void advance(const uint32_t sz[2]) {
     pos += sz[0];
     lpos += sz[1];
+  }
+};
+
+// What an out-of-line generator hands back.  The generators take the context BY VALUE and return the fields they
+// advance: a context passed by reference would live in scratch memory and, because every cell store may alias it, be
+// re-read from there around every single push (measured: 3 loads per store in the distance kernels).
+struct EmitOut {
+  u256 v;
+  uint64_t pos, lpos;
+  int err;
+  HD void take(const WCtx& c) {
+    pos = c.pos;
+    lpos = c.lpos;
+    err = c.err;
+  }
+  HD void give(WCtx& c) const {
+    c.pos = pos;
+    c.lpos = lpos;
+    c.err = err;
+  }
+};
+struct EmitOut2 {
+  u256 v, w;
+  uint64_t pos, lpos;
+  int err;
+  HD void take(const WCtx& c) {
+    pos = c.pos;
+    lpos = c.lpos;
+    err = c.err;
+  }
+  HD void give(WCtx& c) const {
+    c.pos = pos;
+    c.lpos = lpos;
+    c.err = err;
   }
 };
 
@@ -207,7 +243,19 @@ struct Gadgets {
     return k + (rem > 1 ? 1 : 0);
   }
   // range_check(a, bits); `ac` = canonical value of a.  Returns the last cell queued for lookup.
-  HDN u256 r_range_check(const u256& a, const u256& ac, uint32_t bits) {
+  static HDN EmitOut r_range_check__ool(WCtx cv, u256 a, u256 ac, uint32_t bits) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.r_range_check__body(a, ac, bits);
+    o.take(cv);
+    return o;
+  }
+  HD u256 r_range_check(const u256& a, const u256& ac, uint32_t bits) {
+    EmitOut o = r_range_check__ool(c, a, ac, bits);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 r_range_check__body(const u256& a, const u256& ac, uint32_t bits) {
     const uint32_t L = T.L, k = (bits + L - 1) / L, rem = bits % L;
     u256 last;
     if (k == 1) {
@@ -262,7 +310,19 @@ struct Gadgets {
     }
     r_check_less_than_emit(a, b, bits, b_const);
   }
-  HDN void r_check_less_than_emit(const u256& a, const u256& b, uint32_t bits, bool b_const) {
+  static HDN EmitOut r_check_less_than_emit__ool(WCtx cv, u256 a, u256 b, uint32_t bits, bool b_const) {
+    Gadgets g(cv);
+    g.r_check_less_than_emit__body(a, b, bits, b_const);
+    EmitOut o;
+    o.v = u256_zero();
+    o.take(cv);
+    return o;
+  }
+  HD void r_check_less_than_emit(const u256& a, const u256& b, uint32_t bits, bool b_const) {
+    EmitOut o = r_check_less_than_emit__ool(c, a, b, bits, b_const);
+    o.give(c);
+  }
+  HD void r_check_less_than_emit__body(const u256& a, const u256& b, uint32_t bits, bool b_const) {
     u256 sa = fr_add(T.pow2[bits], a), chk = fr_sub(sa, b);
     c.push(chk, true); c.push(b, false, b_const); c.push(T.one, false, true);
     c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false, true); c.push(T.one, false, true); c.push(a, false);
@@ -329,7 +389,20 @@ struct Gadgets {
       }
     }
   }
-  HDN void r_div_mod_var(const u256& a, const u256& b, uint32_t a_bits, uint32_t b_bits, u256& div, u256& rem) {
+  static HDN EmitOut2 r_div_mod_var__ool(WCtx cv, u256 a, u256 b, uint32_t a_bits, uint32_t b_bits) {
+    Gadgets g(cv);
+    EmitOut2 o;
+    g.r_div_mod_var__body(a, b, a_bits, b_bits, o.v, o.w);
+    o.take(cv);
+    return o;
+  }
+  HD void r_div_mod_var(const u256& a, const u256& b, uint32_t a_bits, uint32_t b_bits, u256& div, u256& rem) {
+    EmitOut2 o = r_div_mod_var__ool(c, a, b, a_bits, b_bits);
+    o.give(c);
+    div = o.v;
+    rem = o.w;
+  }
+  HD void r_div_mod_var__body(const u256& a, const u256& b, uint32_t a_bits, uint32_t b_bits, u256& div, u256& rem) {
     u256 ac = from_mont<Fr>(a), bc = from_mont<Fr>(b), qc, rc;
     if (u256_is_zero(bc)) {  // BigUint division by zero panics in the reference
       c.err = 1;
@@ -389,7 +462,19 @@ struct Gadgets {
     }
     return fp_is_neg_emit(a);
   }
-  HDN u256 fp_is_neg_emit(const u256& a) {
+  static HDN EmitOut fp_is_neg_emit__ool(WCtx cv, u256 a) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_is_neg_emit__body(a);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_is_neg_emit(const u256& a) {
+    EmitOut o = fp_is_neg_emit__ool(c, a);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_is_neg_emit__body(const u256& a) {
     u256 div, rem;
     r_div_mod_pow2(a, 2 * T.P + 1, 254, div, rem);
     u256 is_pos = g_is_zero(div);
@@ -402,7 +487,19 @@ struct Gadgets {
     }
     return fp_qabs_emit(a);
   }
-  HDN u256 fp_qabs_emit(const u256& a) {
+  static HDN EmitOut fp_qabs_emit__ool(WCtx cv, u256 a) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_qabs_emit__body(a);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_qabs_emit(const u256& a) {
+    EmitOut o = fp_qabs_emit__ool(c, a);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_qabs_emit__body(const u256& a) {
     u256 rev = g_neg(a);
     u256 n = fp_is_neg(a);
     return g_select(rev, a, n);
@@ -418,7 +515,19 @@ struct Gadgets {
     }
     return fp_signed_div_scale_emit(a);
   }
-  HDN u256 fp_signed_div_scale_emit(const u256& a) {
+  static HDN EmitOut fp_signed_div_scale_emit__ool(WCtx cv, u256 a) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_signed_div_scale_emit__body(a);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_signed_div_scale_emit(const u256& a) {
+    EmitOut o = fp_signed_div_scale_emit__ool(c, a);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_signed_div_scale_emit__body(const u256& a) {
     const uint32_t P = T.P;
     u256 ac = from_mont<Fr>(a), div, rem;
     bool neg = u256_bits(ac) > 253 || (u256_bits(ac) == 253 && !u256_is_zero(u256_low_bits(ac, 252)));  // a > 2^252
@@ -451,7 +560,19 @@ struct Gadgets {
     }
     return fp_qmul_emit(a, b);
   }
-  HDN u256 fp_qmul_emit(const u256& a, const u256& b) {
+  static HDN EmitOut fp_qmul_emit__ool(WCtx cv, u256 a, u256 b) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_qmul_emit__body(a, b);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_qmul_emit(const u256& a, const u256& b) {
+    EmitOut o = fp_qmul_emit__ool(c, a, b);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_qmul_emit__body(const u256& a, const u256& b) {
     u256 ab = g_mul(a, b);
     return fp_signed_div_scale(ab);
   }
@@ -474,7 +595,19 @@ struct Gadgets {
     }
     return fp_qdiv_emit(a, b);
   }
-  HDN u256 fp_qdiv_emit(const u256& a, const u256& b) {
+  static HDN EmitOut fp_qdiv_emit__ool(WCtx cv, u256 a, u256 b) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_qdiv_emit__body(a, b);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_qdiv_emit(const u256& a, const u256& b) {
+    EmitOut o = fp_qdiv_emit__ool(c, a, b);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_qdiv_emit__body(const u256& a, const u256& b) {
     const uint32_t P = T.P;
     u256 sa = fp_is_neg(a);
     u256 sb = fp_is_neg(b);
@@ -563,7 +696,19 @@ struct Gadgets {
     }
     fp_check_power_of_two_emit(p2, e, e_small);
   }
-  HDN void fp_check_power_of_two_emit(const u256& p2, const u256& e, uint64_t e_small) {
+  static HDN EmitOut fp_check_power_of_two_emit__ool(WCtx cv, u256 p2, u256 e, uint64_t e_small) {
+    Gadgets g(cv);
+    g.fp_check_power_of_two_emit__body(p2, e, e_small);
+    EmitOut o;
+    o.v = u256_zero();
+    o.take(cv);
+    return o;
+  }
+  HD void fp_check_power_of_two_emit(const u256& p2, const u256& e, uint64_t e_small) {
+    EmitOut o = fp_check_power_of_two_emit__ool(c, p2, e, e_small);
+    o.give(c);
+  }
+  HD void fp_check_power_of_two_emit__body(const u256& p2, const u256& e, uint64_t e_small) {
     const uint32_t nb = 2 * T.P;
     u256 pc = from_mont<Fr>(p2);
     // num_to_bits: inner_product(bits, pow2) starting with constant 1, then nb assert_bit
@@ -636,7 +781,19 @@ struct Gadgets {
     }
     return fp_qlog2_emit(a);
   }
-  HDN u256 fp_qlog2_emit(const u256& a) {
+  static HDN EmitOut fp_qlog2_emit__ool(WCtx cv, u256 a) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_qlog2_emit__body(a);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_qlog2_emit(const u256& a) {
+    EmitOut o = fp_qlog2_emit__ool(c, a);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_qlog2_emit__body(const u256& a) {
     const uint32_t P = T.P;
     u256 a_assigned = g_add(a, zero());
     u256 is_neg = fp_is_neg(a);
@@ -697,7 +854,19 @@ struct Gadgets {
     }
     return fp_qexp2_emit(a);
   }
-  HDN u256 fp_qexp2_emit(const u256& a) {
+  static HDN EmitOut fp_qexp2_emit__ool(WCtx cv, u256 a) {
+    Gadgets g(cv);
+    EmitOut o;
+    o.v = g.fp_qexp2_emit__body(a);
+    o.take(cv);
+    return o;
+  }
+  HD u256 fp_qexp2_emit(const u256& a) {
+    EmitOut o = fp_qexp2_emit__ool(c, a);
+    o.give(c);
+    return o.v;
+  }
+  HD u256 fp_qexp2_emit__body(const u256& a) {
     const uint32_t P = T.P;
     u256 a_abs = fp_qabs(a);
     u256 ip, fpart;

@@ -149,36 +149,36 @@ struct Gadgets {
   HD u256 inv_cell(const u256& x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (c.inv_cnt) {
-      if (!c.in_window(c.pos + 2) || !c.in_rank(c.pos + 2)) return T.one;  // this window does not store the cell at all
+      if (!c.in_window(c.pos + 2) || !c.in_rank(c.pos + 2)) return mont_one<Fr>();  // this window does not store the cell at all
       uint32_t i = atomicAdd(c.inv_cnt, 1u);
       if (i < c.inv_cap) {
         c.inv_pos[i] = c.pos + 2;
         c.inv_val[i] = x;
-        return T.one;  // placeholder, overwritten by k_inv_fixup
+        return mont_one<Fr>();  // placeholder, overwritten by k_inv_fixup
       }
     }
 #endif
     return mont_inv<Fr>(x);
   }
   HD u256 inv_or_one(const u256& x) const {
-    if (u256_is_zero(x)) return T.one;
+    if (u256_is_zero(x)) return mont_one<Fr>();
     return inv_cell(x);
   }
 
   // ================================================================ GateChip templates
   HD u256 g_add(const u256& a, const u256& b) {  // [a, b, 1, out]
     u256 o = fr_add(a, b);
-    c.push(a, true); c.push(b, false); c.push(T.one, false, true); c.push(o, false);
+    c.push(a, true); c.push(b, false); c.push(mont_one<Fr>(), false, true); c.push(o, false);
     return o;
   }
   HD u256 g_sub(const u256& a, const u256& b) {  // [out, b, 1, a]
     u256 o = fr_sub(a, b);
-    c.push(o, true); c.push(b, false); c.push(T.one, false, true); c.push(a, false);
+    c.push(o, true); c.push(b, false); c.push(mont_one<Fr>(), false, true); c.push(a, false);
     return o;
   }
   HD u256 g_neg(const u256& a) {  // [a, out, 1, 0]
     u256 o = fr_neg(a);
-    c.push(a, true); c.push(o, false); c.push(T.one, false, true); c.push(zero(), false, true);
+    c.push(a, true); c.push(o, false); c.push(mont_one<Fr>(), false, true); c.push(zero(), false, true);
     return o;
   }
   HD u256 g_mul(const u256& a, const u256& b) {  // [0, a, b, out]
@@ -194,33 +194,33 @@ struct Gadgets {
   HD void g_assert_bit(const u256& x) {  // [0, x, x, x]
     c.push(zero(), true, true); c.push(x, false); c.push(x, false); c.push(x, false);
   }
-  HD u256 g_not(const u256& a) { return g_sub(T.one, a); }
+  HD u256 g_not(const u256& a) { return g_sub(mont_one<Fr>(), a); }
   HD u256 g_and(const u256& a, const u256& b) { return g_mul(a, b); }
   HD u256 g_or(const u256& a, const u256& b) {  // [1-b, 1, b, 1, b, a, 1-b, out]
-    u256 nb = fr_sub(T.one, b);
+    u256 nb = fr_sub(mont_one<Fr>(), b);
     u256 o = fr_sub(fr_add(a, b), fr_mul(a, b));
-    c.push(nb, true); c.push(T.one, false, true); c.push(b, false); c.push(T.one, false, true);
+    c.push(nb, true); c.push(mont_one<Fr>(), false, true); c.push(b, false); c.push(mont_one<Fr>(), false, true);
     c.push(b, true); c.push(a, false); c.push(nb, false); c.push(o, false);
     return o;
   }
   HD u256 g_select(const u256& a, const u256& b, const u256& s) {  // [a-b, 1, b, a, b, sel, a-b, out]
     u256 d = fr_sub(a, b);
-    u256 o = u256_is_zero(s) ? b : (u256_eq(s, T.one) ? a : fr_add(fr_mul(d, s), b));
-    c.push(d, true); c.push(T.one, false, true); c.push(b, false); c.push(a, false);
+    u256 o = u256_is_zero(s) ? b : (u256_eq(s, mont_one<Fr>()) ? a : fr_add(fr_mul(d, s), b));
+    c.push(d, true); c.push(mont_one<Fr>(), false, true); c.push(b, false); c.push(a, false);
     c.push(b, true); c.push(s, false); c.push(d, false); c.push(o, false);
     return o;
   }
   // is_zero with the inverse cell supplied (WitnessFraction evaluated)
   HD u256 g_is_zero_inv(const u256& a, const u256& inv) {  // [z, a, inv, 1, 0, a, z, 0]
-    u256 z = u256_is_zero(a) ? T.one : zero();
-    c.push(z, true); c.push(a, false); c.push(inv, false); c.push(T.one, false, true);
+    u256 z = u256_is_zero(a) ? mont_one<Fr>() : zero();
+    c.push(z, true); c.push(a, false); c.push(inv, false); c.push(mont_one<Fr>(), false, true);
     c.push(zero(), true, true); c.push(a, false); c.push(z, false); c.push(zero(), false, true);
     return z;
   }
   HD u256 g_is_zero(const u256& a) {
     if (c.skip(8)) {
       c.pos += 8;
-      return u256_is_zero(a) ? T.one : zero();
+      return u256_is_zero(a) ? mont_one<Fr>() : zero();
     }
     return g_is_zero_inv(a, inv_or_one(a));
   }
@@ -324,8 +324,8 @@ struct Gadgets {
   }
   HD void r_check_less_than_emit__body(const u256& a, const u256& b, uint32_t bits, bool b_const) {
     u256 sa = fr_add(T.pow2[bits], a), chk = fr_sub(sa, b);
-    c.push(chk, true); c.push(b, false, b_const); c.push(T.one, false, true);
-    c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false, true); c.push(T.one, false, true); c.push(a, false);
+    c.push(chk, true); c.push(b, false, b_const); c.push(mont_one<Fr>(), false, true);
+    c.push(sa, true); c.push(fr_neg(T.pow2[bits]), false, true); c.push(mont_one<Fr>(), false, true); c.push(a, false);
     r_range_check(chk, from_mont<Fr>(chk), bits);
   }
   HD void r_check_big_less_than_safe(const u256& a, const u256& bound_mont, uint32_t bound_bits) {
@@ -336,15 +336,15 @@ struct Gadgets {
   HD u256 r_is_less_than(const u256& a, const u256& b, uint32_t bits) {
     const uint32_t L = T.L, k = (bits + L - 1) / L, padded = k * L;
     u256 sa = fr_add(T.pow2[padded], a), sh = fr_sub(sa, b);
-    c.push(sh, true); c.push(b, false); c.push(T.one, false, true);
-    c.push(sa, true); c.push(fr_neg(T.pow2[padded]), false, true); c.push(T.one, false, true); c.push(a, false);
+    c.push(sh, true); c.push(b, false); c.push(mont_one<Fr>(), false, true);
+    c.push(sa, true); c.push(fr_neg(T.pow2[padded]), false, true); c.push(mont_one<Fr>(), false, true); c.push(a, false);
     u256 shc = from_mont<Fr>(sh);
     u256 last = r_range_check(sh, shc, padded + L);
     return g_is_zero_inv(last, inv_small_or_full(last, u256_extract(shc, padded, L)));
   }
   // inverse of a value known to equal the small canonical integer `v` (< 260), else Fermat
   HD u256 inv_small_or_full(const u256& x, uint32_t v) const {
-    if (v == 0) return T.one;
+    if (v == 0) return mont_one<Fr>();
     if (v < 260) return T.small_inv[v];
     return inv_cell(x);
   }
@@ -357,7 +357,7 @@ struct Gadgets {
     rem = to_mont<Fr>(rc);
     c.push(rem, true); c.push(T.pow2[shift], false, true); c.push(div, false); c.push(a, false);
     // div < 2^a_bits / 2^shift + 1 ; rem < 2^shift
-    u256 bound = fr_add(T.pow2[a_bits - shift], T.one);
+    u256 bound = fr_add(T.pow2[a_bits - shift], mont_one<Fr>());
     r_check_big_less_than_safe(div, bound, a_bits - shift + 1);
     r_check_big_less_than_safe(rem, T.pow2[shift], shift + 1);
   }
@@ -458,7 +458,7 @@ struct Gadgets {
   HD u256 fp_is_neg(const u256& a) {  // fixed_point.rs:523-539
     if (c.skip2(T.sz.is_neg)) {
       c.advance(T.sz.is_neg);
-      return v_is_neg(from_mont<Fr>(a)) ? T.one : zero();
+      return v_is_neg(from_mont<Fr>(a)) ? mont_one<Fr>() : zero();
     }
     return fp_is_neg_emit(a);
   }
@@ -582,10 +582,10 @@ struct Gadgets {
     g_assert_bit(a2);
     g_assert_bit(b2);
     u256 ab = g_add(a2, b2);
-    u256 one = g_add(T.one, zero());
+    u256 one = g_add(mont_one<Fr>(), zero());
     u256 d = g_sub(ab, one);
     // d in {-1, 0, 1}
-    u256 inv = u256_is_zero(d) ? T.one : (u256_eq(d, T.one) ? T.one : fr_neg(T.one));
+    u256 inv = u256_is_zero(d) ? mont_one<Fr>() : (u256_eq(d, mont_one<Fr>()) ? mont_one<Fr>() : fr_neg(mont_one<Fr>()));
     return g_is_zero_inv(d, inv);
   }
   HD u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
@@ -643,7 +643,7 @@ struct Gadgets {
     u256 last = zero();
     for (int i = 0; i < M; i++) {
       u256 y_add = fr_add(last, coef[i]);  // qadd(last_y, Constant(coef)): [last_y, coef, 1, out]
-      c.push(last, true, i == 0); c.push(coef[i], false, true); c.push(T.one, false, true); c.push(y_add, false);
+      c.push(last, true, i == 0); c.push(coef[i], false, true); c.push(mont_one<Fr>(), false, true); c.push(y_add, false);
       if (i < M - 1) last = fp_qmul(x, y_add);
       else result = y_add;
     }
@@ -665,7 +665,7 @@ struct Gadgets {
         } else {
           u256 ci = i < 260 ? T.small[i] : to_mont<Fr>(u256_from_u64(i));
           u256 d = fr_sub(idx, ci);  // is_equal(idx, Constant(i)) = sub [d, i, 1, idx] + is_zero
-          c.push(d, true); c.push(ci, false, true); c.push(T.one, false, true); c.push(idx, false);
+          c.push(d, true); c.push(ci, false, true); c.push(mont_one<Fr>(), false, true); c.push(idx, false);
           g_is_zero_inv(d, signed_small_inv(d, diff));
         }
       }
@@ -678,13 +678,13 @@ struct Gadgets {
       bool hit = (idx_small == i);
       if (hit) s = ai;
       c.push(ai, false, cells_const);
-      c.push(hit ? T.one : zero(), false);
+      c.push(hit ? mont_one<Fr>() : zero(), false);
       c.push(s, i + 1 < n);
     }
     return s;
   }
   HD u256 signed_small_inv(const u256& x, int64_t v) const {
-    if (v == 0) return T.one;
+    if (v == 0) return mont_one<Fr>();
     if (v > 0 && v < 260) return T.small_inv[v];
     if (v < 0 && v > -260) return fr_neg(T.small_inv[-v]);
     return inv_cell(x);
@@ -715,7 +715,7 @@ struct Gadgets {
     uint32_t nset = 0;
     {
       u256 rem = pc;  // bits are peeled off a running right shift (static register indexing only)
-      u256 s = (rem.w[0] & 1u) ? T.one : zero();
+      u256 s = (rem.w[0] & 1u) ? mont_one<Fr>() : zero();
       nset += rem.w[0] & 1u;
       c.push(s, true);
       for (uint32_t i = 1; i < nb; i++) {
@@ -723,13 +723,13 @@ struct Gadgets {
         uint32_t bit = rem.w[0] & 1u;
         nset += bit;
         if (bit) s = fr_add(s, T.pow2[i]);
-        c.push(bit ? T.one : zero(), false);
+        c.push(bit ? mont_one<Fr>() : zero(), false);
         c.push(T.pow2[i], false, true);
         c.push(s, i + 1 < nb);
       }
       rem = pc;
       for (uint32_t i = 0; i < nb; i++) {
-        g_assert_bit((rem.w[0] & 1u) ? T.one : zero());
+        g_assert_bit((rem.w[0] & 1u) ? mont_one<Fr>() : zero());
         rem = u256_shr_small(rem, 1);
       }
     }
@@ -737,27 +737,27 @@ struct Gadgets {
     {
       u256 rem = pc;
       uint32_t run = rem.w[0] & 1u;
-      c.push(run ? T.one : zero(), nb > 1);
+      c.push(run ? mont_one<Fr>() : zero(), nb > 1);
       for (uint32_t i = 1; i < nb; i++) {
         rem = u256_shr_small(rem, 1);
         uint32_t bit = rem.w[0] & 1u;
         run += bit;
-        c.push(bit ? T.one : zero(), false);
-        c.push(T.one, false, true);
+        c.push(bit ? mont_one<Fr>() : zero(), false);
+        c.push(mont_one<Fr>(), false, true);
         c.push(small(run), i + 1 < nb);
       }
     }
     u256 sum = small(nset);
-    u256 sm1 = g_sub(sum, T.one);
+    u256 sm1 = g_sub(sum, mont_one<Fr>());
     g_is_zero_inv(sm1, signed_small_inv(sm1, (int64_t)nset - 1));
     u256 walk = pc;  // the cell callback is invoked for i = 0, 1, 2, ... in order
     u256 bit = g_select_from_idx(nb, e, e_small, [&](uint32_t) {
-      u256 v = (walk.w[0] & 1u) ? T.one : u256_zero();
+      u256 v = (walk.w[0] & 1u) ? mont_one<Fr>() : u256_zero();
       walk = u256_shr_small(walk, 1);
       return v;
     });
-    u256 bm1 = g_sub(bit, T.one);
-    g_is_zero_inv(bm1, u256_is_zero(bm1) ? T.one : fr_neg(T.one));
+    u256 bm1 = g_sub(bit, mont_one<Fr>());
+    g_is_zero_inv(bm1, u256_is_zero(bm1) ? mont_one<Fr>() : fr_neg(mont_one<Fr>()));
   }
   HD u256 v_qlog2(const u256& a) {
     u256 ac = from_mont<Fr>(a);
@@ -805,7 +805,7 @@ struct Gadgets {
     u256 exp1 = g_add(small_or_mont(nd), zero());
     fp_check_power_of_two(pow1w, exp1, nd);
     u256 pow2w = g_mul(pow1w, T.small[2]);
-    u256 exp2 = g_add(exp1, T.one);
+    u256 exp2 = g_add(exp1, mont_one<Fr>());
     fp_check_power_of_two(pow2w, exp2, (uint64_t)nd + 1);
     u256 lt2 = r_is_less_than(a, pow2w, 2 * P);
     u256 gt1 = r_is_less_than(pow1w, a, 2 * P);

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTable
           for (uint32_t j = 0; j <= tid; j++) s = fr_add(s, sh[j]);
           c.pos = sumbase + 1 + 3ull * (i - 1);
           c.push(v, false);
-          c.push(T->one, false, true);
+          c.push(mont_one<Fr>(), false, true);
           c.push(s, i + 1 < D);
         }
       }
@@ -517,15 +517,27 @@ __global__ __launch_bounds__(64) void k_km_assign(Streams st, const FpTables* __
     if (live && s == S - 1) ind[(size_t)v * K + k] = r;
   }
 }
+#define KM_PF 8
 __global__ void k_km_sizes(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t base, const u256* __restrict__ ind, u256* __restrict__ sizes) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= kl.K) return;
   WCtx c = make_ctx(st, T, 0, 0);
   Gadgets g(c);
+  // the running sum is sequential, the operands are not: fetch KM_PF of them ahead of the dependent chain (a load
+  // per step on the critical path made this kernel pure memory latency)
   u256 s = ind[k];
-  for (uint32_t v = 1; v < kl.N; v++) {
-    c.pos = base + ((uint64_t)(v - 1) * kl.K + k) * 4;
-    s = g.g_add(s, ind[(size_t)v * kl.K + k]);
+  for (uint32_t v0 = 1; v0 < kl.N; v0 += KM_PF) {
+    u256 x[KM_PF];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) x[q] = ind[(size_t)(v0 + q < kl.N ? v0 + q : kl.N - 1) * kl.K + k];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) {
+      const uint32_t v = v0 + q;
+      if (v < kl.N) {
+        c.pos = base + ((uint64_t)(v - 1) * kl.K + k) * 4;
+        s = g.g_add(s, x[q]);
+      }
+    }
   }
   sizes[k] = s;
 }
@@ -537,8 +549,15 @@ __global__ __launch_bounds__(64) void k_km_filter(Streams st, const FpTables* __
   WCtx c = make_ctx(st, T, cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)v * (8 + 8ull * kl.D), 0);
   Gadgets g(c);
   u256 sel = ind[(size_t)v * kl.K + k];
-  u256 iz = g.g_is_zero_inv(sel, u256_is_zero(sel) ? T->one : scale_inv);
-  for (uint32_t j = 0; j < kl.D; j++) filt[((size_t)k * kl.N + v) * kl.D + j] = g.g_select(u256_zero(), vectors[(size_t)v * kl.D + j], iz);
+  u256 iz = g.g_is_zero_inv(sel, u256_is_zero(sel) ? mont_one<Fr>() : scale_inv);
+  for (uint32_t j0 = 0; j0 < kl.D; j0 += KM_PF) {
+    u256 x[KM_PF];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) x[q] = vectors[(size_t)v * kl.D + (j0 + q < kl.D ? j0 + q : kl.D - 1)];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++)
+      if (j0 + q < kl.D) filt[((size_t)k * kl.N + v) * kl.D + j0 + q] = g.g_select(u256_zero(), x[q], iz);
+  }
 }
 __global__ __launch_bounds__(64) void k_km_sum(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ filt,
                                                u256* __restrict__ sums) {
@@ -549,9 +568,18 @@ __global__ __launch_bounds__(64) void k_km_sum(Streams st, const FpTables* __res
   Gadgets g(c);
   const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D);
   u256 s = filt[((size_t)k * kl.N) * kl.D + j];
-  for (uint32_t v = 1; v < kl.N; v++) {
-    c.pos = base + ((uint64_t)(v - 1) * kl.D + j) * 4;
-    s = g.g_add(filt[((size_t)k * kl.N + v) * kl.D + j], s);  // qadd(vector_j, sum_j)
+  for (uint32_t v0 = 1; v0 < kl.N; v0 += KM_PF) {
+    u256 x[KM_PF];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) x[q] = filt[((size_t)k * kl.N + (v0 + q < kl.N ? v0 + q : kl.N - 1)) * kl.D + j];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) {
+      const uint32_t v = v0 + q;
+      if (v < kl.N) {
+        c.pos = base + ((uint64_t)(v - 1) * kl.D + j) * 4;
+        s = g.g_add(x[q], s);  // qadd(vector_j, sum_j)
+      }
+    }
   }
   sums[id] = s;
 }
@@ -595,7 +623,7 @@ __device__ u256 trace_sum(WCtx& c, const FpTables* T, const u256* v, int n, unsi
   for (int i = 1; i < n; i++) {
     s = fr_add(s, v[i]);
     c.push(v[i], false, (cmask >> i) & 1u);
-    c.push(T->one, false, true);
+    c.push(mont_one<Fr>(), false, true);
     c.push(s, i + 1 < n);
   }
   return s;
@@ -603,7 +631,7 @@ __device__ u256 trace_sum(WCtx& c, const FpTables* T, const u256* v, int n, unsi
 __device__ u256 trace_ip_const(WCtx& c, const FpTables* T, const u256* a, const u256* row, int n) {  // inner_product(a, constants)
   u256 s;
   int i0, ng;
-  if (u256_eq(row[0], T->one)) {
+  if (u256_eq(row[0], mont_one<Fr>())) {
     s = a[0];
     i0 = 1;
     ng = n - 1;
@@ -647,7 +675,7 @@ __device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const
   }
   for (int i = n_in + 1, k = 0; i < PSD_T; i++, k++) {
     u256 cst = sp->start[0][i];
-    if (k == 0) cst = fr_add(cst, T->one);
+    if (k == 0) cst = fr_add(cst, mont_one<Fr>());
     u256 v[2] = {st[i], cst};
     st[i] = trace_sum(c, T, v, 2, 2u);
   }
@@ -748,15 +776,6 @@ __global__ void k_layout_plan(const uint8_t* __restrict__ sel, uint64_t n_cells,
     S += r;
   }
   *n_bp = cnt;
-}
-__global__ void k_layout_starts(const uint64_t* __restrict__ bp, uint64_t n_bp, uint64_t* __restrict__ starts) {
-  if (blockIdx.x || threadIdx.x) return;
-  uint64_t s = 0;
-  starts[0] = 0;
-  for (uint64_t i = 0; i < n_bp; i++) {
-    s += bp[i];
-    starts[i + 1] = s;
-  }
 }
 __global__ __launch_bounds__(256) void k_layout_columns(const u256* __restrict__ stream, uint64_t n_cells, const uint64_t* __restrict__ starts,
                                                         const uint64_t* __restrict__ bp, uint64_t n_bp, uint32_t k, u256* __restrict__ cols,
@@ -1061,6 +1080,25 @@ using namespace vdb;
 // rank window applied by the *_dev witness entry points (vdb_wit_set_window); full range by default
 static uint64_t g_win[4] = {0, ~0ull, 0, ~0ull};
 
+// break points and their prefix sums (column c starts at stream cell starts[c]) -> device scratch slot 1
+static int upload_break_points(const uint64_t* break_points, uint64_t n_bp, uint64_t** dbp, uint64_t** dstarts) {
+  static std::vector<uint64_t> h;  // pageable source: hipMemcpyAsync stages it before returning
+  h.resize(2 * n_bp + 2);
+  uint64_t acc = 0;
+  h[n_bp] = 0;
+  for (uint64_t i = 0; i < n_bp; i++) {
+    h[i] = break_points[i];
+    acc += break_points[i];
+    h[n_bp + 1 + i] = acc;
+  }
+  uint64_t* d = (uint64_t*)scratch_get(1, (2 * n_bp + 2) * sizeof(uint64_t));
+  if (!d) return VDB_ERR_OOM;
+  VDB_HIP(hipMemcpyAsync(d, h.data(), (2 * n_bp + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
+  *dbp = d;
+  *dstarts = d + n_bp;
+  return VDB_OK;
+}
+
 // upload helper for the host-pointer entry points
 static int upload(DevBuf& d, const void* src, size_t bytes) {
   TRY(d.alloc(bytes));
@@ -1320,16 +1358,8 @@ int vdb_layout_columns_range_dev(const vdb_fr* stream_dev, uint64_t n_cells, con
     sum += break_points[i];
   }
   VDB_ARG(sum <= n_cells && n_cells - sum <= rows, "break points do not match the stream length");
-  uint64_t* d = (uint64_t*)scratch_get(1, (2 * n_bp + 2) * sizeof(uint64_t));
-  if (!d) return VDB_ERR_OOM;
-  uint64_t* dbp = d;
-  uint64_t* dst = d + n_bp;
-  if (n_bp) VDB_HIP(hipMemcpyAsync(dbp, break_points, n_bp * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
-  {
-    VDB_PROF("k_layout_starts");
-    hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
-  }
-  VDB_LAUNCH_CHECK();
+  uint64_t *dbp, *dst;
+  TRY(upload_break_points(break_points, n_bp, &dbp, &dst));
   uint64_t total = (col_hi - col_lo) * rows;
   {
     VDB_PROF("k_layout_columns");
@@ -1365,16 +1395,8 @@ int vdb_layout_const_mask_dev(const uint8_t* flags_dev, uint64_t n_cells, const 
   VDB_REQUIRE_INIT();
   VDB_ARG(flags_dev && mask_dev && (break_points || n_bp == 0) && k <= 28, "bad argument");
   const uint64_t rows = 1ull << k;
-  uint64_t* d = (uint64_t*)scratch_get(1, (2 * n_bp + 2) * sizeof(uint64_t));
-  if (!d) return VDB_ERR_OOM;
-  uint64_t* dbp = d;
-  uint64_t* dst = d + n_bp;
-  if (n_bp) VDB_HIP(hipMemcpyAsync(dbp, break_points, n_bp * sizeof(uint64_t), hipMemcpyHostToDevice, ctx().stream));
-  {
-    VDB_PROF("k_layout_starts");
-    hipLaunchKernelGGL(k_layout_starts, dim3(1), dim3(1), 0, ctx().stream, dbp, n_bp, dst);
-  }
-  VDB_LAUNCH_CHECK();
+  uint64_t *dbp, *dst;
+  TRY(upload_break_points(break_points, n_bp, &dbp, &dst));
   uint64_t total = (n_bp + 1) * rows;
   {
     VDB_PROF("k_layout_const_mask");

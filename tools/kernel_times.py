@@ -9,7 +9,8 @@ from halo2_vectordb_amd import api
 from halo2_vectordb_amd.pipeline import KmeansHotPath
 
 api.init(0)
-hp = KmeansHotPath().setup()
+r, w = (int(x) for x in (sys.argv[1:3] if len(sys.argv) > 2 else (0, 1)))
+hp = KmeansHotPath(col_shard=(r, w)).setup()
 hp.step()
 api.profile_begin()
 hp.step()

@@ -241,14 +241,28 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   // on its own; a forward transform's last pass reduces without a product (l9_canon_wide)
   L9 FIN;
   if (LAST && p.scale) FIN = l9_split(p.fin);
-  for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+  // inter-pass twiddles are fetched for all of the thread's elements up front: on gfx9 a load that follows stores
+  // waits for their acknowledgement too (one in-order vmcnt), which would put a store round trip between elements
+  constexpr uint32_t EPT = NTT_TILE / NTT_THREADS;
+  u256 twv[EPT];
+  if (!LAST) {
+#pragma unroll
+    for (uint32_t it = 0; it < EPT; it++) {
+      const uint32_t e = tid + it * NTT_THREADS;
+      const uint32_t g = e & (G - 1), q = e >> p.logG;
+      const uint64_t ex = ((uint64_t)q * ((uint64_t)i0 + g)) << (p.log_n - S - p.log_inner);
+      if (e < T) twv[it] = ld256(tw + ex);
+    }
+  }
+#pragma unroll
+  for (uint32_t it = 0; it < EPT; it++) {
+    const uint32_t e = tid + it * NTT_THREADS;
+    if (e >= T) break;
     uint32_t g = e & (G - 1), q = e >> p.logG;
     L9 v = lds_get(D, g * row + bitrev_s(q, S));
     l9_renorm(v);
     if (!LAST) {
-      uint64_t i = (uint64_t)i0 + g;
-      uint64_t ex = ((uint64_t)q * i) << (p.log_n - S - p.log_inner);
-      v = l9_mul(v, l9_split(ld256(tw + ex)));
+      v = l9_mul(v, l9_split(twv[it]));
       st256(cout + base + (uint64_t)q * jstride + g, l9_canon(v));
     } else {
       uint64_t pos;

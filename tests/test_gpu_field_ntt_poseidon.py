@@ -67,6 +67,30 @@ def test_lagrange_to_coeff_and_extended(api, O, k):
     assert np.array_equal(got_e, want_e)
 
 
+@pytest.mark.parametrize("k,ext", [(7, 3), (9, 1), (10, 1), (10, 3), (12, 1), (13, 3)])
+def test_coeff_to_extended_other_extensions(api, O, k, ext):
+    """extension factors 2 and 8 (the zero-padded first pass skips stages only when at most a quarter of a row is
+    data), single-pass and multi-pass sizes"""
+    rng = np.random.default_rng(70 + 10 * k + ext)
+    cols = O.random_fr(rng, 2 << k).reshape(2, 1 << k, 4)
+    want_c, want_e = O.lde_batch(cols, ext=ext, threads=4)
+    got_c = api.lagrange_to_coeff(cols)
+    assert np.array_equal(got_c, want_c)
+    assert np.array_equal(api.coeff_to_extended(got_c, ext), want_e)
+
+
+def test_ntt_three_passes_k20(api, O):
+    """2^20 = 128 x 128 x 64: the three-pass decomposition (middle pass with two outer digits)"""
+    rng = np.random.default_rng(61)
+    k = 20
+    cols = O.random_fr(rng, 1 << k).reshape(1, 1 << k, 4)
+    w = O.root_of_unity(k)
+    f = api.ntt_batch(cols, w)
+    assert np.array_equal(f, O.ntt_batch(cols, w, threads=4))
+    winv = O.fr_inv(w.reshape(1, 4))[0]
+    assert np.array_equal(api.ntt_batch(f, winv, api.NTT_INVERSE_SCALE), cols)
+
+
 def test_ntt_roundtrip_full_size(api, O):
     # size-independent property at the bench size (k=16 -> extended 2^18): iNTT(NTT(x)) == x
     rng = np.random.default_rng(60)

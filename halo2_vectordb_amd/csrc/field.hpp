@@ -302,97 +302,6 @@ HD u256 mont_mul(const u256& a, const u256& b) {
   uint32_t borrow = u256_sub(s, r, p);
   return borrow ? r : s;
 }
-// ---- lazy-reduction variants for the NTT butterflies -------------------------------------------------------
-// Values live in [0, 2p) (any 256-bit pattern below 4p is a valid multiplier input).  The constant operand (a
-// twiddle w) is pre-split into the nine 29-bit limbs of 32*w mod p, so a * Bp * 2^-261 = a * w * 2^-256 needs no
-// operand shift, and because a * Bp / 2^261 + p < 1.03 p the final conditional subtraction is dropped.
-template <class M>
-HD void mont_pre_limbs(const u256& w, uint32_t Bp[9]) {
-  u256 x = w;
-#pragma unroll
-  for (int i = 0; i < 5; i++) x = mod_add<M>(x, x);  // 32 * w mod p
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
-    uint32_t lo = x.w[wb];
-    uint32_t hi = wb + 1 < 8 ? x.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
-    Bp[k] = (ob ? ((lo >> ob) | (hi << (32 - ob))) : lo) & 0x1fffffffu;
-  }
-}
-template <class M>
-HD u256 mont_mul_lazy_pre(const u256& a, const uint32_t Bp[9], const uint32_t* A_limbs = nullptr) {
-  constexpr uint32_t MASK = 0x1fffffffu;
-  uint32_t A[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    if (A_limbs) {
-      A[k] = A_limbs[k];
-    } else {
-      int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
-      uint32_t lo = a.w[wb];
-      uint32_t hi = wb + 1 < 8 ? a.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
-      A[k] = ob ? ((lo >> ob) | (hi << (32 - ob))) : lo;
-      if (k < 8) A[k] &= MASK;  // top limb keeps every remaining bit (a < 2^256)
-    }
-  }
-  uint32_t L[9];
-  mont_core29<M>(L, A, Bp);
-  u256 r;
-  r.w[0] = L[0] | (L[1] << 29);
-  r.w[1] = (L[1] >> 3) | (L[2] << 26);
-  r.w[2] = (L[2] >> 6) | (L[3] << 23);
-  r.w[3] = (L[3] >> 9) | (L[4] << 20);
-  r.w[4] = (L[4] >> 12) | (L[5] << 17);
-  r.w[5] = (L[5] >> 15) | (L[6] << 14);
-  r.w[6] = (L[6] >> 18) | (L[7] << 11);
-  r.w[7] = (L[7] >> 21) | (L[8] << 8);
-  return r;  // < 2p
-}
-// a (any value below 4p) times a canonical b: result in [0, 2p), no final subtraction
-// (a * b / 2^256 + p < 4p * 0.19 + p < 2p)
-template <class M>
-HD u256 mont_mul_lazy(const u256& a, const u256& b) {
-  constexpr uint32_t MASK = 0x1fffffffu;
-  uint32_t A[9], B[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    int pos = 29 * k - 5;  // limb k of (a << 5)
-    if (pos < 0) {
-      A[k] = (a.w[0] << 5) & MASK;
-    } else {
-      int w = pos >> 5, o = pos & 31;
-      uint32_t lo = w < 8 ? a.w[w < 8 ? w : 0] : 0u;
-      uint32_t hi = w + 1 < 8 ? a.w[w + 1 < 8 ? w + 1 : 0] : 0u;
-      A[k] = o ? ((lo >> o) | (hi << (32 - o))) : lo;
-      if (k < 8) A[k] &= MASK;
-    }
-    int pb = 29 * k, wb = pb >> 5, ob = pb & 31;
-    uint32_t lob = b.w[wb];
-    uint32_t hib = wb + 1 < 8 ? b.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
-    B[k] = (ob ? ((lob >> ob) | (hib << (32 - ob))) : lob) & MASK;
-  }
-  return mont_mul_lazy_pre<M>(u256_zero(), B, A);
-}
-// u + v for u, v in [0, 2p): result in [0, 2p)
-template <class M>
-HD u256 lazy_add(const u256& u, const u256& v) {
-  u256 r, s, p2;
-  u256 p = mod_p<M>();
-  u256_add(p2, p, p);
-  u256_add(r, u, v);  // < 4p < 2^256
-  uint32_t borrow = u256_sub(s, r, p2);
-  return borrow ? r : s;
-}
-// u - v + 2p for u, v in [0, 2p): result in (0, 4p), a valid lazy multiplier input
-template <class M>
-HD u256 lazy_sub(const u256& u, const u256& v) {
-  u256 t, r, p2;
-  u256 p = mod_p<M>();
-  u256_add(p2, p, p);
-  u256_add(t, u, p2);
-  u256_sub(r, t, v);
-  return r;
-}
 // [0, 2p) -> [0, p)
 template <class M>
 HD u256 lazy_canon(const u256& a) {

@@ -524,7 +524,6 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ part
   // result = sum_L total_L + per * sum_L L * running_L
   // suffix scan of running over lanes: suf_L = sum_{L' >= L} running_L'
   XYZZ suf = running;
-#pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     XYZZ other = shfl_xyzz(suf, (int)lane + o < 64 ? (int)lane + o : (int)lane);
     if ((int)lane + o < 64) xyzz_add(suf, other);
@@ -532,7 +531,6 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const XYZZ* __restrict__ part
   // sum_{L>=1} suf_L = sum_L L * running_L
   XYZZ t2 = lane >= 1 ? suf : xyzz_identity();
   XYZZ t1 = total;
-#pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     XYZZ a = shfl_xyzz(t1, (int)lane + o < 64 ? (int)lane + o : (int)lane);
     XYZZ b = shfl_xyzz(t2, (int)lane + o < 64 ? (int)lane + o : (int)lane);

@@ -92,7 +92,7 @@ int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr *x, double *out, siz
  *      already-assigned quantized inputs; sizes come from the matching *_size call.
  *      metric: 0 euclidean, 1 cosine, 2 manhattan (DistanceChip, src/gadget/distance.rs:97-195).
  *      selector_out (optional, 1 flag byte per advice cell): bit 0 marks gate starts — the keygen-side information
- *      from which vdb_layout_plan derives the break points that the reference pins in configs/*.json
+ *      from which vdb_layout_plan derives the break points that the reference pins in configs/<name>.json
  *      (src/scaffold/mod.rs:272, 285-287); bit 1 marks cells that hold a data-independent QuantumCell::Constant
  *      of the gate templates (used by vdb_msm_batch_masked_dev).  VDB_ERR_DOMAIN replaces the reference's panics. ---------- */
 int vdb_wit_distance_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n_pairs, size_t dim, uint64_t *cells, uint64_t *lookups);

@@ -518,70 +518,110 @@ __global__ __launch_bounds__(64) void k_km_assign(Streams st, const FpTables* __
   }
 }
 #define KM_PF 8
-__global__ void k_km_sizes(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t base, const u256* __restrict__ ind, u256* __restrict__ sizes) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= kl.K) return;
-  WCtx c = make_ctx(st, T, 0, 0);
-  Gadgets g(c);
-  // the running sum is sequential, the operands are not: fetch KM_PF of them ahead of the dependent chain (a load
-  // per step on the critical path made this kernel pure memory latency)
-  u256 s = ind[k];
-  for (uint32_t v0 = 1; v0 < kl.N; v0 += KM_PF) {
-    u256 x[KM_PF];
+__device__ __forceinline__ u256 shfl_up_u256(const u256& v, int delta) {
+  u256 r;
 #pragma unroll
-    for (uint32_t q = 0; q < KM_PF; q++) x[q] = ind[(size_t)(v0 + q < kl.N ? v0 + q : kl.N - 1) * kl.K + k];
-#pragma unroll
-    for (uint32_t q = 0; q < KM_PF; q++) {
-      const uint32_t v = v0 + q;
-      if (v < kl.N) {
-        c.pos = base + ((uint64_t)(v - 1) * kl.K + k) * 4;
-        s = g.g_add(s, x[q]);
-      }
-    }
-  }
-  sizes[k] = s;
+  for (int i = 0; i < 8; i++) r.w[i] = (uint32_t)__shfl_up((int)v.w[i], delta, 64);
+  return r;
 }
-__global__ __launch_bounds__(64) void k_km_filter(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ vectors,
-                                                  const u256* __restrict__ ind, u256 scale_inv, u256* __restrict__ filt) {
-  uint32_t id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= kl.K * kl.N) return;
-  uint32_t k = id / kl.N, v = id % kl.N;
-  WCtx c = make_ctx(st, T, cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)v * (8 + 8ull * kl.D), 0);
-  Gadgets g(c);
-  u256 sel = ind[(size_t)v * kl.K + k];
-  u256 iz = g.g_is_zero_inv(sel, u256_is_zero(sel) ? mont_one<Fr>() : scale_inv);
-  for (uint32_t j0 = 0; j0 < kl.D; j0 += KM_PF) {
-    u256 x[KM_PF];
+__device__ __forceinline__ u256 shfl_u256w(const u256& v, int src) {
+  u256 r;
 #pragma unroll
-    for (uint32_t q = 0; q < KM_PF; q++) x[q] = vectors[(size_t)v * kl.D + (j0 + q < kl.D ? j0 + q : kl.D - 1)];
+  for (int i = 0; i < 8; i++) r.w[i] = (uint32_t)__shfl((int)v.w[i], src, 64);
+  return r;
+}
+// One wavefront folds one chain s_v = s_{v-1} + x_v (s_0 = x_0) and emits the qadd cells of steps v = 1 .. N-1 at
+// base + (v - 1) * stride: ORDER 0 = [s_{v-1}, x_v, 1, s_v], ORDER 1 = [x_v, s_{v-1}, 1, s_v].  The chain is
+// sequential in the reference; here lane l owns the contiguous steps [l * per, (l + 1) * per): lane totals (loads
+// only), a wavefront scan, then every lane emits its steps from its own prefix.  Loads always run ahead of the stores
+// of a chunk (a load issued after stores waits for their acknowledgement), and lanes whose cells lie outside the
+// rank window skip the emission altogether.  Returns the chain total (all lanes).
+template <int ORDER, class LoadFn>
+__device__ __forceinline__ u256 chain_fold_wave(WCtx& c, uint64_t base, uint64_t stride, uint32_t N, LoadFn&& x) {
+  const uint32_t lane = threadIdx.x & 63, per = (N + 63) / 64;
+  const uint32_t lo = lane * per < N ? lane * per : N, hi = lo + per < N ? lo + per : N;
+  u256 tot = u256_zero();
+  for (uint32_t v0 = lo; v0 < hi; v0 += KM_PF) {
+    u256 xv[KM_PF];
+#pragma unroll
+    for (uint32_t q = 0; q < KM_PF; q++) xv[q] = x(v0 + q < hi ? v0 + q : hi - 1);
 #pragma unroll
     for (uint32_t q = 0; q < KM_PF; q++)
-      if (j0 + q < kl.D) filt[((size_t)k * kl.N + v) * kl.D + j0 + q] = g.g_select(u256_zero(), x[q], iz);
+      if (v0 + q < hi) tot = fr_add(tot, xv[q]);
   }
-}
-__global__ __launch_bounds__(64) void k_km_sum(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ filt,
-                                               u256* __restrict__ sums) {
-  uint32_t id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= kl.K * kl.D) return;
-  uint32_t k = id / kl.D, j = id % kl.D;
-  WCtx c = make_ctx(st, T, 0, 0);
-  Gadgets g(c);
-  const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D);
-  u256 s = filt[((size_t)k * kl.N) * kl.D + j];
-  for (uint32_t v0 = 1; v0 < kl.N; v0 += KM_PF) {
-    u256 x[KM_PF];
+  u256 inc = tot;  // inclusive scan over lanes
+  for (int o = 1; o < 64; o <<= 1) {
+    u256 t = shfl_up_u256(inc, o);
+    if ((int)lane >= o) inc = fr_add(inc, t);
+  }
+  const u256 total = shfl_u256w(inc, 63);
+  u256 run = fr_sub(inc, tot);  // exclusive prefix = s_{lo-1}
+  // the lane's cells: steps max(lo, 1) .. hi-1
+  const uint32_t first = lo ? lo : 1;
+  if (first >= hi) return total;
+  const uint64_t c_lo = base + (uint64_t)(first - 1) * stride, c_hi = base + (uint64_t)(hi - 2) * stride + 4;
+  if (!c.count_only && (c_hi <= c.rlo || c_lo >= c.rhi)) return total;
+  for (uint32_t v0 = lo; v0 < hi; v0 += KM_PF) {
+    u256 xv[KM_PF];
 #pragma unroll
-    for (uint32_t q = 0; q < KM_PF; q++) x[q] = filt[((size_t)k * kl.N + (v0 + q < kl.N ? v0 + q : kl.N - 1)) * kl.D + j];
+    for (uint32_t q = 0; q < KM_PF; q++) xv[q] = x(v0 + q < hi ? v0 + q : hi - 1);
 #pragma unroll
     for (uint32_t q = 0; q < KM_PF; q++) {
       const uint32_t v = v0 + q;
-      if (v < kl.N) {
-        c.pos = base + ((uint64_t)(v - 1) * kl.D + j) * 4;
-        s = g.g_add(x[q], s);  // qadd(vector_j, sum_j)
+      if (v < hi) {
+        const u256 nx = fr_add(run, xv[q]);
+        if (v >= 1) {
+          c.pos = base + (uint64_t)(v - 1) * stride;
+          c.push(ORDER == 0 ? run : xv[q], true);
+          c.push(ORDER == 0 ? xv[q] : run, false);
+          c.push(mont_one<Fr>(), false, true);
+          c.push(nx, false);
+        }
+        run = nx;
       }
     }
   }
-  sums[id] = s;
+  return total;
+}
+// cluster sizes: sizes_k = sum_v indicator[v][k] as a chain of qadd cells (vectordb.rs:316-322); one wavefront per cluster
+__global__ __launch_bounds__(64) void k_km_sizes(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t base, const u256* __restrict__ ind,
+                                                 u256* __restrict__ sizes) {
+  const uint32_t k = blockIdx.x;
+  WCtx c = make_ctx(st, T, 0, 0);
+  const u256 tot = chain_fold_wave<0>(c, base + 4ull * k, 4ull * kl.K, kl.N, [&](uint32_t v) { return ind[(size_t)v * kl.K + k]; });
+  if (threadIdx.x == 0) sizes[k] = tot;
+}
+// filtered vectors: select(0, vector_j, is_zero(indicator)) per (cluster, vector, dimension); a thread owns KM_PF dimensions
+__global__ __launch_bounds__(64) void k_km_filter(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ vectors,
+                                                  const u256* __restrict__ ind, u256 scale_inv, u256* __restrict__ filt) {
+  const uint32_t JC = (kl.D + KM_PF - 1) / KM_PF;
+  const uint64_t id = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (id >= (uint64_t)kl.K * kl.N * JC) return;
+  const uint32_t jc = (uint32_t)(id % JC), v = (uint32_t)((id / JC) % kl.N), k = (uint32_t)(id / ((uint64_t)JC * kl.N));
+  const uint32_t j0 = jc * KM_PF;
+  const u256 sel = ind[(size_t)v * kl.K + k];
+  u256 x[KM_PF];
+#pragma unroll
+  for (uint32_t q = 0; q < KM_PF; q++) x[q] = vectors[(size_t)v * kl.D + (j0 + q < kl.D ? j0 + q : kl.D - 1)];
+  const uint64_t cb = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)v * (8 + 8ull * kl.D);
+  WCtx c = make_ctx(st, T, cb, 0);
+  Gadgets g(c);
+  u256 iz;
+  if (jc == 0) iz = g.g_is_zero_inv(sel, u256_is_zero(sel) ? mont_one<Fr>() : scale_inv);
+  else iz = u256_is_zero(sel) ? mont_one<Fr>() : u256_zero();
+  c.pos = cb + 8 + 8ull * j0;
+#pragma unroll
+  for (uint32_t q = 0; q < KM_PF; q++)
+    if (j0 + q < kl.D) filt[((size_t)k * kl.N + v) * kl.D + j0 + q] = g.g_select(u256_zero(), x[q], iz);
+}
+// per-cluster, per-dimension sums of the filtered vectors (vectordb.rs:338-347): one wavefront per (cluster, dimension)
+__global__ __launch_bounds__(64) void k_km_sum(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, const u256* __restrict__ filt,
+                                               u256* __restrict__ sums) {
+  const uint32_t id = blockIdx.x, k = id / kl.D, j = id % kl.D;
+  WCtx c = make_ctx(st, T, 0, 0);
+  const uint64_t base = cbase0 + (uint64_t)k * kl.per_cluster + (uint64_t)kl.N * (8 + 8ull * kl.D) + 4ull * j;
+  const u256 tot = chain_fold_wave<1>(c, base, 4ull * kl.D, kl.N, [&](uint32_t v) { return filt[((size_t)k * kl.N + v) * kl.D + j]; });
+  if (threadIdx.x == 0) sums[id] = tot;
 }
 __global__ __launch_bounds__(64) void k_km_div(Streams st, const FpTables* __restrict__ T, KmLayout kl, uint64_t cbase0, uint64_t clbase0,
                                                const u256* __restrict__ sums, const u256* __restrict__ sizes, u256* __restrict__ cent) {
@@ -978,18 +1018,19 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
     VDB_LAUNCH_CHECK();
     {
       VDB_PROF("k_km_sizes");
-      hipLaunchKernelGGL(k_km_sizes, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, pos + kl.assign, ind_out, sizes);
+      hipLaunchKernelGGL(k_km_sizes, dim3((unsigned)K), dim3(64), 0, s, st, fp->dev, kl, pos + kl.assign, ind_out, sizes);
     }
     VDB_LAUNCH_CHECK();
     uint64_t cb = pos + kl.assign + kl.sizes, clb = lpos + kl.assign_l;
     {
       VDB_PROF("k_km_filter");
-      hipLaunchKernelGGL(k_km_filter, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, vectors, ind_out, scale_inv, filt);
+      hipLaunchKernelGGL(k_km_filter, dim3((unsigned)((K * n * ((dim + KM_PF - 1) / KM_PF) + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, vectors,
+                         ind_out, scale_inv, filt);
     }
     VDB_LAUNCH_CHECK();
     {
       VDB_PROF("k_km_sum");
-      hipLaunchKernelGGL(k_km_sum, dim3((unsigned)((K * dim + 63) / 64)), dim3(64), 0, s, st, fp->dev, kl, cb, filt, sums);
+      hipLaunchKernelGGL(k_km_sum, dim3((unsigned)(K * dim)), dim3(64), 0, s, st, fp->dev, kl, cb, filt, sums);
     }
     VDB_LAUNCH_CHECK();
     {

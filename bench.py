@@ -150,7 +150,7 @@ def main():
         elapsed = float(t.item())
         # the one real exchange step: gather the 64-byte commitments of every rank's column shard
         from halo2_vectordb_amd.pipeline import gather_commitments
-        commitments = gather_commitments(dist, commitments, hp.n_adv_cols, hp.n_lk_cols, rank, world, dev)
+        commitments = gather_commitments(dist, commitments, hp.shards, dev)
 
     total_cells = hp.n_cells + hp.n_lookup
     ms_per_step = elapsed / args.steps * 1e3

@@ -144,6 +144,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return res;
 }
 
+// per column: the number of (scalar, window) entries its MSM sorts and accumulates — the non-zero signed digits of the
+// cells that are not masked out
+__global__ __launch_bounds__(256) void k_msm_count_entries(const u256* __restrict__ scalars, const uint8_t* __restrict__ mask, uint64_t rows, uint32_t c,
+                                                           uint32_t W, unsigned long long* __restrict__ counts) {
+  const uint64_t col = blockIdx.x;
+  uint32_t n = 0;
+  for (uint64_t r = threadIdx.x; r < rows; r += 256) {
+    const uint64_t i = col * rows + r;
+    if (mask && mask[i]) continue;
+    for_each_digit(ld256(scalars + i), c, W, [&](uint32_t, uint32_t, bool) { n++; });
+  }
+  for (int o = 32; o >= 1; o >>= 1) n += __shfl_down(n, o, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counts[col], (unsigned long long)n);
+}
+
 // One workgroup per column: counting sort of (bucket -> table index|sign), segment numbering and range cutting.
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, size_t n, size_t table_n, uint32_t c, uint32_t W,
                                                                uint32_t* __restrict__ entries, size_t ent_cap,
@@ -762,6 +777,23 @@ int vdb_msm_batch_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, 
   if (rc) return rc;
   VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
   VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_msm_count_entries_dev(const vdb_srs* srs, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev, uint64_t* counts_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && scalars_dev && counts_out && n <= srs->n, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  unsigned long long* d = (unsigned long long*)scratch_get(2, n_cols * sizeof(unsigned long long));
+  if (!d) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(d, 0, n_cols * sizeof(unsigned long long), cx.stream));
+  {
+    VDB_PROF("k_msm_count_entries");
+    hipLaunchKernelGGL(k_msm_count_entries, dim3((unsigned)n_cols), dim3(256), 0, cx.stream, as_u256(scalars_dev), skip_mask_dev, (uint64_t)n, srs->c, srs->W, d);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(counts_out, d, n_cols * sizeof(uint64_t), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
   return VDB_OK;
 }
 int vdb_msm_batch_masked_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev,

@@ -47,12 +47,43 @@ def column_shards(n_adv, n_lk, world):
     return [(shard_range(n_adv, r, world), shard_range(n_lk, r, world)) for r in range(world)]
 
 
-def gather_commitments(dist, local, n_adv, n_lk, rank, world, device):
+def balanced_ranges(cost, world):
+    """Contiguous blocks of a column list with (nearly) equal summed cost: block r ends at the first column where the
+    running cost reaches (r + 1) / world of the total."""
+    cost = np.asarray(cost, dtype=np.float64)
+    n = len(cost)
+    if n == 0:
+        return [(0, 0)] * world
+    cum = np.cumsum(cost)
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(max(cuts[-1], min(n, int(np.searchsorted(cum, cum[-1] * r / world, side="left")) + 1)))
+    cuts.append(n)
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
+def balanced_column_shards(var_adv, var_lk, world, msm_share=0.28):
+    """Like column_shards, but the blocks equalise estimated time instead of column count: every column costs one unit
+    (NTT, layout, bucket reduction) plus `msm_share` units per mean-column's worth of MSM entries (the non-zero signed
+    window digits of its non-constant cells: what its commitment sorts and accumulates; the share is the measured ratio
+    of those two groups of kernels: ~9 us of accumulate / combine per mean column against ~33 us of NTT, sort and
+    bucket reduction).  Witness columns differ a lot here (input and indicator columns are
+    nearly empty, fixed-point columns hold 100-bit values), which is what skews equal-count blocks."""
+    var_adv = np.asarray(var_adv, dtype=np.float64)
+    var_lk = np.asarray(var_lk, dtype=np.float64)
+    mean = max(1.0, (var_adv.sum() + var_lk.sum()) / max(1, len(var_adv) + len(var_lk)))
+    adv = balanced_ranges(1.0 + msm_share * var_adv / mean, world)
+    lk = balanced_ranges(1.0 + msm_share * var_lk / mean, world)
+    return list(zip(adv, lk))
+
+
+def gather_commitments(dist, local, shards, device):
     """The one real exchange step of the path: all_gather of the 64-byte commitments of every rank's column
-    shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64, [advice block | lookup block].
-    Returns (n_adv + n_lk, 8) in the unsharded order [all advice | all lookup]."""
+    shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64, [advice block | lookup block];
+    `shards`: the per-rank ((a_lo, a_hi), (l_lo, l_hi)) list every rank derived identically (column_shards /
+    balanced_column_shards).  Returns (n_adv + n_lk, 8) in the unsharded order [all advice | all lookup]."""
     import torch
-    shards = column_shards(n_adv, n_lk, world)
+    world = len(shards)
     counts = [(a[1] - a[0]) + (l[1] - l[0]) for a, l in shards]
     mx = max(counts)
     mine = torch.zeros((mx, 8), dtype=torch.int64, device=device)
@@ -81,6 +112,7 @@ class KmeansHotPath:
         self.tau = tau
         self.factor_constants = True
         self.shard_witness = True   # generate only the witness cells this rank's columns hold (values are computed everywhere)
+        self.balance_shards = True  # equalise estimated time per rank instead of column count
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self):
@@ -114,8 +146,36 @@ class KmeansHotPath:
         max_rows = self.rows - MINIMUM_ROWS
         self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
         self.n_cols = self.n_adv_cols + self.n_lk_cols
+        from_ints = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        tau = from_ints([self.tau * (1 << 256) % R])[0]
+        g, gl = api.srs_setup_unsafe(self.k, tau)
+        self.g_lagrange = gl
+        self.srs = api.Srs(self.k, None, gl)
         # column sharding over ranks: a block of the advice columns and a block of the lookup columns each
-        (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = column_shards(self.n_adv_cols, self.n_lk_cols, self.world)[self.rank]
+        self.shards = column_shards(self.n_adv_cols, self.n_lk_cols, self.world)
+        if self.world > 1 and self.balance_shards:
+            # keygen-time statistics of the layout just produced (every rank computes the same numbers)
+            n_el = self.n_adv_cols * self.rows
+            d_tmpm = api.DeviceBuffer(n_el)
+            check(lib.vdb_layout_const_mask_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k, d_tmpm.ptr))
+            d_tmpc = api.DeviceBuffer(max(self.n_adv_cols, self.n_lk_cols, 1) * self.rows * B)
+            check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                             d_tmpc.ptr, None, 0))
+            var_adv = np.zeros(self.n_adv_cols, dtype=np.uint64)
+            check(lib.vdb_msm_count_entries_dev(self.srs.h, d_tmpc.ptr, ctypes.c_size_t(self.n_adv_cols), ctypes.c_size_t(self.rows), d_tmpm.ptr,
+                                                api._p(var_adv)))
+            var_lk = np.zeros(max(self.n_lk_cols, 1), dtype=np.uint64)
+            if self.n_lk_cols:
+                check(lib.vdb_layout_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, d_tmpc.ptr,
+                                                ctypes.c_uint64(self.n_lk_cols), None, 0))
+                check(lib.vdb_msm_count_entries_dev(self.srs.h, d_tmpc.ptr, ctypes.c_size_t(self.n_lk_cols), ctypes.c_size_t(self.rows), None,
+                                                    api._p(var_lk)))
+            d_tmpm.free()
+            d_tmpc.free()
+            self.msm_entries = (var_adv, var_lk[: self.n_lk_cols])
+            self.shards = balanced_column_shards(var_adv, var_lk[: self.n_lk_cols], self.world)
+        (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = self.shards[self.rank]
         self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
         self.my_cols = self.my_adv + self.my_lk
         # the stretch of the flat stream / lookup stream those columns hold (column c = stream[starts[c] : starts[c] + bp[c] + 1])
@@ -127,8 +187,6 @@ class KmeansHotPath:
             self.win_adv = (0, 0)
         self.win_lk = (self.l_lo * max_rows, min(self.l_hi * max_rows, self.n_lookup)) if self.my_lk else (0, 0)
         rng = np.random.default_rng(self.seed + 7)
-        from_ints = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
-        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
         raw = rng.integers(0, 1 << 62, size=(self.n_cols * N_BLIND, 4), dtype=np.int64).astype(object)
         blind = from_ints([(int(r[0]) | int(r[1]) << 62 | int(r[2]) << 124 | int(r[3]) << 186) % R for r in raw])
         self.blind = blind  # treated as Montgomery representatives: any value < r is a valid field element
@@ -136,10 +194,6 @@ class KmeansHotPath:
         self.d_blind.upload(blind)
         self.d_cols = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * B)
         self.d_ext = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * 4 * B)
-        tau = from_ints([self.tau * (1 << 256) % R])[0]
-        g, gl = api.srs_setup_unsafe(self.k, tau)
-        self.g_lagrange = gl
-        self.srs = api.Srs(self.k, None, gl)
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
         # (lookup columns hold no constants: their mask stays zero and their constant point is the identity)

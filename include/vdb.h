@@ -169,6 +169,11 @@ int vdb_msm(const vdb_srs *srs, int basis, const vdb_fr *scalars, size_t n, vdb_
 int vdb_msm_batch(const vdb_srs *srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
 /* scalars_dev: contiguous n_cols x n in HBM; out_host: n_cols points */
 int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, vdb_g1 *out_host);
+/* per column: the number of (scalar, window) entries vdb_msm_batch[_masked]_dev would sort and accumulate for it (non-zero
+ * signed digits of the cells not flagged in skip_mask_dev, which may be NULL).  A keygen-time statistic used to balance
+ * column shards across GPUs.  counts_out: host, n_cols values. */
+int vdb_msm_count_entries_dev(const vdb_srs *srs, const vdb_fr *scalars_dev, size_t n_cols, size_t n, const uint8_t *skip_mask_dev,
+                              uint64_t *counts_out);
 /* Prover-side commit with the constant cells factored out: cells flagged in skip_mask_dev (n_cols x n bytes, from
  * vdb_layout_const_mask_dev) are skipped and const_points_dev[col] — the keygen-time MSM of exactly those cells
  * (vdb_mask_select_dev(keep_const = 1) + vdb_msm_batch_dev) — is added.  Same group element as vdb_msm_batch_dev. */

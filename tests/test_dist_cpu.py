@@ -17,7 +17,7 @@ def _worker(rank, world, port, n_adv, n_lk, q):
     (a_lo, a_hi), (l_lo, l_hi) = column_shards(n_adv, n_lk, world)[rank]
     mine = list(range(a_lo, a_hi)) + [n_adv + c for c in range(l_lo, l_hi)]     # global column numbers, buffer order
     local = (np.array(mine, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :]) * np.uint64(0x9E3779B97F4A7C15)
-    out = gather_commitments(dist, local.reshape(len(mine), 8), n_adv, n_lk, rank, world, "cpu")
+    out = gather_commitments(dist, local.reshape(len(mine), 8), column_shards(n_adv, n_lk, world), "cpu")
     q.put((rank, mine, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -57,3 +57,21 @@ def test_shard_ranges_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_shards_partition_and_balance():
+    from halo2_vectordb_amd.pipeline import balanced_column_shards, balanced_ranges
+    rng = np.random.default_rng(3)
+    for n_adv, n_lk, w in ((1, 0, 2), (7, 3, 2), (100, 17, 3), (6801, 1345, 8)):
+        va = rng.integers(0, 65536, n_adv) * (rng.random(n_adv) > 0.2)   # some nearly empty columns
+        vl = rng.integers(60000, 65536, n_lk)
+        shards = balanced_column_shards(va, vl, w)
+        assert len(shards) == w
+        for which, n in ((0, n_adv), (1, n_lk)):
+            spans = [s[which] for s in shards]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(spans, spans[1:]))
+    cost = np.r_[np.ones(500), 3 * np.ones(500)]
+    spans = balanced_ranges(cost, 4)
+    sums = [cost[a:b].sum() for a, b in spans]
+    assert max(sums) - min(sums) <= 3.0 + 1e-9

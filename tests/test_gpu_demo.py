@@ -1,0 +1,135 @@
+"""GPU counterpart of the reference's end-to-end demo test (tests/demo_test.rs:13-56, tests/demo/mod.rs:38-91):
+
+    DemoZKDB::new  = chip_kmeans  +  Merkle roots of the database, the centroids and every cluster
+    DemoZKDB::ann  = chip_nearest_vector over the centroids (root must equal the stored centroids root)
+                     -> select the cluster -> chip_nearest_vector inside it (root must equal that cluster's root)
+
+compared with the f64 DemoDB (tests/demo/mod.rs:6-36, tests/vectordb/mod.rs:31-91, 202-218) at the reference's
+tolerance (relative 1e-6), with exact cluster ids / indices.  Everything chip-side runs through the C ABI on the GPU
+(vdb_wit_kmeans / vdb_wit_nearest / vdb_wit_merkle); the oracle is used only to cross-check the GPU's cells bit for bit.
+Inputs are seeded (the reference's are not) and avoid ties so that "first minimum" is unambiguous in f64 and fixed point.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, L = 48, 13  # tests/vectordb/mod.rs:3-4
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init(0)
+    return a
+
+
+def euclid(a, b):
+    return float(np.sqrt(((a - b) ** 2).sum()))
+
+
+def f64_kmeans(vectors, K, I):
+    """tests/vectordb/mod.rs:31-91"""
+    cent = [v.copy() for v in vectors[:K]]
+    ids = [0] * len(vectors)
+    for _ in range(I):
+        sizes = [0] * K
+        for i, v in enumerate(vectors):
+            d = [euclid(v, c) for c in cent]
+            ids[i] = d.index(min(d))
+            sizes[ids[i]] += 1
+        for k in range(K):
+            mean = np.zeros(vectors.shape[1])
+            for i, v in enumerate(vectors):
+                if ids[i] == k:
+                    mean += v
+            cent[k] = mean / sizes[k]
+    return cent, ids
+
+
+def f64_nearest(q, vectors):
+    d = [euclid(v, q) for v in vectors]
+    i = d.index(min(d))
+    return i, vectors[i]
+
+
+def rel_close(a, b, eps=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= eps * np.maximum(np.abs(a), np.abs(b)) + 1e-300))
+
+
+class GpuDemoZKDB:
+    def __init__(self, api, O, database, K, I):
+        self.api, self.O, self.db = api, O, database
+        self.qdb = api.quantize(database, P)
+        km = api.wit_kmeans("euclidean", self.qdb, K, I, P=P, L=L)
+        # the same cells as the CPU restatement, bit for bit
+        c = O.Ctx(store=True)
+        c.kmeans("euclidean", self.qdb, K, I, P=P, L=L)
+        assert np.array_equal(km["stream"], c.advice())
+        self.centroids_q = km["centroids"]
+        self.centroids = api.dequantize(km["centroids"].reshape(-1, 4), P).reshape(K, -1)
+        ind = api.dequantize(km["indicators"].reshape(-1, 4), P).reshape(len(database), K)
+        # chip_kmeans: "the first index that has 1 is the cluster id" (tests/vectordb/mod.rs:121-132)
+        self.cluster_ids = [int(np.argmax(row == 1.0)) for row in ind]
+        assert all(row[i] == 1.0 for row, i in zip(ind, self.cluster_ids))
+        self.database_root = api.wit_merkle(self.qdb)["root"]
+        self.centroids_root = api.wit_merkle(api.quantize(self.centroids, P))["root"]
+        self.cluster_roots = [api.wit_merkle(api.quantize(self.cluster(k), P))["root"] for k in range(K)]
+
+    def cluster(self, k):
+        return self.db[[i for i, c in enumerate(self.cluster_ids) if c == k]]
+
+    def chip_nearest(self, q, vectors):
+        qq, qv = self.api.quantize(q.reshape(1, -1), P)[0], self.api.quantize(vectors, P)
+        nv = self.api.wit_nearest("euclidean", qq, qv, P=P, L=L)
+        one = self.O.fr_from_ints([1])[0]
+        idx = [i for i in range(len(vectors)) if np.array_equal(nv["indicator"][i], one)]   # compare_fields(v, F::one())
+        assert len(idx) >= 1
+        return idx[0], self.api.dequantize(nv["result"], P), self.api.wit_merkle(qv)["root"]
+
+    def ann(self, q):
+        cid, _, croot = self.chip_nearest(q, self.centroids)
+        assert np.array_equal(croot, self.centroids_root), "centroid roots do not match"
+        _, res, root = self.chip_nearest(q, self.cluster(cid))
+        assert np.array_equal(root, self.cluster_roots[cid]), "cluster roots do not match"
+        return res
+
+
+@pytest.mark.parametrize("dim,n,K,I,seed", [(4, 4, 2, 4, 1), (4, 12, 3, 3, 2), (16, 40, 4, 4, 3)])
+def test_demo_pipeline(api, O, dim, n, K, I, seed):
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        db = rng.random((n, dim))
+        cent, ids = f64_kmeans(db, K, I)
+        if len(set(ids)) == K:          # every cluster non-empty (the reference's f64 code divides by the size)
+            break
+    zk = GpuDemoZKDB(api, O, db, K, I)
+    assert zk.cluster_ids == ids
+    assert rel_close(zk.centroids, np.array(cent))
+    for _ in range(3):
+        q = rng.random(dim)
+        cid, _ = f64_nearest(q, np.array(cent))
+        _, want = f64_nearest(q, db[[i for i, c in enumerate(ids) if c == cid]])
+        assert rel_close(zk.ann(q), want)
+    # roots are self-consistent field elements and the database root depends on the data
+    assert not np.array_equal(zk.database_root, zk.centroids_root)
+    assert np.array_equal(api.wit_merkle(zk.qdb)["root"], zk.database_root)
+
+
+def test_siftsmall_shaped_pipeline(api, O, tmp_path):
+    """tests/demo_test.rs:59-88 (first 10 base vectors, query #1, K=2, I=1) on a synthetic SIFT-shaped .fvecs file:
+    the real siftsmall dataset is not part of the reference repository."""
+    from halo2_vectordb_amd.io import read_fvecs, write_fvecs
+    rng = np.random.default_rng(20260005)
+    write_fvecs(tmp_path / "base.fvecs", rng.integers(0, 219, size=(25, 128)))
+    write_fvecs(tmp_path / "query.fvecs", rng.integers(0, 219, size=(3, 128)))
+    db = read_fvecs(tmp_path / "base.fvecs", count=10, dim=128)
+    q = read_fvecs(tmp_path / "query.fvecs", count=1, dim=128)[0]
+    cent, ids = f64_kmeans(db, 2, 1)
+    assert len(set(ids)) == 2
+    zk = GpuDemoZKDB(api, O, db, 2, 1)
+    assert zk.cluster_ids == ids and rel_close(zk.centroids, np.array(cent))
+    cid, _ = f64_nearest(q, np.array(cent))
+    _, want = f64_nearest(q, db[[i for i, c in enumerate(ids) if c == cid]])
+    assert rel_close(zk.ann(q), want)

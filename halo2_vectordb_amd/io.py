@@ -43,3 +43,48 @@ def write_fvecs(path, vectors):
         for row in v:
             f.write(struct.pack("<I", len(row)))
             f.write(row.tobytes())
+
+
+# ---------------------------------------------------------------- example inputs (data/*.in)
+def load_input(path):
+    """`data/{name}.in` of the reference's examples (serde_json of the example's `CircuitInput`): a JSON object whose
+    values are numbers, vectors or lists of vectors.  Returned as numpy float64 arrays keyed like the file
+    (e.g. {"vectors": (n, d)} for kmeans / merkle, {"query": (d,), "database": (n, d)} for query, {"a", "b"} for the
+    distance examples)."""
+    import json
+    with open(path) as f:
+        raw = json.load(f)
+    return {k: np.asarray(v, dtype=np.float64) for k, v in raw.items()}
+
+
+# ---------------------------------------------------------------- pinning file (configs/{name}.json)
+# Keygen writes, Prove reads (src/scaffold/mod.rs:272, 285-287): the circuit shape parameters and the break points of
+# the advice stream.  Layout recalled from snark-verifier-sdk's AggregationConfigPinning (the Pinning type of the
+# scaffold, src/scaffold/mod.rs:436-438) — [UPSTREAM-RECALL, parity unpinned: the reference holds no sample file]:
+#   {"params": {"degree": k, "num_advice": A, "num_lookup_advice": LA, "num_fixed": F, "lookup_bits": L},
+#    "break_points": [[b_0, b_1, ...]]}          (one list per phase; this path has phase 0 only)
+def write_pinning(path, k, break_points, num_lookup_advice, lookup_bits, num_fixed=1):
+    import json
+    bp = [int(b) for b in break_points]
+    doc = {"params": {"degree": int(k), "num_advice": len(bp) + 1, "num_lookup_advice": int(num_lookup_advice), "num_fixed": int(num_fixed),
+                      "lookup_bits": int(lookup_bits)},
+           "break_points": [bp]}
+    with open(path, "w") as f:
+        json.dump(doc, f)
+
+
+def read_pinning(path):
+    """Returns (params dict, break points of phase 0 as uint64 array); checks the invariants the layout relies on."""
+    import json
+    with open(path) as f:
+        doc = json.load(f)
+    params, bps = doc["params"], doc["break_points"]
+    if len(bps) < 1 or any(len(p) for p in bps[1:]):
+        raise ValueError("only phase-0 break points are supported on this path")
+    bp = np.asarray(bps[0], dtype=np.uint64)
+    if params["num_advice"] != len(bp) + 1:
+        raise ValueError("num_advice does not match the number of break points")
+    rows = 1 << int(params["degree"])
+    if len(bp) and int(bp.max()) >= rows:
+        raise ValueError("break point beyond the column height")
+    return params, bp

@@ -115,7 +115,10 @@ class KmeansHotPath:
         self.balance_shards = True  # equalise estimated time per rank instead of column count
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
-    def setup(self):
+    def setup(self, pinning=None):
+        """`pinning`: path of a configs/{name}.json written by an earlier keygen (io.write_pinning); when given, its break
+        points are used as they are — the Prove arm of the reference (src/scaffold/mod.rs:285-287) — after checking that
+        they describe this circuit; otherwise they are derived from the keygen-style run, like the Keygen arm."""
         lib, n, dim, K, I = self.lib, self.n, self.dim, self.K, self.I
         vec, self.seed = sift_like_vectors(self.seed, n, dim, K)
         self.vectors_f64 = vec
@@ -142,6 +145,12 @@ class KmeansHotPath:
         check(lib.vdb_layout_plan_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), self.k, MINIMUM_ROWS, api._p(self.bp), ctypes.c_uint64(self.bp.size),
                                       ctypes.byref(nbp)))
         self.bp = self.bp[:nbp.value]
+        if pinning is not None:
+            from .io import read_pinning
+            params, bp = read_pinning(pinning)
+            if params["degree"] != self.k or params["lookup_bits"] != self.L or not np.array_equal(bp, self.bp):
+                raise ValueError("pinning file does not describe this circuit (degree, lookup_bits or break points differ)")
+            self.bp = bp
         self.n_adv_cols = len(self.bp) + 1
         max_rows = self.rows - MINIMUM_ROWS
         self.n_lk_cols = math.ceil(self.n_lookup / max_rows)
@@ -221,6 +230,11 @@ class KmeansHotPath:
         d_fmask.free()
         api.sync()
         return self
+
+    def write_pinning(self, path):
+        """configs/{name}.json of the Keygen arm (src/scaffold/mod.rs:272)."""
+        from .io import write_pinning
+        write_pinning(path, self.k, self.bp, self.n_lk_cols, self.L)
 
     def set_vectors(self, vectors_f64):
         """Prove for a different database of the same shape (the keygen-time data above stays untouched)."""

@@ -162,3 +162,22 @@ def test_sharded_ranks_reproduce_the_unsharded_job(api, O, world, metric):
         assert np.array_equal(cent, want_cent) and np.array_equal(ind, want_ind)
         hp.free()
     assert np.array_equal(np.concatenate(adv + lk), want_commit)
+
+
+def test_pinning_file_keygen_then_prove(api, O, tmp_path):
+    """Keygen arm writes configs/{name}.json, Prove arm reads it back (src/scaffold/mod.rs:272, 285-287): same break
+    points, same commitments; a pinning of another circuit is refused."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    cfg = dict(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11)
+    keygen = KmeansHotPath(**cfg).setup()
+    pin = tmp_path / "kmeans.json"
+    keygen.write_pinning(pin)
+    want = keygen.step().copy()
+    keygen.free()
+    prove = KmeansHotPath(**cfg).setup(pinning=pin)
+    assert np.array_equal(prove.step(), want)
+    prove.free()
+    other = KmeansHotPath(**dict(cfg, I=1))
+    with pytest.raises(ValueError):
+        other.setup(pinning=pin)
+    other.free()

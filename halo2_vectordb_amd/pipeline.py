@@ -100,8 +100,10 @@ def gather_commitments(dist, local, shards, device):
 class KmeansHotPath:
     """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
 
-    def __init__(self, n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="euclidean", seed=20260004, tau=0x5EED5EED5EED,
+    def __init__(self, n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="euclidean", seed=20260004, tau=None,
                  col_shard=(0, 1)):
+        """`tau`: toxic-waste scalar of the "unsafe" SRS as a canonical integer; None = the scalar the reference's
+        `gen_srs(k)` derives from its fixed ChaCha20 seed (srs.gen_srs_tau, src/scaffold/mod.rs:260)."""
         self.n, self.dim, self.K, self.I, self.k, self.P, self.L = n, dim, K, I, k, P, L
         self.metric = api.METRICS[metric]
         self.metric_name = metric
@@ -157,6 +159,9 @@ class KmeansHotPath:
         self.n_cols = self.n_adv_cols + self.n_lk_cols
         from_ints = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
         R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        if self.tau is None:
+            from .srs import gen_srs_tau
+            self.tau = gen_srs_tau()
         tau = from_ints([self.tau * (1 << 256) % R])[0]
         g, gl = api.srs_setup_unsafe(self.k, tau)
         self.g_lagrange = gl

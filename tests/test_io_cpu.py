@@ -60,3 +60,26 @@ def test_load_example_inputs(tmp_path):
     assert q["query"].shape == (3,) and q["database"].shape == (2, 3)
     d = load_input(tmp_path / "distances.in")
     assert d["a"].tolist() == [0.123, 0.456, 1.789] and d["b"][0] == 1.123
+
+
+def test_chacha20_rng_and_srs_scalar():
+    """rand_chacha::ChaCha20Rng::from_seed([0; 32]) against the RFC 7539 appendix A.1 zero-key keystream (blocks 0 and 1),
+    and the scalar gen_srs derives from it"""
+    from halo2_vectordb_amd.srs import ChaCha20Rng, R_MOD, chacha20_block, fr_random, gen_srs_tau
+    b0 = bytes.fromhex("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                       "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    b1 = bytes.fromhex("9f07e7be5551387a98ba977c732d080dcb0f29a048e3656912c6533e32ee7aed"
+                       "29b721769ce64e43d57133b074d839d531ed1f28510afb45ace10a1f4b794d6f")
+    assert chacha20_block(bytes(32), 0) == b0 and chacha20_block(bytes(32), 1) == b1
+    rng = ChaCha20Rng()
+    assert rng.next_u64() == int.from_bytes(b0[:8], "little")      # rand_chacha: first words 0xade0b876, 0x903df1a0
+    assert rng.next_u64() == int.from_bytes(b0[8:16], "little")
+    tau = gen_srs_tau()
+    assert tau == int.from_bytes(b0, "little") % R_MOD and 0 < tau < R_MOD
+    rng2 = ChaCha20Rng()
+    assert fr_random(rng2) == tau and fr_random(rng2) == int.from_bytes(b1, "little") % R_MOD
+    # RFC 7539 2.3.2 block-function test vector (key 00..1f, counter 1, nonce 000000090000004a00000000)
+    key = bytes(range(32))
+    nonce_as_stream = int.from_bytes(bytes.fromhex("0000004a00000000"), "little")
+    blk = chacha20_block(key, 1 | (0x09000000 << 32), nonce_as_stream)
+    assert blk[:16].hex() == "10f1e7e4d13b5915500fdd1fa32071c4"

@@ -93,7 +93,8 @@ __device__ __forceinline__ void lds_put(const L9Planes& P, uint32_t idx, const L
 // multiplier inputs stay below 6 * 2^29 per limb and nothing reaches 2^32.  Values stay below 22 r over ten stages.
 template <bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict__ in, u256* __restrict__ out,
-                                                         const u256* __restrict__ tw, NttPass p, uint32_t tiles_per_col) {
+                                                         const u256* __restrict__ tw, const u256* __restrict__ tw_inter, NttPass p,
+                                                         uint32_t tiles_per_col) {
   extern __shared__ uint4 smem[];
   const uint32_t S = p.S, m = 1u << S, G = 1u << p.logG, T = m * G;
   const uint32_t row = m + 1, NE = G * row, NW = m / 2 ? m / 2 : 1;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       const uint32_t e = tid + it * NTT_THREADS;
       const uint32_t g = e & (G - 1), q = e >> p.logG;
       const uint64_t ex = ((uint64_t)q * ((uint64_t)i0 + g)) << (p.log_n - S - p.log_inner);
-      if (e < T) twv[it] = ld256(tw + ex);
+      if (e < T) twv[it] = ld256(tw_inter + ex);
     }
   }
 #pragma unroll
@@ -263,7 +264,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     l9_renorm(v);
     if (!LAST) {
       v = l9_mul(v, l9_split(twv[it]));
-      st256(cout + base + (uint64_t)q * jstride + g, l9_canon(v));
+      // below 1.2 r and exactly normalised: stored without the final conditional subtraction (the next pass only needs
+      // normalised limbs below 1.9 r)
+      st256(cout + base + (uint64_t)q * jstride + g, l9_pack(v));
     } else {
       uint64_t pos;
       if (p.nprev == 0) {
@@ -300,9 +303,11 @@ __global__ __launch_bounds__(256) void k_twiddles(u256* __restrict__ tw, u256 om
   }
 }
 
-static const u256* get_twiddles(uint32_t log_n, const u256& omega, int* err) {
+// `factor`: what every entry is multiplied by — 32 (plain table) or 32 / n (`scaled`: the inter-pass table of an inverse
+// transform, which folds the final 1/n into a product that is made anyway)
+static const u256* get_twiddles(uint32_t log_n, const u256& omega, const u256& factor, bool scaled, int* err) {
   Context& c = ctx();
-  Context::TwKey key{log_n, omega};
+  Context::TwKey key{log_n | (scaled ? 0x80000000u : 0u), omega};
   auto it = c.twiddles.find(key);
   if (it != c.twiddles.end()) return it->second;
   uint64_t n = 1ull << log_n;
@@ -316,7 +321,7 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, int* err) {
   uint64_t threads = (n + chunk - 1) / chunk;
   {
     VDB_PROF("k_twiddles");
-    hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, host_fr_from_u64(32), n, chunk);
+    hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, tw, omega, factor, n, chunk);
   }
   e = hipGetLastError();
   if (e != hipSuccess) {
@@ -347,7 +352,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     return VDB_ERR_ARG;
   }
   int err = VDB_OK;
-  const u256* tw = get_twiddles(log_n, omega, &err);
+  const u256 m32 = host_fr_from_u64(32);
+  const u256* tw = get_twiddles(log_n, omega, m32, false, &err);
   if (!tw) return err;
 
   // pass sizes
@@ -361,8 +367,14 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     L = (log_n + ms - 1) / ms;  // passes of up to 512 points: 2^16 = 256 x 256, 2^18 = 512 x 512
     for (uint32_t l = 0; l < L; l++) S[l] = log_n / L + (l < log_n % L ? 1 : 0);
   }
-  const u256 m32 = host_fr_from_u64(32);
   const u256 fin = scale_ninv ? fr_mul(mont_inv<Fr>(host_fr_from_u64(n)), m32) : m32;
+  // multi-pass inverse transforms take 1/n with the inter-pass twiddles of pass 0; their last pass then ends like a
+  // forward transform's, without a product
+  const u256* tw_scaled = tw;
+  if (scale_ninv && L > 1) {
+    tw_scaled = get_twiddles(log_n, omega, fin, true, &err);
+    if (!tw_scaled) return err;
+  }
   u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
   z1 = fr_mul(z1, m32);
   z2 = fr_mul(z2, m32);
@@ -397,7 +409,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.fin = fin;
       memcpy(p.ckp, ckp, sizeof(ckp));
       bool last = (l == L - 1);
-      p.scale = last && scale_ninv;
+      p.scale = last && scale_ninv && L == 1;
       // zero-padded input (coeff_to_extended): when rows of pass 0 run along the top digit and only their first
       // quarter is data, stages 0 and 1 are pure replication
       p.s0 = (l == 0 && !last && S[0] >= 3 && in_len * 4 <= n) ? 2 : 0;
@@ -474,12 +486,12 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       if (last) {
         {
           VDB_PROF("k_ntt_pass");
-          hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+          hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
         }
       } else {
         {
           VDB_PROF("k_ntt_pass");
-          hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, p, tiles);
+          hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, l == 0 ? tw_scaled : tw, p, tiles);
         }
       }
       VDB_LAUNCH_CHECK();

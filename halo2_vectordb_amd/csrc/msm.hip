@@ -89,15 +89,13 @@ __device__ __forceinline__ bool fold_scalar(u256& s) {
   return false;
 }
 
+// signed window digits of a folded magnitude s (nb = its bit length): f(window, |digit|, negative)
 template <class F>
-__device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t c, uint32_t W, F&& f) {
-  if (u256_is_zero(mont_scalar)) return;  // Montgomery form of zero is zero: skip the product for the ~1/3 zero cells
-  u256 s = from_mont<Fr>(mont_scalar);
-  bool neg = fold_scalar(s);
+__device__ __forceinline__ void emit_digits(u256 s, bool neg, uint32_t nb, uint32_t c, uint32_t W, F&& f, size_t idx = 0) {
   uint32_t carry = 0;
   const uint32_t half = 1u << (c - 1), full = 1u << c;
   // witness scalars are mostly short: stop after the window that can still receive a carry
-  uint32_t wend = u256_bits(s) / c + 2;
+  uint32_t wend = nb / c + 2;
   if (wend > W) wend = W;
   for (uint32_t j = 0; j < wend; j++) {
     uint32_t d = (s.w[0] & (full - 1)) + carry;
@@ -110,7 +108,95 @@ __device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t
     } else {
       carry = 0;
     }
-    if (d) f(j, d, neg != dneg);
+    if (d) f(j, d, neg != dneg, idx);
+  }
+}
+template <class F>
+__device__ __forceinline__ void for_each_digit(const u256& mont_scalar, uint32_t c, uint32_t W, F&& f) {
+  if (u256_is_zero(mont_scalar)) return;  // Montgomery form of zero is zero: skip the product for the ~1/3 zero cells
+  u256 s = from_mont<Fr>(mont_scalar);
+  bool neg = fold_scalar(s);
+  emit_digits(s, neg, u256_bits(s), c, W, [&](uint32_t j, uint32_t d, bool ng, size_t) { f(j, d, ng); });
+}
+// same for a magnitude below 2^32
+template <class F>
+__device__ __forceinline__ void emit_digits32(uint32_t mag, bool neg, uint32_t nb, uint32_t c, uint32_t W, F&& f, size_t idx) {
+  uint32_t carry = 0;
+  const uint32_t half = 1u << (c - 1), full = 1u << c;
+  uint32_t wend = nb / c + 2;
+  if (wend > W) wend = W;
+  for (uint32_t j = 0; j < wend; j++) {
+    uint32_t d = (mag & (full - 1)) + carry;
+    mag >>= c;
+    bool dneg = false;
+    if (d > half) {
+      d = full - d;
+      dneg = true;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    if (d) f(j, d, neg != dneg, idx);
+  }
+}
+// Two-speed, two-pass walk over a column's scalars (the counting sort visits them twice: histogram, then scatter).
+// Every lane of a wavefront pays for the longest path among its 64 scalars, and witness columns mix a majority of short
+// values (bits, 15-bit limbs) with ~100-bit fixed-point values.  First visit (`first`): the Montgomery reduction, sign
+// fold and bit length are computed once; a short scalar (magnitude below 2^32 and at most three windows) leaves an
+// 8-byte record {magnitude, sign, length} and is processed from registers; a long one is appended to a queue
+// (wavefront-aggregated) and all long ones are then processed densely, every lane holding one.  Second visit: the short
+// scalars come straight from their records (no 32-byte load, no field arithmetic), the long ones from the queue.
+// `queue`, `rec`: n entries of this column each.
+#define MSM_REC_VALID (1ull << 63)
+template <class F>
+__device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const uint8_t* __restrict__ mk, size_t n, uint32_t c, uint32_t W,
+                                             uint32_t* __restrict__ queue, unsigned long long* __restrict__ rec, uint32_t* s_qcnt, bool first, F&& f) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t short_bits = 3 * c - 1 < 32 ? 3 * c - 1 : 32;
+  if (first) {
+    if (tid == 0) *s_qcnt = 0;
+    __syncthreads();
+    for (size_t i0 = 0; i0 < n; i0 += MSM_SORT_THREADS) {
+      const size_t i = i0 + tid;
+      bool live = i < n && !(mk && mk[i]);  // masked: constant cell, its term is part of the precomputed per-column point
+      u256 s;
+      bool neg = false;
+      uint32_t nb = 0;
+      if (live) {
+        s = ld256(sc + i);
+        live = !u256_is_zero(s);  // Montgomery form of zero is zero: no reduction for the ~1/3 zero cells
+      }
+      if (live) {
+        s = from_mont<Fr>(s);
+        neg = fold_scalar(s);
+        nb = u256_bits(s);
+      }
+      const bool is_long = live && nb > short_bits;
+      const unsigned long long m = __ballot(is_long);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(s_qcnt, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (is_long) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      }
+      const bool is_short = live && !is_long;
+      if (i < n) rec[i] = is_short ? (MSM_REC_VALID | ((unsigned long long)nb << 40) | ((unsigned long long)(neg ? 1 : 0) << 32) | s.w[0]) : 0ull;
+      if (is_short) emit_digits32(s.w[0], neg, nb, c, W, f, i);
+    }
+  } else {
+    for (size_t i0 = 0; i0 < n; i0 += MSM_SORT_THREADS) {
+      const size_t i = i0 + tid;
+      const unsigned long long r = i < n ? rec[i] : 0ull;
+      if (r & MSM_REC_VALID) emit_digits32((uint32_t)r, ((r >> 32) & 1) != 0, (uint32_t)(r >> 40) & 0xffu, c, W, f, i);
+    }
+  }
+  __syncthreads();  // queue complete (written and read by this workgroup only)
+  const uint32_t nq = *s_qcnt;
+  for (uint32_t qi = tid; qi < nq; qi += MSM_SORT_THREADS) {
+    const size_t i = queue[qi];
+    u256 s = from_mont<Fr>(ld256(sc + i));
+    const bool neg = fold_scalar(s);
+    emit_digits(s, neg, u256_bits(s), c, W, f, i);
   }
 }
 
@@ -166,23 +252,24 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
                                                                uint32_t* __restrict__ counters /* [0]=segments, [1]=overflow, [2]=max segs/bucket, [3]=ranges */,
                                                                uint32_t seg_cap, uint32_t range_cap,
                                                                const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg,
-                                                               uint32_t lcap /* range length, a power of two */) {
+                                                               uint32_t lcap /* range length, a power of two */,
+                                                               uint32_t* __restrict__ longq /* n per column: queue of the long scalars */,
+                                                               unsigned long long* __restrict__ recs /* n per column: short-scalar records */) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
   uint32_t* cursor = sh + B;      // B
   uint32_t* ucnt = sh + 2 * B;    // B
   uint32_t* wave_sums = sh + 3 * B;  // 18
-  __shared__ uint32_t s_base, s_rbase;
+  __shared__ uint32_t s_base, s_rbase, s_qcnt;
   const uint32_t col = blockIdx.x, tid = threadIdx.x;
   const u256* sc = scalars + (size_t)col * n;
   const uint8_t* mk = skip_mask ? skip_mask + (size_t)col * n : nullptr;
   for (uint32_t b = tid; b < B; b += MSM_SORT_THREADS) hist[b] = 0;
   __syncthreads();
-  for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
-    if (mk && mk[i]) continue;  // constant cell: its term is part of the precomputed per-column point
-    for_each_digit(ld256(sc + i), c, W, [&](uint32_t, uint32_t d, bool) { atomicAdd(&hist[d - 1], 1u); });
-  }
+  uint32_t* queue = longq + (size_t)col * n;
+  unsigned long long* rec = recs + (size_t)col * n;
+  walk_scalars(sc, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); });
   __syncthreads();
   if (dbg == 1) return;
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
@@ -275,13 +362,10 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __syncthreads();
   if (dbg == 2) return;
   uint32_t* ent = entries + (size_t)col * ent_cap;
-  for (size_t i = tid; i < n; i += MSM_SORT_THREADS) {
-    if (mk && mk[i]) continue;
-    for_each_digit(ld256(sc + i), c, W, [&](uint32_t j, uint32_t d, bool neg) {
-      uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
-      ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
-    });
-  }
+  walk_scalars(sc, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
+    uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
+    ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
+  });
 }
 
 // ---- accumulation in nine-limb form ------------------------------------------------------------------------------
@@ -611,13 +695,14 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   const size_t seg_cap_col = B + range_cap_col;
   // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
   // thousands of independent column reductions in flight
-  size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ) + MSM_RAW_WORDS * 4) + 2 * (B + 1) * 4;
+  size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ) + MSM_RAW_WORDS * 4) + 2 * (B + 1) * 4 +
+                   n * 12;
   size_t nb = ((size_t)40 << 30) / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;
   if (nb > 4096) nb = 4096;
   if (nb * seg_cap_col > 0x7fffffffull) nb = 0x7fffffffull / seg_cap_col;
-  uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 256);
+  uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 512);
   if (!buf) return VDB_ERR_OOM;
   uint32_t* entries = (uint32_t*)buf;
   XYZZ* partials = (XYZZ*)(buf + nb * ent_cap * 4);
@@ -627,6 +712,8 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   uint32_t* seg_off = (uint32_t*)((uint8_t*)seginfo + nb * seg_cap_col * sizeof(MsmSegInfo));
   uint32_t* bucket_off = seg_off + nb * (B + 1);
   uint32_t* counters = bucket_off + nb * (B + 1);
+  unsigned long long* recs = (unsigned long long*)(((uintptr_t)(counters + 64) + 7) & ~(uintptr_t)7);  // n records per column
+  uint32_t* longq = (uint32_t*)(recs + nb * n);                       // then n queue entries per column
   const uint32_t seg_cap = (uint32_t)(nb * seg_cap_col), range_cap = (uint32_t)(nb * range_cap_col);
   size_t lds = (3 * (size_t)B + 32) * sizeof(uint32_t);
   MsmL9Consts l9k;
@@ -642,7 +729,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       VDB_PROF("k_msm_sort");
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
                        ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
-                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0, lcap);
+                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0, lcap, longq, recs);
     }
     VDB_LAUNCH_CHECK();
     {

@@ -88,6 +88,13 @@ HD L9 l9_mul(const L9& a, const L9& b) {
   mont_core29<M>(r.l, a.l, b.l);
   return r;
 }
+// a * a / 2^261 (+ less than p) for a normalised a (limbs below 2^29 + 8)
+template <class M>
+HD L9 l9_sqr(const L9& a) {
+  L9 r;
+  mont_sqr_core29<M>(r.l, a.l);
+  return r;
+}
 // exactly normalised limbs of a value below 2p -> canonical eight words
 template <class M>
 HD u256 l9_canon(const L9& t) {

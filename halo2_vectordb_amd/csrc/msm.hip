@@ -392,14 +392,14 @@ __device__ __forceinline__ void mdbl_l9(AccL9& acc, bool& ident, const L9& x, co
   const L9 u = l9_add(y, y);               // limbs < 2 * 2^29, value <= 4q
   L9 un = u;
   l9_renorm(un);
-  const L9 v = l9_mul<Fq>(u, un);          // < 1.1 q
+  const L9 v = l9_sqr<Fq>(un);             // < 1.1 q
   const L9 w = l9_mul<Fq>(u, v);           // < 1.03 q
   const L9 sv = l9_mul<Fq>(x, v);          // < 1.01 q
   const L9 xx = l9_mul<Fq>(x, x);          // < 1.01 q
   const L9 m = l9_add(l9_add(xx, xx), xx); // limbs < 3 * 2^29, value < 3.1 q
   L9 mn = m;
   l9_renorm(mn);
-  const L9 mm = l9_mul<Fq>(m, mn);         // < 1.06 q
+  const L9 mm = l9_sqr<Fq>(mn);            // < 1.06 q
   const L9 ns = l9_neg(sv, K.c2);
   L9 x3 = l9_add(l9_add(mm, ns), ns);      // mm - 2 sv + 4q: limbs < 5 * 2^29, value < 5.1 q
   l9_carry(x3);
@@ -436,8 +436,8 @@ __device__ __forceinline__ void madd_l9(AccL9& acc, bool& ident, const Affine& p
   L9 pn = pd, rn = rd;
   l9_renorm(pn);
   l9_renorm(rn);
-  const L9 pp = l9_mul<Fq>(pd, pn);        // < 1.5 q
-  const L9 r2 = l9_mul<Fq>(rd, rn);        // < 1.5 q
+  const L9 pp = l9_sqr<Fq>(pn);            // < 1.5 q
+  const L9 r2 = l9_sqr<Fq>(rn);            // < 1.5 q
   if (l9_is_zero_mod<Fq>(pp)) {            // same x (exact test on the product: q is prime)
     if (l9_is_zero_mod<Fq>(r2)) mdbl_l9(acc, ident, x2, y2, K);  // same point
     else ident = true;                                            // opposite points

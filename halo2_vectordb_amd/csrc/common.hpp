@@ -20,6 +20,13 @@ struct Context {
   bool ready = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  // second stream for the latency-bound tail of a deferred MSM (vdb_msm_batch_masked_dev_begin/_end): its bucket
+  // folding runs beside whatever the caller queues on the main stream next (the NTTs)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_tail = nullptr;
+  bool msm_pending = false;       // a deferred MSM has not been collected yet
+  const void* msm_counters = nullptr;
+  const void* msm_out = nullptr;  // device buffer the deferred MSM writes its points to
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int cu_count = 256;
   // twiddle tables keyed by (log_n, first limb words of omega): tw[e] = omega^e, e < n

@@ -176,6 +176,8 @@ int vdb_init(int device) {
   if (c.ready) vdb_shutdown();
   VDB_HIP(hipSetDevice(device));
   VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  VDB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+  VDB_HIP(hipEventCreateWithFlags(&c.ev_tail, hipEventDisableTiming));
   VDB_HIP(hipEventCreate(&c.ev0));
   VDB_HIP(hipEventCreate(&c.ev1));
   hipDeviceProp_t prop;
@@ -189,6 +191,8 @@ void vdb_shutdown(void) {
   Context& c = ctx();
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
+  (void)hipStreamSynchronize(c.aux);
+  c.msm_pending = false;
   for (auto& kv : c.twiddles) (void)hipFree(kv.second);
   c.twiddles.clear();
   for (int i = 0; i < 6; i++) {
@@ -198,6 +202,8 @@ void vdb_shutdown(void) {
   }
   (void)hipEventDestroy(c.ev0);
   (void)hipEventDestroy(c.ev1);
+  (void)hipEventDestroy(c.ev_tail);
+  (void)hipStreamDestroy(c.aux);
   (void)hipStreamDestroy(c.stream);
   c.ready = false;
 }

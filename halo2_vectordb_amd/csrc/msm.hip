@@ -682,9 +682,17 @@ static uint32_t pick_window(uint32_t k) {
 }
 
 // device-level batched MSM: scalars_dev = n_cols x n (contiguous), out_dev = n_cols affine points
+// `defer_tail`: the bucket folding of the LAST batch (k_msm_combine, k_msm_reduce: short latency-bound launches that
+// leave most of the chip idle) goes to the context's auxiliary stream and the function returns without waiting;
+// msm_collect() joins.  The scalars are no longer read at that point, so the caller may overwrite them (NTT in place).
 int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev, const uint8_t* skip_mask = nullptr,
-                  const Affine* add_points = nullptr) {
+                  const Affine* add_points = nullptr, bool defer_tail = false) {
   Context& cx = ctx();
+  if (g_prof_on) defer_tail = false;  // per-kernel timing serialises on the main stream
+  if (cx.msm_pending) {
+    set_error("msm: a deferred batch has not been collected (vdb_msm_batch_end)");
+    return VDB_ERR_ARG;
+  }
   if (n_cols == 0) return VDB_OK;
   const Affine* table = srs->table[basis];
   const uint32_t c = srs->c, W = srs->W, B = srs->B;
@@ -743,24 +751,56 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       hipLaunchKernelGGL(k_msm_partials, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, raw, partials, counters, seg_cap, l9k.to_std);
     }
     VDB_LAUNCH_CHECK();
+    hipStream_t ts = cx.stream;
+    if (defer_tail && c0 + nc == n_cols) {
+      VDB_HIP(hipEventRecord(cx.ev_tail, cx.stream));
+      VDB_HIP(hipStreamWaitEvent(cx.aux, cx.ev_tail, 0));
+      ts = cx.aux;
+    }
     {
       // at most ceil(log2(max segments per bucket)) passes do work; the rest exit on the device-side maximum
       uint32_t max_nt = (uint32_t)range_cap_col + 1, passes = 0;
       while ((1u << passes) < max_nt) passes++;
       for (uint32_t ps = 0; ps < passes; ps++) {
         VDB_PROF("k_msm_combine");
-        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, cx.stream, partials, seginfo, counters, ps, seg_cap);
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, ts, partials, seginfo, counters, ps, seg_cap);
       }
       VDB_LAUNCH_CHECK();
     }
     {
       VDB_PROF("k_msm_reduce");
-      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, cx.stream, partials, seg_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, ts, partials, seg_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
     }
     VDB_LAUNCH_CHECK();
   }
+  if (defer_tail) {
+    cx.msm_pending = true;
+    cx.msm_counters = counters;
+    return VDB_OK;
+  }
   uint32_t h_counters[2] = {0, 0};
   VDB_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  if (h_counters[1]) {
+    set_error("msm: internal task buffer overflow");
+    return VDB_ERR_HIP;
+  }
+  return VDB_OK;
+}
+
+// joins a deferred batch: both streams drained, overflow flag checked
+int msm_collect() {
+  Context& cx = ctx();
+  if (!cx.msm_pending) return VDB_OK;
+  cx.msm_pending = false;
+  VDB_HIP(hipStreamSynchronize(cx.aux));
+  if (!cx.msm_counters) {  // the batch ran synchronously (profiling): nothing left to check
+    VDB_HIP(hipStreamSynchronize(cx.stream));
+    return VDB_OK;
+  }
+  uint32_t h_counters[2] = {0, 0};
+  VDB_HIP(hipMemcpyAsync(h_counters, cx.msm_counters, sizeof(h_counters), hipMemcpyDeviceToHost, cx.stream));
+  cx.msm_counters = nullptr;
   VDB_HIP(hipStreamSynchronize(cx.stream));
   if (h_counters[1]) {
     set_error("msm: internal task buffer overflow");
@@ -881,6 +921,33 @@ int vdb_msm_count_entries_dev(const vdb_srs* srs, const vdb_fr* scalars_dev, siz
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipMemcpyAsync(counts_out, d, n_cols * sizeof(uint64_t), hipMemcpyDeviceToHost, cx.stream));
   VDB_HIP(hipStreamSynchronize(cx.stream));
+  return VDB_OK;
+}
+int vdb_msm_batch_masked_dev_begin(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev,
+                                   const vdb_g1* const_points_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && scalars_dev && (basis == 0 || basis == 1), "bad argument");
+  VDB_ARG(srs->table[basis], "srs was loaded without this basis");
+  VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size");
+  VDB_ARG((skip_mask_dev == nullptr) == (const_points_dev == nullptr), "mask and constant points go together");
+  if (n_cols == 0) return VDB_OK;
+  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  if (!dout) return VDB_ERR_OOM;
+  ctx().msm_out = dout;
+  int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev), true);
+  if (rc == VDB_OK && !ctx().msm_pending) ctx().msm_pending = true;  // profiling mode ran it synchronously: _end still copies out
+  return rc;
+}
+int vdb_msm_batch_end(vdb_g1* out_host, size_t n_cols) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(out_host || n_cols == 0, "null pointer");
+  int rc = msm_collect();
+  if (rc) return rc;
+  if (n_cols == 0) return VDB_OK;
+  const void* dout = ctx().msm_out;
+  VDB_ARG(dout, "no deferred MSM to collect");
+  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
   return VDB_OK;
 }
 int vdb_msm_batch_masked_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev,

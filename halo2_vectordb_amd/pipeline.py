@@ -62,7 +62,7 @@ def balanced_ranges(cost, world):
     return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
 
 
-def balanced_column_shards(var_adv, var_lk, world, msm_share=0.28):
+def balanced_column_shards(var_adv, var_lk, world, msm_share=0.22):
     """Like column_shards, but the blocks equalise estimated time instead of column count: every column costs one unit
     (NTT, layout, bucket reduction) plus `msm_share` units per mean-column's worth of MSM entries (the non-zero signed
     window digits of its non-constant cells: what its commitment sorts and accumulates; the share is the measured ratio
@@ -293,17 +293,17 @@ class KmeansHotPath:
         self.commitments = np.zeros((self.my_cols, 8), dtype=np.uint64)
 
         def commit():
-            if self.factor_constants:
-                check(lib.vdb_msm_batch_masked_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows),
-                                                   self.d_mask.ptr, self.d_cpts.ptr, api._p(self.commitments)))
-            else:
-                check(lib.vdb_msm_batch_dev(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), api._p(self.commitments)))
+            # the MSM is queued without waiting; the bucket folding of its last batch runs on a second stream beside the NTTs
+            mask = self.d_mask.ptr if self.factor_constants else None
+            cpts = self.d_cpts.ptr if self.factor_constants else None
+            check(lib.vdb_msm_batch_masked_dev_begin(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), mask, cpts))
 
         stage("commit_msm", commit)
 
         def ntt():
             check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
             check(lib.vdb_coeff_to_extended_dev(my, self.d_ext.ptr, ctypes.c_size_t(self.my_cols), self.k, 2))
+            check(lib.vdb_msm_batch_end(api._p(self.commitments), ctypes.c_size_t(self.my_cols)))
 
         stage("ntt", ntt)
         api.sync()

@@ -169,6 +169,13 @@ int vdb_msm(const vdb_srs *srs, int basis, const vdb_fr *scalars, size_t n, vdb_
 int vdb_msm_batch(const vdb_srs *srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
 /* scalars_dev: contiguous n_cols x n in HBM; out_host: n_cols points */
 int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, vdb_g1 *out_host);
+/* Deferred form of vdb_msm_batch[_masked]_dev (mask and constant points may both be NULL): _begin queues the whole MSM and
+ * returns without waiting; the bucket folding of its last batch — short, latency-bound launches — runs on a second
+ * stream, so work queued next (vdb_lagrange_to_coeff_dev / vdb_coeff_to_extended_dev on the same columns: the scalars
+ * are no longer read) overlaps it.  _end waits and copies the n_cols commitments out.  One deferred MSM at a time. */
+int vdb_msm_batch_masked_dev_begin(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, const uint8_t *skip_mask_dev,
+                                   const vdb_g1 *const_points_dev);
+int vdb_msm_batch_end(vdb_g1 *out_host, size_t n_cols);
 /* per column: the number of (scalar, window) entries vdb_msm_batch[_masked]_dev would sort and accumulate for it (non-zero
  * signed digits of the cells not flagged in skip_mask_dev, which may be NULL).  A keygen-time statistic used to balance
  * column shards across GPUs.  counts_out: host, n_cols values. */

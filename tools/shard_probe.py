@@ -9,8 +9,10 @@ from halo2_vectordb_amd import api
 from halo2_vectordb_amd.pipeline import KmeansHotPath
 
 api.init(0)
-for w in (1, 2, 4, 8):
-    for r in sorted({0, w // 2, w - 1}):
+import sys
+worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
+for w in worlds:
+    for r in (range(w) if len(worlds) == 1 else sorted({0, w // 2, w - 1})):
         hp = KmeansHotPath(col_shard=(r, w)).setup()
         hp.step()
         t = {}

@@ -701,14 +701,21 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   while (lcap < MSM_LCAP_MAX && (n_cols * n) / lcap >= ((size_t)1 << 19)) lcap <<= 1;  // keep >= ~2^20 ranges in a large job
   const size_t range_cap_col = (ent_cap + lcap - 1) / lcap;  // worst case: every digit non-zero
   const size_t seg_cap_col = B + range_cap_col;
-  // batch so that the worst-case scratch stays below ~40 GiB of the 288 GB HBM: large batches keep
-  // thousands of independent column reductions in flight
+  // large batches keep thousands of independent column reductions in flight
   size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ) + MSM_RAW_WORDS * 4) + 2 * (B + 1) * 4 +
                    n * 12;
-  size_t nb = ((size_t)40 << 30) / per_col;
+  // budget: half of what is free on the card (counting the slot this buffer already holds), between 8 and 96 GiB —
+  // on a 288 GB MI355X the 8,146 columns of the kmeans k = 16 job go through in ONE batch (76 GB), so the whole
+  // bucket-folding tail can run beside the NTTs (defer_tail)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)80 << 30;
+  size_t budget = (free_b + cx.scratch_bytes[2]) / 2;
+  if (budget < ((size_t)8 << 30)) budget = (size_t)8 << 30;
+  if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+  size_t nb = budget / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;
-  if (nb > 4096) nb = 4096;
+  if (nb > 16384) nb = 16384;
   if (nb * seg_cap_col > 0x7fffffffull) nb = 0x7fffffffull / seg_cap_col;
   uint8_t* buf = (uint8_t*)scratch_get(2, nb * per_col + 512);
   if (!buf) return VDB_ERR_OOM;

@@ -363,7 +363,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     S[0] = log_n;
   } else {
     static const uint32_t max_s = getenv("VDB_NTT_MAX_S") ? (uint32_t)atoi(getenv("VDB_NTT_MAX_S")) : 9u;
-    const uint32_t ms = max_s >= 5 && max_s <= 9 ? max_s : 9u;
+    uint32_t ms = max_s >= 4 && max_s <= 9 ? max_s : 9u;
+    while ((log_n + ms - 1) / ms > NTT_MAX_PASSES) ms++;  // at most NTT_MAX_PASSES digits
     L = (log_n + ms - 1) / ms;  // passes of up to 512 points: 2^16 = 256 x 256, 2^18 = 512 x 512
     for (uint32_t l = 0; l < L; l++) S[l] = log_n / L + (l < log_n % L ? 1 : 0);
   }
@@ -466,6 +467,9 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
         p.nprev = 0;
       } else {
         p.logG = 10 - S[l];  // 1024-element tiles: G = 4 for 256-point, G = 2 for 512-point DFTs
+        // a tile cannot be wider than the digit it is cut from: the inner index of a non-last pass, the first digit of the last
+        const uint32_t room = last ? S[0] : p.log_inner;
+        if (p.logG > room) p.logG = room;
         p.nprev = l;  // only read when last
         for (uint32_t q = 0; q < l && q < NTT_MAX_PASSES; q++) p.prevS[q] = S[q];
       }

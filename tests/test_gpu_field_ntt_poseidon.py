@@ -124,3 +124,32 @@ def test_fr_mul_throughput_report(api):
     rate = api.bench_fr_mul()
     print(f"\nFr Montgomery mul throughput: {rate / 1e9:.1f} G mul/s")
     assert rate > 1e9
+
+
+@pytest.mark.parametrize("max_s", ["4", "5", "6"])
+def test_ntt_small_pass_sizes_in_a_subprocess(max_s):
+    """VDB_NTT_MAX_S (read once per process) forces 3- and 4-digit decompositions at small sizes: the general multi-pass
+    path (middle passes, digit peeling of the output index, tiles narrower than 1024 elements) against the oracle"""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import numpy as np\n"
+        "from halo2_vectordb_amd import api\n"
+        "from oracle import oracle as O\n"
+        "api.init(0)\n"
+        "rng = np.random.default_rng(5)\n"
+        "for k in (9, 11, 13, 16, 17):\n"
+        "    cols = O.random_fr(rng, 2 << k).reshape(2, 1 << k, 4)\n"
+        "    w = O.root_of_unity(k)\n"
+        "    assert np.array_equal(api.ntt_batch(cols, w), O.ntt_batch(cols, w, threads=4)), k\n"
+        "for k in (9, 12):\n"
+        "    cols = O.random_fr(rng, 2 << k).reshape(2, 1 << k, 4)\n"
+        "    wc, we = O.lde_batch(cols, ext=2, threads=4)\n"
+        "    gc = api.lagrange_to_coeff(cols)\n"
+        "    assert np.array_equal(gc, wc) and np.array_equal(api.coeff_to_extended(gc, 2), we), k\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VDB_NTT_MAX_S=max_s, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", script], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

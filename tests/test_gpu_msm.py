@@ -58,6 +58,21 @@ def test_msm_random_and_edges(api, O, k):
     srs.free()
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 12])
+def test_msm_small_and_ragged(api, O, k):
+    """tiny SRS sizes, shorter-than-SRS columns (n < 2^k is allowed), one column, and a wide batch of short columns (the
+    range length is chosen per batch)"""
+    rng = np.random.default_rng(900 + k)
+    n_full = 1 << k
+    g, _ = O.srs_from_tau(k, 0x51EDE + k)
+    srs = api.Srs(k, g, None)
+    for n_cols, n in ((1, n_full), (3, max(1, n_full - 1)), (2, max(1, n_full // 2)), (65 if k <= 6 else 5, n_full)):
+        cols = np.stack([witness_like(O, rng, n) if c % 2 else O.random_fr(rng, n) for c in range(n_cols)])
+        got = api.msm_batch(srs, cols, basis=0)
+        assert np.array_equal(got, O.msm_batch(cols, g[:n], threads=4)), (k, n_cols, n)
+    srs.free()
+
+
 def test_msm_degenerate_bases(api, O):
     """tau = 2 makes many table points coincide (doubling / cancellation paths); identity bases too"""
     k = 8

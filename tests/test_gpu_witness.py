@@ -148,3 +148,33 @@ def test_layout_plan_and_columns(api, O):
     assert np.array_equal(cols, want)
     wantl = O.layout_lookup(c.lookup(), k, lcols.shape[0])
     assert np.array_equal(lcols, wantl)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan"])
+def test_smallest_and_ragged_shapes(api, O, metric):
+    """degenerate shapes through every gadget: one dimension, one database vector, one cluster, a single iteration,
+    dimensions just past a multiple of the head kernel's block (257), an odd database size"""
+    rng = np.random.default_rng(4242)
+    # nearest: one vector, one dimension
+    for n, dim in ((1, 1), (1, 5), (2, 1), (3, 257)):
+        db, q = rng.random((n, dim)) + 0.1, rng.random(dim) + 0.1
+        qq, qdb = O.quantize(q), O.quantize(db)
+        got = api.wit_nearest(metric, qq, qdb, selectors=True)
+        c = O.Ctx(store=True, keygen=True)
+        ind, res = c.nearest_vector(metric, qq, qdb)
+        assert np.array_equal(got["indicator"], ind) and np.array_equal(got["result"], res), (n, dim)
+        assert_streams(got, c)
+    # kmeans: a single cluster, a single iteration, one dimension
+    for n, dim, K, I in ((2, 1, 1, 1), (3, 2, 1, 2), (5, 1, 2, 1), (7, 129, 3, 1)):
+        v = rng.random((n, dim)) + 0.05
+        qv = O.quantize(v)
+        c = O.Ctx(store=True, keygen=True)
+        cent, ind = c.kmeans(metric, qv, K, I)
+        if c.err:   # e.g. cosine in one dimension: every vector is at distance 0 of the first centroid, the others stay empty
+            with pytest.raises(api.VdbError) as e:   # the reference panics on the division by the empty cluster's size
+                api.wit_kmeans(metric, qv, K, I, selectors=True)
+            assert e.value.code == -5
+            continue
+        got = api.wit_kmeans(metric, qv, K, I, selectors=True)
+        assert np.array_equal(got["centroids"], cent) and np.array_equal(got["indicators"], ind), (n, dim, K, I)
+        assert_streams(got, c)

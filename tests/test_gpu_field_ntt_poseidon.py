@@ -153,3 +153,15 @@ def test_ntt_small_pass_sizes_in_a_subprocess(max_s):
     env = dict(os.environ, VDB_NTT_MAX_S=max_s, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", script], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_lde_k18_maximum_config_size(api, O):
+    """BASELINE configs[4] works at 2^18 rows: lagrange_to_coeff (2 passes) and coeff_to_extended to 2^20 (3 passes, the
+    zero-padded first pass skipping its two replication stages) against the oracle, one column"""
+    rng = np.random.default_rng(1818)
+    k = 18
+    cols = O.random_fr(rng, 1 << k).reshape(1, 1 << k, 4)
+    want_c, want_e = O.lde_batch(cols, ext=2, threads=4)
+    got_c = api.lagrange_to_coeff(cols)
+    assert np.array_equal(got_c, want_c)
+    assert np.array_equal(api.coeff_to_extended(got_c, 2), want_e)

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "vdb_mask_select_dev": [_P, _P, _U64, _I, _P],
     "vdb_msm_count_entries_dev": [_P, _P, _SZ, _SZ, _P, _P],
     "vdb_msm_batch_masked_dev_begin": [_P, _I, _P, _SZ, _SZ, _P, _P], "vdb_msm_batch_end": [_P, _SZ],
+    "vdb_colsrc_build_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _U32, _P],
+    "vdb_colsrc_build_lookup_dev": [_P, _U64, _U32, _U32, _U64, _U64, _P, _U32, _P],
+    "vdb_msm_batch_src_dev_begin": [_P, _I, _P, _SZ, _SZ, _U32, _P, _P], "vdb_lagrange_to_coeff_src_dev": [_P, _P, _SZ, _U32, _U32],
     "vdb_ntt_batch": [_P, _SZ, _U32, _P, _I], "vdb_ntt_batch_dev": [_P, _SZ, _U32, _P, _I],
     "vdb_lagrange_to_coeff": [_P, _SZ, _U32], "vdb_lagrange_to_coeff_dev": [_P, _SZ, _U32],
     "vdb_coeff_to_extended": [_P, _P, _SZ, _U32, _U32], "vdb_coeff_to_extended_dev": [_P, _P, _SZ, _U32, _U32],

@@ -74,6 +74,18 @@ void* scratch_get(int slot, size_t bytes);
 
 #define VDB_LAUNCH_CHECK() VDB_HIP(hipGetLastError())
 
+// A column that has not been materialised: rows [0, len) are the contiguous cells src[0 .. len) of a witness stream,
+// the last n_blind rows come from `blind` (when given), everything else is zero.  Same layout as the C ABI's vdb_colsrc.
+struct ColSrc {
+  const u256* src;
+  uint64_t len;
+  const u256* blind;
+};
+__device__ __forceinline__ u256 colsrc_fetch(const ColSrc& cs, uint64_t i, uint64_t n, uint32_t n_blind) {
+  if (i < cs.len) return ld256(cs.src + i);
+  if (cs.blind && i >= n - n_blind) return ld256(cs.blind + (i - (n - n_blind)));
+  return u256_zero();
+}
 static inline const u256* as_u256(const vdb_fr* p) { return reinterpret_cast<const u256*>(p); }
 static inline u256* as_u256(vdb_fr* p) { return reinterpret_cast<u256*>(p); }
 
@@ -116,6 +128,6 @@ u256 host_fr_from_u64(uint64_t v);
 
 // internal device-level entry points shared between translation units (all on ctx().stream)
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len);
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind);
 
 }  // namespace vdb

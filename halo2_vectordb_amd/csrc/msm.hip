@@ -148,9 +148,13 @@ __device__ __forceinline__ void emit_digits32(uint32_t mag, bool neg, uint32_t n
 // scalars come straight from their records (no 32-byte load, no field arithmetic), the long ones from the queue.
 // `queue`, `rec`: n entries of this column each.
 #define MSM_REC_VALID (1ull << 63)
+// `sc` (a materialised column) or `cs` (a column still lying in the witness stream, see ColSrc) supplies the scalars.
 template <class F>
-__device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const uint8_t* __restrict__ mk, size_t n, uint32_t c, uint32_t W,
-                                             uint32_t* __restrict__ queue, unsigned long long* __restrict__ rec, uint32_t* s_qcnt, bool first, F&& f) {
+__device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const ColSrc* __restrict__ cs, uint32_t n_blind, const uint8_t* __restrict__ mk,
+                                             size_t n, uint32_t c, uint32_t W, uint32_t* __restrict__ queue, unsigned long long* __restrict__ rec,
+                                             uint32_t* s_qcnt, bool first, F&& f) {
+  ColSrc src;
+  if (cs) src = *cs;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t short_bits = 3 * c - 1 < 32 ? 3 * c - 1 : 32;
   if (first) {
@@ -163,7 +167,7 @@ __device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const 
       bool neg = false;
       uint32_t nb = 0;
       if (live) {
-        s = ld256(sc + i);
+        s = cs ? colsrc_fetch(src, i, n, n_blind) : ld256(sc + i);
         live = !u256_is_zero(s);  // Montgomery form of zero is zero: no reduction for the ~1/3 zero cells
       }
       if (live) {
@@ -194,7 +198,7 @@ __device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const 
   const uint32_t nq = *s_qcnt;
   for (uint32_t qi = tid; qi < nq; qi += MSM_SORT_THREADS) {
     const size_t i = queue[qi];
-    u256 s = from_mont<Fr>(ld256(sc + i));
+    u256 s = from_mont<Fr>(cs ? colsrc_fetch(src, i, n, n_blind) : ld256(sc + i));
     const bool neg = fold_scalar(s);
     emit_digits(s, neg, u256_bits(s), c, W, f, i);
   }
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(256) void k_msm_count_entries(const u256* __restric
 }
 
 // One workgroup per column: counting sort of (bucket -> table index|sign), segment numbering and range cutting.
-__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, size_t n, size_t table_n, uint32_t c, uint32_t W,
+__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __restrict__ scalars, const ColSrc* __restrict__ srcs, uint32_t n_blind, size_t n,
+                                                               size_t table_n, uint32_t c, uint32_t W,
                                                                uint32_t* __restrict__ entries, size_t ent_cap,
                                                                uint32_t* __restrict__ seg_off, uint32_t* __restrict__ bucket_off, MsmRange* __restrict__ ranges,
                                                                uint32_t* __restrict__ counters /* [0]=segments, [1]=overflow, [2]=max segs/bucket, [3]=ranges */,
@@ -263,13 +268,14 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   uint32_t* wave_sums = sh + 3 * B;  // 18
   __shared__ uint32_t s_base, s_rbase, s_qcnt;
   const uint32_t col = blockIdx.x, tid = threadIdx.x;
-  const u256* sc = scalars + (size_t)col * n;
+  const u256* sc = scalars ? scalars + (size_t)col * n : nullptr;
+  const ColSrc* cs = srcs ? srcs + col : nullptr;
   const uint8_t* mk = skip_mask ? skip_mask + (size_t)col * n : nullptr;
   for (uint32_t b = tid; b < B; b += MSM_SORT_THREADS) hist[b] = 0;
   __syncthreads();
   uint32_t* queue = longq + (size_t)col * n;
   unsigned long long* rec = recs + (size_t)col * n;
-  walk_scalars(sc, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); });
+  walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); });
   __syncthreads();
   if (dbg == 1) return;
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __syncthreads();
   if (dbg == 2) return;
   uint32_t* ent = entries + (size_t)col * ent_cap;
-  walk_scalars(sc, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
+  walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
     uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
     ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
   });
@@ -686,7 +692,7 @@ static uint32_t pick_window(uint32_t k) {
 // leave most of the chip idle) goes to the context's auxiliary stream and the function returns without waiting;
 // msm_collect() joins.  The scalars are no longer read at that point, so the caller may overwrite them (NTT in place).
 int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev, const uint8_t* skip_mask = nullptr,
-                  const Affine* add_points = nullptr, bool defer_tail = false) {
+                  const Affine* add_points = nullptr, bool defer_tail = false, const ColSrc* srcs = nullptr, uint32_t n_blind = 0) {
   Context& cx = ctx();
   if (g_prof_on) defer_tail = false;  // per-kernel timing serialises on the main stream
   if (cx.msm_pending) {
@@ -742,7 +748,8 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
     VDB_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), cx.stream));
     {
       VDB_PROF("k_msm_sort");
-      hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev + c0 * n, n, srs->n, c, W, entries,
+      hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev ? scalars_dev + c0 * n : nullptr, srcs ? srcs + c0 : nullptr,
+                       n_blind, n, srs->n, c, W, entries,
                        ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
                        getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0, lcap, longq, recs);
     }
@@ -943,6 +950,22 @@ int vdb_msm_batch_masked_dev_begin(const vdb_srs* srs, int basis, const vdb_fr* 
   ctx().msm_out = dout;
   int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev), true);
   if (rc == VDB_OK && !ctx().msm_pending) ctx().msm_pending = true;  // profiling mode ran it synchronously: _end still copies out
+  return rc;
+}
+int vdb_msm_batch_src_dev_begin(const vdb_srs* srs, int basis, const vdb_colsrc* src_dev, size_t n_cols, size_t n, uint32_t n_blind,
+                                const uint8_t* skip_mask_dev, const vdb_g1* const_points_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(srs && src_dev && (basis == 0 || basis == 1), "bad argument");
+  VDB_ARG(srs->table[basis], "srs was loaded without this basis");
+  VDB_ARG(n <= srs->n && n > 0 && n_blind <= n, "n exceeds the loaded SRS size");
+  VDB_ARG((skip_mask_dev == nullptr) == (const_points_dev == nullptr), "mask and constant points go together");
+  if (n_cols == 0) return VDB_OK;
+  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  if (!dout) return VDB_ERR_OOM;
+  ctx().msm_out = dout;
+  int rc = msm_batch_dev(srs, basis, nullptr, n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev), true,
+                         reinterpret_cast<const ColSrc*>(src_dev), n_blind);
+  if (rc == VDB_OK && !ctx().msm_pending) ctx().msm_pending = true;
   return rc;
 }
 int vdb_msm_batch_end(vdb_g1* out_host, size_t n_cols) {

@@ -35,6 +35,8 @@ struct NttPass {
   uint64_t in_len;                // elements >= in_len of the input column read as zero
   uint64_t in_stride, out_stride; // column strides (elements)
   uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
+  const ColSrc* srcs;             // pass 0 only: columns still lying in a witness stream (null: read `in`)
+  uint32_t n_blind;
   u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery
   uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
 };
@@ -108,6 +110,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   const uint32_t tid = threadIdx.x;
   const uint32_t col = blockIdx.x / tiles_per_col, tile = blockIdx.x % tiles_per_col;
   const u256* cin = in + (size_t)col * p.in_stride;
+  ColSrc csrc;
+  const bool from_src = p.first && p.srcs != nullptr;
+  if (from_src) csrc = p.srcs[col];
   u256* cout = out + (size_t)col * p.out_stride;
 
   // tile geometry
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     uint64_t idx = base + j * jstride + g * gstride;
     L9 v;
     if (!p.first || idx < p.in_len) {
-      v = l9_split(ld256(cin + idx));
+      v = l9_split(from_src ? colsrc_fetch(csrc, idx, 1ull << p.log_n, p.n_blind) : ld256(cin + idx));
       if (p.coset) {
         uint32_t r3 = (uint32_t)(idx % 3);
         if (r3 == 1) v = l9_mul(v, Z1);
@@ -336,7 +341,7 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, const u256& f
 // Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
 // result goes to out (stride n) or back into data when out == nullptr.
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len) {
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind) {
   Context& c = ctx();
   if (n_cols == 0) return VDB_OK;
   if (log_n > 26) {
@@ -349,6 +354,10 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   u256* dst = out_or_null ? out_or_null : data;
   if (!out_or_null && in_stride != n) {
     set_error("ntt: in-place transform needs in_len == n");
+    return VDB_ERR_ARG;
+  }
+  if (srcs && (!out_or_null || in_len != n || log_n <= 10)) {
+    set_error("ntt: column sources need an output buffer and a multi-pass size");
     return VDB_ERR_ARG;
   }
   int err = VDB_OK;
@@ -405,6 +414,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.first = (l == 0);
       p.coset = (l == 0 && coset_in);
       p.in_len = in_len;
+      p.srcs = (l == 0 && srcs) ? srcs + c0 : nullptr;
+      p.n_blind = n_blind;
       p.zeta1 = z1;
       p.zeta2 = z2;
       p.fin = fin;
@@ -448,7 +459,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       const u256* src;
       u256* out;
       if (l == 0) {
-        src = data + c0 * in_stride;
+        src = srcs ? scratch : data + c0 * in_stride;  // with column sources `in` is not read
         p.in_stride = in_stride;
       } else {
         src = scratch;
@@ -530,7 +541,7 @@ int vdb_ntt_batch_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t log_n, const vdb
   VDB_ARG(cols_dev && omega, "null pointer");
   u256 w;
   memcpy(&w, omega, 32);
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0, nullptr, 0);
 }
 int vdb_ntt_batch(vdb_fr* const* cols, size_t n_cols, uint32_t log_n, const vdb_fr* omega, int flags) {
   VDB_REQUIRE_INIT();
@@ -547,7 +558,13 @@ int vdb_lagrange_to_coeff_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
   VDB_ARG(cols_dev && k <= 26, "bad argument");
   u256 w = mont_inv<Fr>(host_root_of_unity(k));
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0, nullptr, 0);
+}
+int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc* src_dev, vdb_fr* coeff_dev, size_t n_cols, uint32_t k, uint32_t n_blind) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(src_dev && coeff_dev && k <= 26 && k > 10, "bad argument (column sources are supported for k > 10)");
+  u256 w = mont_inv<Fr>(host_root_of_unity(k));
+  return ntt_dev(nullptr, as_u256(coeff_dev), n_cols, k, w, true, false, 0, reinterpret_cast<const ColSrc*>(src_dev), n_blind);
 }
 int vdb_lagrange_to_coeff(vdb_fr* const* cols, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
@@ -564,7 +581,7 @@ int vdb_coeff_to_extended_dev(const vdb_fr* coeff_dev, vdb_fr* ext_dev, size_t n
   VDB_REQUIRE_INIT();
   VDB_ARG(coeff_dev && ext_dev && k + ext_k <= 26, "bad argument");
   u256 w = host_root_of_unity(k + ext_k);
-  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k);
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0);
 }
 int vdb_coeff_to_extended(const vdb_fr* const* coeff_cols, vdb_fr* const* ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();

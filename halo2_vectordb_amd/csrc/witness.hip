@@ -1411,6 +1411,44 @@ int vdb_layout_columns_range_dev(const vdb_fr* stream_dev, uint64_t n_cells, con
   VDB_HIP(hipStreamSynchronize(ctx().stream));  // break_points is a host buffer the caller may free
   return VDB_OK;
 }
+int vdb_colsrc_build_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, uint64_t col_lo,
+                         uint64_t col_hi, const vdb_fr* blind_dev, uint32_t n_blind, vdb_colsrc* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(stream_dev && out_dev && (break_points || n_bp == 0) && k <= 28 && col_lo <= col_hi && col_hi <= n_bp + 1, "bad argument");
+  const uint64_t rows = 1ull << k;
+  std::vector<vdb_colsrc> h(col_hi - col_lo);
+  uint64_t start = 0;
+  for (uint64_t c = 0; c < col_hi; c++) {
+    if (c < n_bp) VDB_ARG(break_points[c] < rows, "break point beyond the column height");
+    const uint64_t len = c < n_bp ? break_points[c] + 1 : n_cells - start;
+    VDB_ARG(start <= n_cells && len <= rows && start + len <= n_cells, "break points do not match the stream length");
+    if (c >= col_lo) {
+      h[c - col_lo].src = stream_dev + start;
+      h[c - col_lo].len = len;
+      h[c - col_lo].blind = blind_dev ? blind_dev + c * n_blind : nullptr;
+    }
+    if (c < n_bp) start += break_points[c];
+  }
+  if (!h.empty()) VDB_HIP(hipMemcpyAsync(out_dev, h.data(), h.size() * sizeof(vdb_colsrc), hipMemcpyHostToDevice, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_colsrc_build_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t col_lo, uint64_t col_hi,
+                                const vdb_fr* blind_dev, uint32_t n_blind, vdb_colsrc* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(out_dev && (lookup_dev || n_cells == 0) && k <= 28 && col_lo <= col_hi && minimum_rows < (1u << k), "bad argument");
+  const uint64_t max_rows = (1ull << k) - minimum_rows;
+  std::vector<vdb_colsrc> h(col_hi - col_lo);
+  for (uint64_t c = col_lo; c < col_hi; c++) {
+    const uint64_t start = c * max_rows;
+    h[c - col_lo].src = lookup_dev + (start < n_cells ? start : 0);
+    h[c - col_lo].len = start < n_cells ? (n_cells - start < max_rows ? n_cells - start : max_rows) : 0;
+    h[c - col_lo].blind = blind_dev ? blind_dev + c * n_blind : nullptr;
+  }
+  if (!h.empty()) VDB_HIP(hipMemcpyAsync(out_dev, h.data(), h.size() * sizeof(vdb_colsrc), hipMemcpyHostToDevice, ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
 int vdb_layout_lookup_dev(const vdb_fr* lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr* cols_dev, uint64_t n_cols,
                           const vdb_fr* blind_dev, uint32_t n_blind) {
   VDB_ARG(n_cols * ((((uint64_t)1 << k)) - minimum_rows) >= n_cells, "not enough lookup columns");

@@ -115,6 +115,7 @@ class KmeansHotPath:
         self.factor_constants = True
         self.shard_witness = True   # generate only the witness cells this rank's columns hold (values are computed everywhere)
         self.balance_shards = True  # equalise estimated time per rank instead of column count
+        self.virtual_layout = True  # commit and transform straight from the witness stream (no stream -> column copy)
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self, pinning=None):
@@ -207,6 +208,15 @@ class KmeansHotPath:
         self.d_blind = api.DeviceBuffer(blind.nbytes)
         self.d_blind.upload(blind)
         self.d_cols = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * B)
+        # column descriptors of my [advice block | lookup block]: where each column lies in the streams (data independent)
+        self.d_src = api.DeviceBuffer(max(self.my_cols, 1) * 24)
+        if self.my_adv:
+            check(lib.vdb_colsrc_build_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                           ctypes.c_uint64(self.a_lo), ctypes.c_uint64(self.a_hi), self.d_blind.ptr, N_BLIND, self.d_src.ptr))
+        if self.my_lk:
+            check(lib.vdb_colsrc_build_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, ctypes.c_uint64(self.l_lo),
+                                                  ctypes.c_uint64(self.l_hi), self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND,
+                                                  self.d_src.at(self.my_adv * 24)))
         self.d_ext = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * 4 * B)
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
@@ -288,7 +298,9 @@ class KmeansHotPath:
 
         stage("witness", self._witness)
 
-        stage("layout", self._layout)
+        virt = self.virtual_layout and self.k > 10
+        if not virt:
+            stage("layout", self._layout)
         my = self.d_cols.ptr
         self.commitments = np.zeros((self.my_cols, 8), dtype=np.uint64)
 
@@ -296,12 +308,18 @@ class KmeansHotPath:
             # the MSM is queued without waiting; the bucket folding of its last batch runs on a second stream beside the NTTs
             mask = self.d_mask.ptr if self.factor_constants else None
             cpts = self.d_cpts.ptr if self.factor_constants else None
-            check(lib.vdb_msm_batch_masked_dev_begin(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), mask, cpts))
+            if virt:
+                check(lib.vdb_msm_batch_src_dev_begin(self.srs.h, 1, self.d_src.ptr, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), N_BLIND, mask, cpts))
+            else:
+                check(lib.vdb_msm_batch_masked_dev_begin(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), mask, cpts))
 
         stage("commit_msm", commit)
 
         def ntt():
-            check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
+            if virt:
+                check(lib.vdb_lagrange_to_coeff_src_dev(self.d_src.ptr, my, ctypes.c_size_t(self.my_cols), self.k, N_BLIND))
+            else:
+                check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
             check(lib.vdb_coeff_to_extended_dev(my, self.d_ext.ptr, ctypes.c_size_t(self.my_cols), self.k, 2))
             check(lib.vdb_msm_batch_end(api._p(self.commitments), ctypes.c_size_t(self.my_cols)))
 
@@ -341,7 +359,7 @@ class KmeansHotPath:
         return cent, ind
 
     def free(self):
-        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext", "d_mask", "d_cpts"):
+        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext", "d_mask", "d_cpts", "d_src"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

@@ -139,6 +139,21 @@ int vdb_layout_columns_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uin
                            const vdb_fr *blind_dev, uint32_t n_blind);
 int vdb_layout_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, vdb_fr *cols_dev, uint64_t n_cols,
                           const vdb_fr *blind_dev, uint32_t n_blind);
+/* Columns without the copy.  A vdb_colsrc describes one column that still lies in a witness stream: rows [0, len) are the
+ * contiguous cells src[0 .. len), the last n_blind rows come from `blind` (may be NULL), every other row is zero — exactly
+ * what vdb_layout_columns[_range]_dev / vdb_layout_lookup[_range]_dev would have written.  The commitment MSM
+ * (vdb_msm_batch_src_dev_begin) and the first pass of lagrange_to_coeff (vdb_lagrange_to_coeff_src_dev, which writes the
+ * coefficient columns) read through it, so the 64 B / cell of the layout copy disappear from the prover's step.  The
+ * descriptors are data independent: build them once per circuit.  out_dev: (col_hi - col_lo) descriptors in device memory. */
+typedef struct {
+  const vdb_fr *src;
+  uint64_t len;
+  const vdb_fr *blind;
+} vdb_colsrc;
+int vdb_colsrc_build_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, uint64_t col_lo,
+                         uint64_t col_hi, const vdb_fr *blind_dev, uint32_t n_blind, vdb_colsrc *out_dev);
+int vdb_colsrc_build_lookup_dev(const vdb_fr *lookup_dev, uint64_t n_cells, uint32_t k, uint32_t minimum_rows, uint64_t col_lo, uint64_t col_hi,
+                                const vdb_fr *blind_dev, uint32_t n_blind, vdb_colsrc *out_dev);
 /* same, restricted to columns [col_lo, col_hi) (multi-GPU column shards); cols_dev holds just that range; blind_dev is
  * still indexed by absolute column */
 int vdb_layout_columns_range_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, uint64_t col_lo,
@@ -175,6 +190,9 @@ int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, 
  * are no longer read) overlaps it.  _end waits and copies the n_cols commitments out.  One deferred MSM at a time. */
 int vdb_msm_batch_masked_dev_begin(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, const uint8_t *skip_mask_dev,
                                    const vdb_g1 *const_points_dev);
+/* same for columns described by vdb_colsrc (n rows each, the last n_blind of them blinding rows) */
+int vdb_msm_batch_src_dev_begin(const vdb_srs *srs, int basis, const vdb_colsrc *src_dev, size_t n_cols, size_t n, uint32_t n_blind,
+                                const uint8_t *skip_mask_dev, const vdb_g1 *const_points_dev);
 int vdb_msm_batch_end(vdb_g1 *out_host, size_t n_cols);
 /* per column: the number of (scalar, window) entries vdb_msm_batch[_masked]_dev would sort and accumulate for it (non-zero
  * signed digits of the cells not flagged in skip_mask_dev, which may be NULL).  A keygen-time statistic used to balance
@@ -197,6 +215,9 @@ int vdb_ntt_batch_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t log_n, const vdb
 /* lagrange_to_coeff for the 2^k domain (omega = ROOT_OF_UNITY^(2^(28-k))) */
 int vdb_lagrange_to_coeff(vdb_fr *const *cols, size_t n_cols, uint32_t k);
 int vdb_lagrange_to_coeff_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t k);
+/* lagrange_to_coeff of columns described by vdb_colsrc: reads the witness stream, writes n_cols coefficient columns of
+ * 2^k elements to coeff_dev (k > 10) */
+int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc *src_dev, vdb_fr *coeff_dev, size_t n_cols, uint32_t k, uint32_t n_blind);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

@@ -181,3 +181,29 @@ def test_pinning_file_keygen_then_prove(api, O, tmp_path):
     with pytest.raises(ValueError):
         other.setup(pinning=pin)
     other.free()
+
+
+@pytest.mark.parametrize("k", [11, 13])
+def test_virtual_layout_matches_the_copied_layout(api, O, k):
+    """committing and transforming straight from the witness stream (vdb_colsrc) gives the same commitments, coefficient
+    columns and extended columns as the path that first copies the stream into columns"""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    cfg = dict(n=14, dim=6, K=3, I=2, k=k, P=48, L=9, seed=11)
+    out = {}
+    for virt in (False, True):
+        hp = KmeansHotPath(**cfg)
+        hp.virtual_layout = virt
+        hp.setup()
+        com = hp.step().copy()
+        coeff = hp.d_cols.download((hp.my_cols, hp.rows, 4))
+        ext = hp.d_ext.download((hp.my_cols, 4 * hp.rows, 4))
+        out[virt] = (com, coeff, ext)
+        if virt:   # and against the oracle, from the columns the copy path lays out
+            hp.relayout()
+            cols = hp.download_columns(list(range(hp.n_cols)))
+            assert np.array_equal(com, O.msm_batch(cols, hp.g_lagrange, threads=4))
+            wc, we = O.lde_batch(cols[:3], ext=2, threads=3)
+            assert np.array_equal(coeff[:3], wc) and np.array_equal(ext[:3], we)
+        hp.free()
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)

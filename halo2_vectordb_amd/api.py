@@ -338,6 +338,23 @@ def poseidon_permute(states):
 
 
 # ---------------------------------------------------------------- device buffers
+def grand_product(num, den):
+    """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i]; num, den: (n_cols, n, 4) uint64 (Montgomery Fr)."""
+    lib = _lib.init()
+    num, den = _fr(num), _fr(den)
+    n_cols, n = num.shape[0], num.shape[1]
+    bufs = [DeviceBuffer(max(num.nbytes, 32)) for _ in range(3)]
+    try:
+        bufs[0].upload(num)
+        bufs[1].upload(den)
+        check(lib.vdb_grand_product_dev(bufs[0].ptr, bufs[1].ptr, _sz(n_cols), _sz(n), bufs[2].ptr))
+        sync()
+        return bufs[2].download((n_cols, n, 4))
+    finally:
+        for b in bufs:
+            b.free()
+
+
 class DeviceBuffer:
     """A raw HBM allocation owned by the library's context."""
 

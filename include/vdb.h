@@ -218,6 +218,11 @@ int vdb_lagrange_to_coeff_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t k);
 /* lagrange_to_coeff of columns described by vdb_colsrc: reads the witness stream, writes n_cols coefficient columns of
  * 2^k elements to coeff_dev (k > 10) */
 int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc *src_dev, vdb_fr *coeff_dev, size_t n_cols, uint32_t k, uint32_t n_blind);
+/* Batched grand product of the permutation / lookup arguments (the first prover-round primitive after
+ * commit + NTT): per column of n entries z[0] = 1, z[i + 1] = z[i] * num[i] / den[i] (i < n - 1).  A zero denominator
+ * inverts to zero like halo2's batch_invert, i.e. z is zero from that row on.  One field inversion per column.
+ * num_dev, den_dev, z_dev: n_cols x n, column-major contiguous, device memory. */
+int vdb_grand_product_dev(const vdb_fr *num_dev, const vdb_fr *den_dev, size_t n_cols, size_t n, vdb_fr *z_dev);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

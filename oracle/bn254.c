@@ -221,6 +221,25 @@ void orc_fr_sub_batch(fr_t *o, const fr_t *a, const fr_t *b, size_t n) {
 void orc_fr_inv_batch(fr_t *o, const fr_t *a, size_t n) {
   for (size_t i = 0; i < n; i++) fr_inv(&o[i], &a[i]);
 }
+/* Grand product of the permutation / lookup arguments (halo2 plonk/permutation/prover.rs and
+ * plonk/lookup/prover.rs, [UPSTREAM-RECALL]): z[0] = 1, z[i + 1] = z[i] * num[i] / den[i].  Denominators are inverted the
+ * way halo2's batch_invert does: a zero stays zero, so the product is zero from there on.  One column of n entries. */
+void orc_grand_product(fr_t *z, const fr_t *num, const fr_t *den, size_t n) {
+  if (n == 0) return;
+  fr_t acc, inv, t;
+  fr_from_u64(&acc, 1);
+  for (size_t i = 0; i < n; i++) {
+    z[i] = acc;
+    if (i + 1 == n) break;
+    if (fr_is_zero(&den[i])) {
+      memset(&acc, 0, sizeof(acc));
+    } else {
+      fr_inv(&inv, &den[i]);
+      fr_mul(&t, &num[i], &inv);
+      fr_mul(&acc, &acc, &t);
+    }
+  }
+}
 void orc_fr_from_canonical_batch(fr_t *o, const u256 *a, size_t n) {
   for (size_t i = 0; i < n; i++) fr_from_canonical(&o[i], &a[i]);
 }

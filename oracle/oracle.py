@@ -126,6 +126,16 @@ def fr_inv(a):
     return o
 
 
+def grand_product(num, den):
+    """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i] per column (zero denominators invert to zero)."""
+    num = np.ascontiguousarray(num, dtype=np.uint64)
+    den = np.ascontiguousarray(den, dtype=np.uint64)
+    z = np.empty_like(num)
+    for c in range(num.shape[0]):
+        lib().orc_grand_product(_p(z[c]), _p(num[c]), _p(den[c]), _sz(num.shape[1]))
+    return z
+
+
 def fr_to_canonical(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     o = np.empty_like(a)

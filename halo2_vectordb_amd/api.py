@@ -338,6 +338,20 @@ def poseidon_permute(states):
 
 
 # ---------------------------------------------------------------- device buffers
+def eval_polys(coeffs, x):
+    """out[c] = sum_i coeffs[c][i] * x^i; coeffs: (n_cols, n, 4) uint64 on the host (uploaded), x: (4,)"""
+    lib = _lib.init()
+    coeffs, x = _fr(coeffs), _fr(x)
+    out = np.zeros((coeffs.shape[0], 4), dtype=np.uint64)
+    buf = DeviceBuffer(max(coeffs.nbytes, 32))
+    try:
+        buf.upload(coeffs)
+        check(lib.vdb_eval_polys_dev(buf.ptr, _sz(coeffs.shape[0]), _sz(coeffs.shape[1]), _p(x), _p(out)))
+        return out
+    finally:
+        buf.free()
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i]; num, den: (n_cols, n, 4) uint64 (Montgomery Fr)."""
     lib = _lib.init()

@@ -11,6 +11,7 @@
 //   pass 2a: rows backwards — S_i / D into z[i + 1];  pass 2b: rows forwards — times N_i.
 // Roofline: 224 B of HBM traffic and 5 products per row — about balanced between HBM and the integer ALU.
 #include "common.hpp"
+#include "limb9.hpp"
 
 namespace vdb {
 
@@ -113,6 +114,56 @@ __global__ __launch_bounds__(GP_THREADS) void k_grand_product(const u256* __rest
   if (threadIdx.x == 0) st256(zo, one);
 }
 
+// ---- evaluation of coefficient-form polynomials at one point (halo2 arithmetic::eval_polynomial, used for every advice
+// polynomial when the prover opens at x, [UPSTREAM-RECALL]) -----------------------------------------------------------
+// out[c] = sum_i a[c][i] x^i.  One 256-thread workgroup per polynomial; thread t owns the coefficients i = t (mod 256)
+// — consecutive lanes read consecutive coefficients, whole lines — and runs Horner in y = x^256:
+//     P_t = sum_k a[t + 256 k] y^k,      out = sum_t x^t P_t   (x^t by square-and-multiply, LDS tree for the sum).
+// Roofline: 32 B per coefficient, one product and one addition: HBM bound in principle (17 GB for C4's columns in
+// 2.7 ms at 6.3 TB/s), about 4.5 ms of integer ALU at the measured product rate — the two are close.
+#define EV_THREADS 256
+// The Horner accumulator lives in nine-limb form (limb9.hpp): acc * y is one 9 x 29-bit product with the pre-scaled
+// constant 32 y, the coefficient is added without carries (limbs stay below 2 * 2^29, values below 2.2 r: no carry pass
+// is ever needed), so a step costs ~250 instructions instead of ~350.
+__global__ __launch_bounds__(EV_THREADS) void k_eval_polys(const u256* __restrict__ coeff, uint64_t n, u256 x, u256 y32 /* 32 x^EV_THREADS */,
+                                                           u256* __restrict__ out) {
+  __shared__ u256 sh[EV_THREADS];
+  const uint64_t col = blockIdx.x;
+  const u256* a = coeff + col * n;
+  const uint32_t t = threadIdx.x;
+  u256 acc = u256_zero();
+  if (t < n) {
+    const L9 Y = l9_split(y32);
+    L9 A;
+#pragma unroll
+    for (int k9 = 0; k9 < 9; k9++) A.l[k9] = 0;
+    // highest k with t + 256 k < n
+    uint64_t k = (n - 1 - t) / EV_THREADS;
+    for (;;) {
+      // (coefficients are fetched four steps ahead of the dependent Horner chain)
+      u256 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) v[q] = ld256(a + t + EV_THREADS * (k >= q ? k - q : 0));
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        if (k < q) break;
+        A = l9_add(l9_mul<Fr>(A, Y), l9_split(v[q]));
+      }
+      if (k < 4) break;
+      k -= 4;
+    }
+    const u256 xt32 = fr_mul(mont_pow<Fr>(x, u256_from_u64(t)), to_mont<Fr>(u256_from_u64(32)));
+    acc = l9_canon<Fr>(l9_mul<Fr>(A, l9_split(xt32)));
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t o = EV_THREADS / 2; o >= 1; o >>= 1) {
+    if (t < o) sh[t] = fr_add(sh[t], sh[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) st256(out + col, sh[0]);
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -129,6 +180,28 @@ int vdb_grand_product_dev(const vdb_fr* num_dev, const vdb_fr* den_dev, size_t n
                      (uint64_t)n);
   }
   VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, vdb_fr* out_host) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && x && out_host && n >= 1, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  u256 xv;
+  memcpy(&xv, x, 32);
+  u256 y = xv;
+  for (int i = 0; i < 8; i++) y = fr_mul(y, y);  // x^256
+  y = fr_mul(y, host_fr_from_u64(32));             // pre-scaled for the nine-limb product
+  u256* dout = (u256*)scratch_get(5, n_cols * sizeof(u256));
+  if (!dout) return VDB_ERR_OOM;
+  {
+    VDB_PROF("k_eval_polys");
+    hipLaunchKernelGGL(k_eval_polys, dim3((unsigned)n_cols), dim3(EV_THREADS), 0, cx.stream, as_u256(coeff_dev), (uint64_t)n, xv, y, dout);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(u256), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
   return VDB_OK;
 }
 

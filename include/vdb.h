@@ -223,6 +223,9 @@ int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc *src_dev, vdb_fr *coeff_dev, 
  * inverts to zero like halo2's batch_invert, i.e. z is zero from that row on.  One field inversion per column.
  * num_dev, den_dev, z_dev: n_cols x n, column-major contiguous, device memory. */
 int vdb_grand_product_dev(const vdb_fr *num_dev, const vdb_fr *den_dev, size_t n_cols, size_t n, vdb_fr *z_dev);
+/* out[c] = sum_i coeff[c][i] * x^i for n_cols coefficient-form polynomials of n coefficients (halo2 eval_polynomial, the
+ * opening evaluations of the advice polynomials).  coeff_dev: device; x: one field element on the host; out_host: host. */
+int vdb_eval_polys_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *out_host);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

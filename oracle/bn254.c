@@ -221,6 +221,16 @@ void orc_fr_sub_batch(fr_t *o, const fr_t *a, const fr_t *b, size_t n) {
 void orc_fr_inv_batch(fr_t *o, const fr_t *a, size_t n) {
   for (size_t i = 0; i < n; i++) fr_inv(&o[i], &a[i]);
 }
+/* halo2 arithmetic::eval_polynomial: sum_i a[i] x^i by Horner's rule */
+void orc_eval_poly(fr_t *out, const fr_t *a, size_t n, const fr_t *x) {
+  fr_t acc;
+  memset(&acc, 0, sizeof(acc));
+  for (size_t i = n; i > 0; i--) {
+    fr_mul(&acc, &acc, x);
+    fr_add(&acc, &acc, &a[i - 1]);
+  }
+  *out = acc;
+}
 /* Grand product of the permutation / lookup arguments (halo2 plonk/permutation/prover.rs and
  * plonk/lookup/prover.rs, [UPSTREAM-RECALL]): z[0] = 1, z[i + 1] = z[i] * num[i] / den[i].  Denominators are inverted the
  * way halo2's batch_invert does: a zero stays zero, so the product is zero from there on.  One column of n entries. */

@@ -74,6 +74,7 @@ void orc_fr_mul_batch(fr_t *o, const fr_t *a, const fr_t *b, size_t n);
 void orc_fr_add_batch(fr_t *o, const fr_t *a, const fr_t *b, size_t n);
 void orc_fr_sub_batch(fr_t *o, const fr_t *a, const fr_t *b, size_t n);
 void orc_fr_inv_batch(fr_t *o, const fr_t *a, size_t n);
+void orc_eval_poly(fr_t *out, const fr_t *a, size_t n, const fr_t *x);
 void orc_grand_product(fr_t *z, const fr_t *num, const fr_t *den, size_t n);
 void orc_fr_from_canonical_batch(fr_t *o, const u256 *a, size_t n);
 void orc_fr_to_canonical_batch(u256 *o, const fr_t *a, size_t n);

@@ -126,6 +126,16 @@ def fr_inv(a):
     return o
 
 
+def eval_polys(coeffs, x):
+    """out[c] = sum_i coeffs[c][i] * x^i (Horner); coeffs: (n_cols, n, 4), x: (4,)"""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    out = np.zeros((coeffs.shape[0], 4), dtype=np.uint64)
+    for c in range(coeffs.shape[0]):
+        lib().orc_eval_poly(_p(out[c]), _p(coeffs[c]), _sz(coeffs.shape[1]), _p(x))
+    return out
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i] per column (zero denominators invert to zero)."""
     num = np.ascontiguousarray(num, dtype=np.uint64)

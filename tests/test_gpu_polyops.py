@@ -51,3 +51,24 @@ def test_grand_product_recurrence_at_bench_size(api, O):
     assert np.array_equal(lhs, rhs)
     assert np.array_equal(z[:, 0], np.tile(O.fr_from_ints([1]), (n_cols, 1)))
     assert np.array_equal(z[:2], O.grand_product(num[:2], den[:2]))
+
+
+@pytest.mark.parametrize("n_cols,n", [(1, 1), (2, 5), (3, 255), (2, 256), (2, 257), (3, 1024), (2, 65536)])
+def test_eval_polys_matches_oracle(api, O, n_cols, n):
+    rng = np.random.default_rng(17 * n + n_cols)
+    coeffs = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    for x in (O.random_fr(rng, 1)[0], O.fr_from_ints([0])[0], O.fr_from_ints([1])[0]):
+        assert np.array_equal(api.eval_polys(coeffs, x), O.eval_polys(coeffs, x))
+
+
+def test_eval_of_interpolant_returns_the_lagrange_values(api, O):
+    """ties the NTT and the evaluation together at the bench size: the coefficients lagrange_to_coeff produces, evaluated
+    at omega^j, are the Lagrange values the column started from"""
+    rng = np.random.default_rng(23)
+    k = 16
+    cols = O.random_fr(rng, 3 << k).reshape(3, 1 << k, 4)
+    coeffs = api.lagrange_to_coeff(cols)
+    w = O.root_of_unity(k)
+    for j in (0, 1, 2, 12345, (1 << k) - 1):
+        x = O.fr_from_ints([pow(O.fr_to_ints(w.reshape(1, 4))[0], j, O.R_MOD)])[0]
+        assert np.array_equal(api.eval_polys(coeffs, x), cols[:, j])

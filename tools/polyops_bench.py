@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of vdb_grand_product_dev on device-resident columns (first brick)."""
+"""Throughput of vdb_grand_product_dev and vdb_eval_polys_dev on device-resident columns (SURVEY §8 f1 bricks)."""
 import ctypes
 import json
 import os
@@ -25,5 +25,13 @@ for it in range(3):
     check(lib.vdb_grand_product_dev(bufs[0].ptr, bufs[1].ptr, ctypes.c_size_t(n_cols), ctypes.c_size_t(n), bufs[2].ptr))
     ms = api.timer_stop()
 rows = n_cols * n
-print(json.dumps({"n_cols": n_cols, "n": n, "ms": round(ms, 3), "rows_per_s": rows / ms * 1e3, "algorithmic_GBps": 224.0 * rows / ms / 1e6,
+x = np.array([0x1234567890ABCDEF, 0x0FEDCBA098765432, 0x1111111122222222, 0x0333333344444444], dtype=np.uint64)
+out = np.zeros((n_cols, 4), dtype=np.uint64)
+for it in range(3):
+    api.timer_start()
+    check(lib.vdb_eval_polys_dev(bufs[0].ptr, ctypes.c_size_t(n_cols), ctypes.c_size_t(n), api._p(x), api._p(out)))
+    ms_ev = api.timer_stop()
+print(json.dumps({"kernel": "k_eval_polys", "n_cols": n_cols, "n": n, "ms": round(ms_ev, 3), "coeff_per_s": rows / ms_ev * 1e3,
+                  "algorithmic_GBps": 32.0 * rows / ms_ev / 1e6, "hbm_frac": 32.0 * rows / ms_ev / 1e6 / 8000.0}))
+print(json.dumps({"kernel": "k_grand_product", "n_cols": n_cols, "n": n, "ms": round(ms, 3), "rows_per_s": rows / ms * 1e3, "algorithmic_GBps": 224.0 * rows / ms / 1e6,
                   "fr_mul_per_s": 5.0 * rows / ms * 1e3}))

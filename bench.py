@@ -192,7 +192,8 @@ def main():
             pass
         if world == 1 and not args.no_cpu_baseline:
             hp.relayout()
-            idx = list(range(0, hp.n_cols, max(1, hp.n_cols // 32)))[:32]
+            ns = min(hp.n_cols, 512)  # ~10-15 s of host work on the GPU box: 1 witness iteration + 512 columns of MSM / NTT
+            idx = list(range(0, hp.n_cols, max(1, hp.n_cols // ns)))[:ns]
             cols = hp.download_columns(idx)
             cpu = cpu_baseline(hp, cols, commitments[idx])
 

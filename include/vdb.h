@@ -16,8 +16,10 @@
  *  - Every function returns 0 on success or a negative VDB_ERR_*; nothing aborts or throws across
  *    the ABI.  vdb_last_error() returns a thread-local message for the last failure.
  *  - Host pointers unless the name ends in _dev (then: device pointers in HBM of the bound GPU).
- *  - One process binds one GPU (vdb_init(device)); calls are blocking and not re-entrant per process,
- *    matching the reference's single prover thread.
+ *  - One process binds one GPU (vdb_init(device)); calls are not re-entrant per process, matching the
+ *    reference's single prover thread.  Entry points with host outputs block until the result is there;
+ *    _dev entry points only queue work on the library's stream (in order), and the vdb_msm_batch_*_begin /
+ *    vdb_msm_batch_end pair is explicitly asynchronous (see there).  vdb_sync() waits for everything queued.
  */
 #ifndef VDB_H
 #define VDB_H

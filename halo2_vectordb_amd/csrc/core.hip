@@ -244,6 +244,7 @@ int vdb_memset_dev(void* dst, int value, size_t bytes) {
 int vdb_sync(void) {
   VDB_REQUIRE_INIT();
   VDB_HIP(hipStreamSynchronize(ctx().stream));
+  VDB_HIP(hipStreamSynchronize(ctx().aux));  // the tail of a deferred MSM, if any
   return VDB_OK;
 }
 int vdb_timer_start(void) {

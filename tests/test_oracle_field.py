@@ -123,3 +123,22 @@ def test_srs_from_tau_commit_consistency(O, PY):
     assert np.array_equal(a, b)
     p_tau = sum(c * pow(tau, j, R) for j, c in enumerate(O.fr_to_ints(coeffs))) % R
     assert tuple(O.fq_to_ints(a.reshape(2, 4))) == PY.g1_mul((1, 2), p_tau)
+
+
+def test_prover_round_primitives_against_python(O):
+    """orc_grand_product / orc_eval_poly (checkers of polyops.hip) against plain Python big-int arithmetic"""
+    R = O.R_MOD
+    rng = np.random.default_rng(99)
+    n = 40
+    num_i = [int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % R for _ in range(n)]
+    den_i = [int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % R for _ in range(n)]
+    den_i[17] = 0
+    z = O.grand_product(O.fr_from_ints(num_i).reshape(1, n, 4), O.fr_from_ints(den_i).reshape(1, n, 4))
+    want, acc = [], 1
+    for i in range(n):
+        want.append(acc)
+        acc = acc * num_i[i] * (pow(den_i[i], -1, R) if den_i[i] else 0) % R
+    assert O.fr_to_ints(z[0]) == want
+    x = int(rng.integers(1, 1 << 62)) ** 3 % R
+    got = O.eval_polys(O.fr_from_ints(num_i).reshape(1, n, 4), O.fr_from_ints([x])[0])
+    assert O.fr_to_ints(got) == [sum(c * pow(x, i, R) for i, c in enumerate(num_i)) % R]

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
                                                                uint32_t* __restrict__ seg_off, uint32_t* __restrict__ bucket_off, MsmRange* __restrict__ ranges,
                                                                uint32_t* __restrict__ counters /* [0]=segments, [1]=overflow, [2]=max segs/bucket, [3]=ranges */,
                                                                uint32_t seg_cap, uint32_t range_cap,
-                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */, int dbg,
+                                                               const uint8_t* __restrict__ skip_mask /* optional: n per column */,
                                                                uint32_t lcap /* range length, a power of two */,
                                                                uint32_t* __restrict__ longq /* n per column: queue of the long scalars */,
                                                                unsigned long long* __restrict__ recs /* n per column: short-scalar records */) {
@@ -277,7 +277,6 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   unsigned long long* rec = recs + (size_t)col * n;
   walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); });
   __syncthreads();
-  if (dbg == 1) return;
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
   const uint32_t ipt = (B + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS;
   uint32_t cnt_local = 0;
@@ -366,7 +365,6 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
     ranges[rbase + r] = rg;
   }
   __syncthreads();
-  if (dbg == 2) return;
   uint32_t* ent = entries + (size_t)col * ent_cap;
   walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
     uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
@@ -751,7 +749,7 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev ? scalars_dev + c0 * n : nullptr, srcs ? srcs + c0 : nullptr,
                        n_blind, n, srs->n, c, W, entries,
                        ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
-                       getenv("VDB_SORT_DBG") ? atoi(getenv("VDB_SORT_DBG")) : 0, lcap, longq, recs);
+                       lcap, longq, recs);
     }
     VDB_LAUNCH_CHECK();
     {

@@ -183,12 +183,12 @@ def test_pinning_file_keygen_then_prove(api, O, tmp_path):
     other.free()
 
 
-@pytest.mark.parametrize("k", [11, 13])
-def test_virtual_layout_matches_the_copied_layout(api, O, k):
+@pytest.mark.parametrize("k,metric", [(11, "euclidean"), (13, "euclidean"), (12, "cosine"), (11, "manhattan")])
+def test_virtual_layout_matches_the_copied_layout(api, O, k, metric):
     """committing and transforming straight from the witness stream (vdb_colsrc) gives the same commitments, coefficient
     columns and extended columns as the path that first copies the stream into columns"""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    cfg = dict(n=14, dim=6, K=3, I=2, k=k, P=48, L=9, seed=11)
+    cfg = dict(n=14, dim=6, K=3, I=2, k=k, P=48, L=9, seed=11, metric=metric)
     out = {}
     for virt in (False, True):
         hp = KmeansHotPath(**cfg)

@@ -88,6 +88,13 @@ HD L9 l9_mul(const L9& a, const L9& b) {
   mont_core29<M>(r.l, a.l, b.l);
   return r;
 }
+// (a1 * b1 + a2 * b2) / 2^261 (+ less than p) with one reduction; limbs of a1 and a2 together below 6 * 2^29
+template <class M>
+HD L9 l9_mul2(const L9& a1, const L9& b1, const L9& a2, const L9& b2) {
+  L9 r;
+  mont_core29_2<M>(r.l, a1.l, b1.l, a2.l, b2.l);
+  return r;
+}
 // a * a / 2^261 (+ less than p) for a normalised a (limbs below 2^29 + 8)
 template <class M>
 HD L9 l9_sqr(const L9& a) {

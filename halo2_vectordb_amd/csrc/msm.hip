@@ -453,10 +453,10 @@ __device__ __forceinline__ void madd_l9(AccL9& acc, bool& ident, const Affine& p
   L9 x3 = l9_add(l9_add(l9_sub(r2, ppp, K.c2), nq), nq);  // r2 - ppp - 2 qq + 6q: limbs < 6.9 * 2^29, value < 7.5 q
   l9_carry(x3);
   const L9 td = l9_sub(qq, x3, K.c8);      // qq - x3 + 8q: limbs < 3 * 2^29, value < 9.1 q
-  const L9 m1 = l9_mul<Fq>(td, rn);        // < 1.5 q
-  const L9 m2 = l9_mul<Fq>(acc.y, ppp);    // < 1.03 q
-  L9 y3 = l9_sub(m1, m2, K.c2);            // < 3.5 q
-  l9_carry(y3);
+  // y3 = td * rn - y1 * ppp as ONE reduced sum of two products: td * rn + (8q - y1) * ppp  (limbs 3 + 2 units,
+  // values 9.1 q * 9.1 q + 8 q * 1.1 q: the result is exactly normalised and below 1.6 q)
+  const L9 ny = l9_neg(acc.y, K.c8);
+  const L9 y3 = l9_mul2<Fq>(td, rn, ny, ppp);
   acc.zz = l9_mul<Fq>(acc.zz, pp);
   acc.zzz = l9_mul<Fq>(acc.zzz, ppp);
   acc.x = x3;

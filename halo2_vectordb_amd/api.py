@@ -352,6 +352,23 @@ def eval_polys(coeffs, x):
         buf.free()
 
 
+def lookup_permute(inputs, table, usable_rows, max_bits):
+    """inputs: (n_cols, n, 4), table: (n, 4) Montgomery Fr on the host; returns (permuted_input, permuted_table)"""
+    lib = _lib.init()
+    inputs, table = _fr(inputs), _fr(table)
+    n_cols, n = inputs.shape[0], inputs.shape[1]
+    bufs = [DeviceBuffer(max(inputs.nbytes, 32)), DeviceBuffer(max(table.nbytes, 32)), DeviceBuffer(max(inputs.nbytes, 32)), DeviceBuffer(max(inputs.nbytes, 32))]
+    try:
+        bufs[0].upload(inputs)
+        bufs[1].upload(table)
+        check(lib.vdb_lookup_permute_dev(bufs[0].ptr, bufs[1].ptr, _sz(n_cols), _sz(n), _sz(usable_rows), ctypes.c_uint32(max_bits), bufs[2].ptr, bufs[3].ptr))
+        sync()
+        return bufs[2].download((n_cols, n, 4)), bufs[3].download((n_cols, n, 4))
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i]; num, den: (n_cols, n, 4) uint64 (Montgomery Fr)."""
     lib = _lib.init()

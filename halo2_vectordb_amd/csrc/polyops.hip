@@ -164,6 +164,124 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_polys(const u256* __restric
   if (t == 0) st256(out + col, sh[0]);
 }
 
+// ---- lookup argument: permuted input / table columns (halo2 plonk/lookup/prover.rs permute_expression_pair,
+// [UPSTREAM-RECALL]) ------------------------------------------------------------------------------------------------
+// Over the usable rows: A' = the input values sorted ascending (canonical integer order); S' holds, at the first row of
+// every run of equal A' values, that value (taken out of the table's multiset), and at the other ("repeated") rows the
+// table values that are left over, in ascending order handed to the repeated rows from the LAST one backwards
+// (upstream pops them off a stack).  Then A'[i] == S'[i] or A'[i] == A'[i - 1] on every row, which is what the lookup
+// argument's grand product checks.
+// halo2-base only looks values up in a range table (cells below 2^lookup_bits), so the sort is a counting
+// sort over 2^max_bits bins: no comparison sort of 254-bit keys.  One 1024-thread workgroup per input column.
+#define LP_THREADS 1024
+__device__ __forceinline__ bool small_canonical(const u256& mont, uint32_t max_bits, uint32_t* v) {
+  const u256 c = from_mont<Fr>(mont);
+  uint32_t hi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) hi |= c.w[i];
+  *v = c.w[0];
+  return hi == 0 && (max_bits >= 32 || (c.w[0] >> max_bits) == 0);
+}
+__global__ __launch_bounds__(256) void k_lp_hist(const u256* __restrict__ col, uint64_t stride, uint64_t usable, uint32_t max_bits, uint32_t bins,
+                                                 uint32_t* __restrict__ hist, int* __restrict__ err) {
+  const u256* c = col + (uint64_t)blockIdx.y * stride;
+  uint32_t* h = hist + (uint64_t)blockIdx.y * bins;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < usable; r += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t v;
+    if (small_canonical(ld256(c + r), max_bits, &v)) atomicAdd(&h[v], 1u);
+    else atomicOr(err, 1);
+  }
+}
+// block-wide exclusive scan of one u32 per thread
+__device__ __forceinline__ uint32_t lp_block_scan(uint32_t v, uint32_t* sh, uint32_t* total) {
+  const uint32_t t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (uint32_t o = 1; o < LP_THREADS; o <<= 1) {
+    uint32_t x = t >= o ? sh[t - o] : 0u;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  const uint32_t inc = sh[t];
+  *total = sh[LP_THREADS - 1];
+  __syncthreads();
+  return inc - v;
+}
+// per column: off[v] = rows before the run of v, dist[v] = distinct input values <= v, lpre[v] = left-over table values < v
+__global__ __launch_bounds__(LP_THREADS) void k_lp_scan(const uint32_t* __restrict__ in_hist, const uint32_t* __restrict__ tab_hist, uint32_t bins,
+                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ dist, uint32_t* __restrict__ lpre,
+                                                        uint32_t* __restrict__ totals /* per column: repeated rows, left-over */, int* __restrict__ err) {
+  __shared__ uint32_t sh[LP_THREADS];
+  const uint64_t col = blockIdx.x;
+  const uint32_t* ih = in_hist + col * bins;
+  const uint32_t per = (bins + LP_THREADS - 1) / LP_THREADS, lo = threadIdx.x * per, hi = lo + per < bins ? lo + per : bins;
+  uint32_t c_sum = 0, d_sum = 0, l_sum = 0;
+  for (uint32_t v = lo; v < hi; v++) {
+    const uint32_t c = ih[v], t = tab_hist[v];
+    c_sum += c;
+    d_sum += c ? 1u : 0u;
+    if (c && !t) atomicOr(err, 2);  // an input value that is not in the table: the reference panics
+    l_sum += t - (c && t ? 1u : 0u);
+  }
+  uint32_t tot_c, tot_d, tot_l;
+  uint32_t c_pre = lp_block_scan(c_sum, sh, &tot_c);
+  uint32_t d_pre = lp_block_scan(d_sum, sh, &tot_d);
+  uint32_t l_pre = lp_block_scan(l_sum, sh, &tot_l);
+  for (uint32_t v = lo; v < hi; v++) {
+    const uint32_t c = ih[v], t = tab_hist[v];
+    off[col * bins + v] = c_pre;
+    lpre[col * bins + v] = l_pre;
+    c_pre += c;
+    d_pre += c ? 1u : 0u;
+    dist[col * bins + v] = d_pre;
+    l_pre += t - (c && t ? 1u : 0u);
+  }
+  if (threadIdx.x == 0) {
+    totals[2 * col] = tot_c - tot_d;  // repeated rows
+    totals[2 * col + 1] = tot_l;      // left-over table values: must be the same number
+    if (tot_c - tot_d != tot_l) atomicOr(err, 4);
+  }
+}
+// largest index v in [0, bins) with a[v] <= x  (a non-decreasing, a[0] <= x)
+__device__ __forceinline__ uint32_t lp_upper(const uint32_t* __restrict__ a, uint32_t bins, uint32_t x) {
+  uint32_t lo = 0, hi = bins;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] <= x) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_lp_rows(const uint32_t* __restrict__ in_hist, const uint32_t* __restrict__ tab_hist, const uint32_t* __restrict__ off,
+                                                 const uint32_t* __restrict__ dist, const uint32_t* __restrict__ lpre, const uint32_t* __restrict__ totals,
+                                                 uint32_t bins, uint64_t usable, uint64_t n, u256* __restrict__ out_in, u256* __restrict__ out_tab) {
+  const uint64_t col = blockIdx.y;
+  const uint32_t *o = off + col * bins, *d = dist + col * bins, *lp = lpre + col * bins, *ih = in_hist + col * bins;
+  const uint32_t R = totals[2 * col];
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    u256 a = u256_zero(), t = u256_zero();
+    if (r < usable) {
+      // run of r: the last value v with off[v] <= r that actually occurs
+      uint32_t v = lp_upper(o, bins, (uint32_t)r);
+      while (ih[v] == 0) v--;  // empty bins share their successor's offset: step back to the occupied one
+      a = to_mont<Fr>(u256_from_u64(v));
+      if ((uint32_t)r == o[v]) {
+        t = a;  // first row of the run takes the value itself out of the table
+      } else {
+        const uint32_t rank = (uint32_t)r - d[v];        // repeated rows before this one
+        const uint32_t k = R - 1 - rank;                 // left-over values are handed out from the last repeated row backwards
+        uint32_t u = lp_upper(lp, bins, k);
+        // bins without left-over share their successor's prefix: the owner of item k is the last bin with lpre <= k that has any
+        while (tab_hist[u] - (ih[u] && tab_hist[u] ? 1u : 0u) == 0) u--;
+        t = to_mont<Fr>(u256_from_u64(u));
+      }
+    }
+    st256(out_in + col * n + r, a);
+    st256(out_tab + col * n + r, t);
+  }
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -202,6 +320,55 @@ int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const v
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(u256), hipMemcpyDeviceToHost, cx.stream));
   VDB_HIP(hipStreamSynchronize(cx.stream));
+  return VDB_OK;
+}
+
+int vdb_lookup_permute_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,
+                           vdb_fr* permuted_input_dev, vdb_fr* permuted_table_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(input_dev && table_dev && permuted_input_dev && permuted_table_dev && usable_rows <= n && max_bits >= 1 && max_bits <= 20, "bad argument");
+  if (n_cols == 0 || n == 0) return VDB_OK;
+  Context& cx = ctx();
+  const uint32_t bins = 1u << max_bits;
+  // scratch: table histogram, then per column: input histogram, off, dist, lpre (bins each) and two totals; one error word
+  const size_t words = (size_t)bins + n_cols * ((size_t)4 * bins + 2) + 16;
+  uint32_t* buf = (uint32_t*)scratch_get(5, words * sizeof(uint32_t));
+  if (!buf) return VDB_ERR_OOM;
+  int* derr = (int*)buf;
+  uint32_t* tab_hist = buf + 16;
+  uint32_t* in_hist = tab_hist + bins;
+  uint32_t* off = in_hist + n_cols * bins;
+  uint32_t* dist = off + n_cols * bins;
+  uint32_t* lpre = dist + n_cols * bins;
+  uint32_t* totals = lpre + n_cols * bins;
+  VDB_HIP(hipMemsetAsync(buf, 0, (16 + (size_t)bins * (1 + n_cols)) * sizeof(uint32_t), cx.stream));
+  const unsigned gx = (unsigned)((usable_rows + 255) / 256 > 0 ? ((usable_rows + 255) / 256 < 256 ? (usable_rows + 255) / 256 : 256) : 1);
+  {
+    VDB_PROF("k_lp_hist");
+    hipLaunchKernelGGL(k_lp_hist, dim3(gx, 1), dim3(256), 0, cx.stream, as_u256(table_dev), (uint64_t)0, (uint64_t)usable_rows, max_bits, bins, tab_hist, derr);
+    hipLaunchKernelGGL(k_lp_hist, dim3(gx, (unsigned)n_cols), dim3(256), 0, cx.stream, as_u256(input_dev), (uint64_t)n, (uint64_t)usable_rows, max_bits, bins,
+                     in_hist, derr);
+  }
+  VDB_LAUNCH_CHECK();
+  {
+    VDB_PROF("k_lp_scan");
+    hipLaunchKernelGGL(k_lp_scan, dim3((unsigned)n_cols), dim3(LP_THREADS), 0, cx.stream, in_hist, tab_hist, bins, off, dist, lpre, totals, derr);
+  }
+  VDB_LAUNCH_CHECK();
+  int h = 0;
+  VDB_HIP(hipMemcpyAsync(&h, derr, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  if (h) {
+    set_error(h & 1 ? "lookup_permute: a value is not below 2^max_bits" : "lookup_permute: an input value does not occur in the table (the reference panics)");
+    return VDB_ERR_DOMAIN;
+  }
+  const unsigned gr = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  {
+    VDB_PROF("k_lp_rows");
+    hipLaunchKernelGGL(k_lp_rows, dim3(gr, (unsigned)n_cols), dim3(256), 0, cx.stream, in_hist, tab_hist, off, dist, lpre, totals, bins, (uint64_t)usable_rows,
+                     (uint64_t)n, as_u256(permuted_input_dev), as_u256(permuted_table_dev));
+  }
+  VDB_LAUNCH_CHECK();
   return VDB_OK;
 }
 

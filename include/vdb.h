@@ -228,6 +228,15 @@ int vdb_grand_product_dev(const vdb_fr *num_dev, const vdb_fr *den_dev, size_t n
 /* out[c] = sum_i coeff[c][i] * x^i for n_cols coefficient-form polynomials of n coefficients (halo2 eval_polynomial, the
  * opening evaluations of the advice polynomials).  coeff_dev: device; x: one field element on the host; out_host: host. */
 int vdb_eval_polys_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *out_host);
+/* Lookup argument, permuted columns (halo2 plonk/lookup/prover.rs permute_expression_pair) for range-table lookups: per
+ * input column, over rows [0, usable_rows): permuted_input = the input values in ascending canonical order;
+ * permuted_table = at the first row of every run of equal values that value, elsewhere the table's left-over values in
+ * ascending order assigned from the last repeated row backwards; rows >= usable_rows are zeroed (the caller adds the
+ * blinding rows).  All values must be canonical integers below 2^max_bits (max_bits <= 20: a counting sort) and every
+ * input value must occur in the table, otherwise VDB_ERR_DOMAIN (the reference panics).
+ * input_dev, permuted_*_dev: n_cols x n; table_dev: one column of n. */
+int vdb_lookup_permute_dev(const vdb_fr *input_dev, const vdb_fr *table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,
+                           vdb_fr *permuted_input_dev, vdb_fr *permuted_table_dev);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

@@ -136,6 +136,33 @@ def eval_polys(coeffs, x):
     return out
 
 
+def lookup_permute(input_vals, table_vals):
+    """halo2 plonk/lookup/prover.rs `permute_expression_pair` over the usable rows, restated literally on canonical
+    integers ([UPSTREAM-RECALL]): sorted input; the table value at the first row of each run, the left-over table values
+    (ascending) popped onto the repeated rows from the last one backwards.  Returns (permuted_input, permuted_table) as
+    lists of ints; raises ValueError where upstream panics (an input value that the table does not hold)."""
+    a = sorted(int(v) for v in input_vals)
+    left = {}
+    for v in table_vals:
+        left[int(v)] = left.get(int(v), 0) + 1
+    s = [0] * len(a)
+    repeated = []
+    for row, v in enumerate(a):
+        if row == 0 or v != a[row - 1]:
+            s[row] = v
+            if left.get(v, 0) == 0:
+                raise ValueError("input value not in table")
+            left[v] -= 1
+        else:
+            repeated.append(row)
+    for v in sorted(left):
+        for _ in range(left[v]):
+            s[repeated.pop()] = v
+    if repeated:
+        raise ValueError("table smaller than the input")
+    return a, s
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i] per column (zero denominators invert to zero)."""
     num = np.ascontiguousarray(num, dtype=np.uint64)

@@ -72,3 +72,47 @@ def test_eval_of_interpolant_returns_the_lagrange_values(api, O):
     for j in (0, 1, 2, 12345, (1 << k) - 1):
         x = O.fr_from_ints([pow(O.fr_to_ints(w.reshape(1, 4))[0], j, O.R_MOD)])[0]
         assert np.array_equal(api.eval_polys(coeffs, x), cols[:, j])
+
+
+def _range_table(O, n, bits):
+    """halo2-base range table column: 0 .. 2^bits - 1 in the first rows, zero padding below"""
+    return O.fr_from_ints([i if i < (1 << bits) else 0 for i in range(n)])
+
+
+@pytest.mark.parametrize("n,usable,bits,n_cols", [(64, 58, 4, 2), (1024, 1018, 8, 3), (4096, 4090, 11, 2), (65536, 65530, 15, 2)])
+def test_lookup_permute_matches_oracle(api, O, n, usable, bits, n_cols):
+    rng = np.random.default_rng(41 * bits + n_cols)
+    table = _range_table(O, n, bits)
+    ins = []
+    for c in range(n_cols):
+        v = rng.integers(0, 1 << bits, size=n)
+        if c == 1:
+            v[: n // 2] = 0          # long run of zeros (the padding cells of a lookup column)
+        ins.append(O.fr_from_ints([int(x) for x in v]))
+    ins = np.stack(ins)
+    got_a, got_s = api.lookup_permute(ins, table, usable, bits)
+    tab_ints = O.fr_to_ints(table[:usable])
+    for c in range(n_cols):
+        want_a, want_s = O.lookup_permute(O.fr_to_ints(ins[c, :usable]), tab_ints)
+        assert O.fr_to_ints(got_a[c, :usable]) == want_a
+        assert O.fr_to_ints(got_s[c, :usable]) == want_s
+        assert not got_a[c, usable:].any() and not got_s[c, usable:].any()
+        # what the lookup argument needs: permutations, and A'[i] in {S'[i], A'[i-1]}
+        assert sorted(want_s) == sorted(tab_ints)
+        assert all(want_a[i] == want_s[i] or (i and want_a[i] == want_a[i - 1]) for i in range(usable))
+
+
+def test_lookup_permute_errors(api, O):
+    n, usable, bits = 256, 250, 6
+    table = _range_table(O, n, bits)
+    ok = O.fr_from_ints([i % 64 for i in range(n)]).reshape(1, n, 4)
+    api.lookup_permute(ok, table, usable, bits)
+    bad = ok.copy()
+    bad[0, 7] = O.fr_from_ints([64])[0]                 # not below 2^bits
+    with pytest.raises(api.VdbError) as e:
+        api.lookup_permute(bad, table, usable, bits)
+    assert e.value.code == -5
+    short_table = O.fr_from_ints([i if i < 32 else 0 for i in range(n)])   # 40 is not in this table
+    with pytest.raises(api.VdbError) as e:
+        api.lookup_permute(ok, short_table, usable, bits)
+    assert e.value.code == -5

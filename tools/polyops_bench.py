@@ -33,5 +33,25 @@ for it in range(3):
     ms_ev = api.timer_stop()
 print(json.dumps({"kernel": "k_eval_polys", "n_cols": n_cols, "n": n, "ms": round(ms_ev, 3), "coeff_per_s": rows / ms_ev * 1e3,
                   "algorithmic_GBps": 32.0 * rows / ms_ev / 1e6, "hbm_frac": 32.0 * rows / ms_ev / 1e6 / 8000.0}))
+# lookup argument: C4's 1,345 lookup columns of 15-bit cells against the range table
+lk_cols, bits, usable = 1345, 15, n - 6
+vals = rng.integers(0, 1 << bits, size=lk_cols * n, dtype=np.uint64)
+R_MONT = (1 << 256) % 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+mont = lambda arr: api.fr_from_canonical(np.stack([arr, np.zeros_like(arr), np.zeros_like(arr), np.zeros_like(arr)], axis=1))
+d_in = api.DeviceBuffer(lk_cols * n * 32)
+for c0 in range(0, lk_cols, 128):
+    c1 = min(lk_cols, c0 + 128)
+    d_in.upload(mont(vals[c0 * n: c1 * n]), offset=c0 * n * 32)
+tab = np.arange(n, dtype=np.uint64)
+tab[tab >= (1 << bits)] = 0
+d_tab = api.DeviceBuffer(n * 32)
+d_tab.upload(mont(tab))
+d_oa, d_os = api.DeviceBuffer(lk_cols * n * 32), api.DeviceBuffer(lk_cols * n * 32)
+for it in range(3):
+    api.timer_start()
+    check(lib.vdb_lookup_permute_dev(d_in.ptr, d_tab.ptr, ctypes.c_size_t(lk_cols), ctypes.c_size_t(n), ctypes.c_size_t(usable), bits, d_oa.ptr, d_os.ptr))
+    ms_lp = api.timer_stop()
+print(json.dumps({"kernel": "k_lp_hist + k_lp_scan + k_lp_rows", "n_cols": lk_cols, "n": n, "bits": bits, "ms": round(ms_lp, 3),
+                  "rows_per_s": lk_cols * n / ms_lp * 1e3, "algorithmic_GBps": 96.0 * lk_cols * n / ms_lp / 1e6}))
 print(json.dumps({"kernel": "k_grand_product", "n_cols": n_cols, "n": n, "ms": round(ms, 3), "rows_per_s": rows / ms * 1e3, "algorithmic_GBps": 224.0 * rows / ms / 1e6,
                   "fr_mul_per_s": 5.0 * rows / ms * 1e3}))

@@ -338,6 +338,20 @@ def poseidon_permute(states):
 
 
 # ---------------------------------------------------------------- device buffers
+def extended_to_coeff(ext_cols, k, ext_k=2):
+    """inverse of coeff_to_extended; ext_cols: (n_cols, 2^(k+ext_k), 4) on the host"""
+    lib = _lib.init()
+    e = _fr(ext_cols)
+    buf = DeviceBuffer(max(e.nbytes, 32))
+    try:
+        buf.upload(e)
+        check(lib.vdb_extended_to_coeff_dev(buf.ptr, _sz(e.shape[0]), ctypes.c_uint32(k), ctypes.c_uint32(ext_k)))
+        sync()
+        return buf.download(e.shape)
+    finally:
+        buf.free()
+
+
 def eval_polys(coeffs, x):
     """out[c] = sum_i coeffs[c][i] * x^i; coeffs: (n_cols, n, 4) uint64 on the host (uploaded), x: (4,)"""
     lib = _lib.init()

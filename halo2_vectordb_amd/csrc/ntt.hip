@@ -30,6 +30,7 @@ struct NttPass {
   uint32_t prevS[NTT_MAX_PASSES]; // their sizes (S_0 .. S_{L-2})
   uint32_t first;                 // this is pass 0 (input staging rules apply)
   uint32_t coset;                 // multiply input element e by zeta^(e mod 3)
+  uint32_t coset_out;             // last pass: multiply output element e by zeta^-(e mod 3) (extended_to_coeff)
   uint32_t scale;                 // multiply output by n^{-1}
   uint32_t s0;                    // first butterfly stage to run (2 when the top three quarters of every row are zero padding)
   uint64_t in_len;                // elements >= in_len of the input column read as zero
@@ -37,7 +38,7 @@ struct NttPass {
   uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
   const ColSrc* srcs;             // pass 0 only: columns still lying in a witness stream (null: read `in`)
   uint32_t n_blind;
-  u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery
+  u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery (zeta^-1 = zeta^2: the same two serve coset_out)
   uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
 };
 
@@ -245,8 +246,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   }
   // write out: the inter-pass twiddle product (or the 1/n product of an inverse transform) brings the value below 2r
   // on its own; a forward transform's last pass reduces without a product (l9_canon_wide)
-  L9 FIN;
+  L9 FIN, ZO1, ZO2;
   if (LAST && p.scale) FIN = l9_split(p.fin);
+  if (LAST && p.coset_out) {
+    ZO1 = l9_split(p.zeta2);  // zeta^-1
+    ZO2 = l9_split(p.zeta1);  // zeta^-2
+  }
   // inter-pass twiddles are fetched for all of the thread's elements up front: on gfx9 a load that follows stores
   // waits for their acknowledgement too (one in-order vmcnt), which would put a store round trip between elements
   constexpr uint32_t EPT = NTT_TILE / NTT_THREADS;
@@ -290,7 +295,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         }
         pos += (uint64_t)q << (p.log_n - S);
       }
-      st256(cout + pos, p.scale ? l9_canon(l9_mul(v, FIN)) : l9_canon_wide(v));
+      if (p.scale) {
+        v = l9_mul(v, FIN);  // single-pass inverse transform: 1/n here
+        const uint32_t r3 = p.coset_out ? (uint32_t)(pos % 3) : 0u;
+        if (r3) v = l9_mul(v, r3 == 1 ? ZO1 : ZO2);
+        st256(cout + pos, l9_canon(v));
+      } else {
+        const uint32_t r3 = p.coset_out ? (uint32_t)(pos % 3) : 0u;
+        st256(cout + pos, r3 ? l9_canon(l9_mul(v, r3 == 1 ? ZO1 : ZO2)) : l9_canon_wide(v));
+      }
     }
   }
 }
@@ -341,7 +354,7 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, const u256& f
 // Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
 // result goes to out (stride n) or back into data when out == nullptr.
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind) {
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out) {
   Context& c = ctx();
   if (n_cols == 0) return VDB_OK;
   if (log_n > 26) {
@@ -422,6 +435,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       memcpy(p.ckp, ckp, sizeof(ckp));
       bool last = (l == L - 1);
       p.scale = last && scale_ninv && L == 1;
+      p.coset_out = last && coset_out;
       // zero-padded input (coeff_to_extended): when rows of pass 0 run along the top digit and only their first
       // quarter is data, stages 0 and 1 are pure replication
       p.s0 = (l == 0 && !last && S[0] >= 3 && in_len * 4 <= n) ? 2 : 0;
@@ -539,7 +553,7 @@ int vdb_ntt_batch_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t log_n, const vdb
   VDB_ARG(cols_dev && omega, "null pointer");
   u256 w;
   memcpy(&w, omega, 32);
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0, nullptr, 0);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0, nullptr, 0, false);
 }
 int vdb_ntt_batch(vdb_fr* const* cols, size_t n_cols, uint32_t log_n, const vdb_fr* omega, int flags) {
   VDB_REQUIRE_INIT();
@@ -556,13 +570,13 @@ int vdb_lagrange_to_coeff_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
   VDB_ARG(cols_dev && k <= 26, "bad argument");
   u256 w = mont_inv<Fr>(host_root_of_unity(k));
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0, nullptr, 0);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0, nullptr, 0, false);
 }
 int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc* src_dev, vdb_fr* coeff_dev, size_t n_cols, uint32_t k, uint32_t n_blind) {
   VDB_REQUIRE_INIT();
   VDB_ARG(src_dev && coeff_dev && k <= 26 && k > 10, "bad argument (column sources are supported for k > 10)");
   u256 w = mont_inv<Fr>(host_root_of_unity(k));
-  return ntt_dev(nullptr, as_u256(coeff_dev), n_cols, k, w, true, false, 0, reinterpret_cast<const ColSrc*>(src_dev), n_blind);
+  return ntt_dev(nullptr, as_u256(coeff_dev), n_cols, k, w, true, false, 0, reinterpret_cast<const ColSrc*>(src_dev), n_blind, false);
 }
 int vdb_lagrange_to_coeff(vdb_fr* const* cols, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
@@ -579,7 +593,13 @@ int vdb_coeff_to_extended_dev(const vdb_fr* coeff_dev, vdb_fr* ext_dev, size_t n
   VDB_REQUIRE_INIT();
   VDB_ARG(coeff_dev && ext_dev && k + ext_k <= 26, "bad argument");
   u256 w = host_root_of_unity(k + ext_k);
-  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0);
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0, false);
+}
+int vdb_extended_to_coeff_dev(vdb_fr* ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(ext_dev && k + ext_k <= 26, "bad argument");
+  u256 w = mont_inv<Fr>(host_root_of_unity(k + ext_k));
+  return ntt_dev(as_u256(ext_dev), nullptr, n_cols, k + ext_k, w, true, false, 0, nullptr, 0, true);
 }
 int vdb_coeff_to_extended(const vdb_fr* const* coeff_cols, vdb_fr* const* ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();

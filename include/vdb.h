@@ -240,6 +240,9 @@ int vdb_lookup_permute_dev(const vdb_fr *input_dev, const vdb_fr *table_dev, siz
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);
+/* EvaluationDomain::extended_to_coeff without the final truncation (the way back for h(X)): in place, per
+ * column of 2^(k+ext_k) evaluations on the extended coset -> the 2^(k+ext_k) coefficients. */
+int vdb_extended_to_coeff_dev(vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_fr_root_of_unity(uint32_t k, vdb_fr *out);
 
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,

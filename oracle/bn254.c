@@ -694,6 +694,18 @@ void orc_coeff_to_extended(fr_t *out, const fr_t *coeffs, unsigned k, unsigned e
   orc_fr_root_of_unity(&omega_e, k + ext);
   orc_ntt(out, k + ext, &omega_e);
 }
+/* halo2 EvaluationDomain::extended_to_coeff, without the final truncation: inverse NTT over the extended domain, then
+ * distribute_powers_zeta(out of the coset): coefficient i times [1, ZETA^2, ZETA][i mod 3]  [UPSTREAM-RECALL] */
+void orc_extended_to_coeff(fr_t *a, unsigned k, unsigned ext) {
+  orc_init();
+  fr_t z2;
+  fr_mul(&z2, &FR_ZETA, &FR_ZETA);
+  orc_lagrange_to_coeff(a, k + ext); /* same arithmetic: inverse transform of size 2^(k+ext) with 1/N */
+  for (size_t i = 0; i < ((size_t)1 << (k + ext)); i++) {
+    if (i % 3 == 1) fr_mul(&a[i], &a[i], &z2);
+    if (i % 3 == 2) fr_mul(&a[i], &a[i], &FR_ZETA);
+  }
+}
 typedef struct {
   fr_t *cols, *ext;
   size_t c0, c1;

@@ -120,6 +120,7 @@ void orc_lagrange_to_coeff(fr_t *a, unsigned k);
 /* EvaluationDomain::coeff_to_extended: zeta-coset scaling, zero-pad to 2^(k+ext), forward NTT.
  * in: n=2^k coeffs; out: 2^(k+ext) evaluations */
 void orc_coeff_to_extended(fr_t *out, const fr_t *coeffs, unsigned k, unsigned ext);
+void orc_extended_to_coeff(fr_t *a, unsigned k, unsigned ext);
 void orc_ntt_batch(fr_t *cols, size_t n_cols, unsigned log_n, const fr_t *omega, int threads);
 void orc_lde_batch(fr_t *ext_out, fr_t *cols_inout, size_t n_cols, unsigned k, unsigned ext, int threads);
 

@@ -288,6 +288,14 @@ def ntt_batch(cols, omega, threads=1):
     return cols
 
 
+def extended_to_coeff(ext_cols, k, ext=2):
+    """inverse of coeff_to_extended per column (all 2^(k+ext) coefficients; the upper ones are zero for a degree < 2^k input)"""
+    a = np.array(ext_cols, dtype=np.uint64, copy=True)
+    for c in range(a.shape[0]):
+        lib().orc_extended_to_coeff(_p(a[c]), ctypes.c_uint(k), ctypes.c_uint(ext))
+    return a
+
+
 def lde_batch(cols, ext=2, threads=1):
     """lagrange_to_coeff then coeff_to_extended for each column; returns (coeffs, extended)."""
     cols = np.array(cols, dtype=np.uint64, copy=True)

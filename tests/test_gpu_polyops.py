@@ -116,3 +116,15 @@ def test_lookup_permute_errors(api, O):
     with pytest.raises(api.VdbError) as e:
         api.lookup_permute(ok, short_table, usable, bits)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("k,ext", [(3, 2), (8, 2), (9, 1), (12, 2), (16, 2)])
+def test_extended_to_coeff_roundtrip_and_oracle(api, O, k, ext):
+    """extended_to_coeff(coeff_to_extended(c)) == c zero-extended, and bit-exact against the oracle on arbitrary input"""
+    rng = np.random.default_rng(90 + k)
+    coeffs = O.random_fr(rng, 2 << k).reshape(2, 1 << k, 4)
+    e = api.coeff_to_extended(coeffs, ext)
+    back = api.extended_to_coeff(e, k, ext)
+    assert np.array_equal(back[:, : 1 << k], coeffs) and not back[:, 1 << k:].any()
+    arbitrary = O.random_fr(rng, 1 << (k + ext)).reshape(1, 1 << (k + ext), 4)
+    assert np.array_equal(api.extended_to_coeff(arbitrary, k, ext), O.extended_to_coeff(arbitrary, k, ext))

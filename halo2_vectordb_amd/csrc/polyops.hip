@@ -282,6 +282,34 @@ __global__ __launch_bounds__(256) void k_lp_rows(const uint32_t* __restrict__ in
   }
 }
 
+// ---- gate part of the quotient numerator on the extended coset ---------------------------------------------------------
+// halo2-base's one custom gate (FlexGateConfig, "vertical" strategy): for every advice column i with selector q_i,
+//     q_i(X) * (a_i(X) + a_i(wX) * a_i(w^2 X) - a_i(w^3 X)) = 0 on the rows,
+// i.e. cells [a, b, c, d] in four consecutive rows satisfy a + b c = d where q = 1.  The prover accumulates the gates
+// with powers of the challenge y (halo2 evaluates them column after column by Horner's rule: acc = acc * y + gate,
+// [UPSTREAM-RECALL] for the order only).  On the extended coset of size 2^(k+e) a rotation by one row is a step of 2^e.
+// One thread per extended row, columns in a loop: consecutive lanes read consecutive rows of the same column.
+__global__ __launch_bounds__(256) void k_gate_eval(const u256* __restrict__ adv, const u256* __restrict__ sel, uint64_t n_cols, uint32_t log_ne, uint32_t e,
+                                                   u256 y, u256* __restrict__ acc) {
+  const uint64_t ne = 1ull << log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ne) return;
+  const uint64_t mask = ne - 1, r = 1ull << e;
+  u256 h = ld256(acc + j);
+  for (uint64_t c = 0; c < n_cols; c++) {
+    const u256* a = adv + c * ne;
+    const u256 q = ld256(sel + c * ne + j);
+    u256 g = fr_sub(fr_add(ld256(a + j), fr_mul(ld256(a + ((j + r) & mask)), ld256(a + ((j + 2 * r) & mask)))), ld256(a + ((j + 3 * r) & mask)));
+    h = fr_add(fr_mul(h, y), fr_mul(q, g));
+  }
+  st256(acc + j, h);
+}
+// h[j] *= t[j mod 2^e],  t[m] = 1 / (zeta^n * w_{2^e}^m - 1): division by the vanishing polynomial X^n - 1 on the coset
+__global__ __launch_bounds__(256) void k_mul_periodic(u256* __restrict__ h, uint64_t ne, const u256* __restrict__ t, uint32_t period_mask) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ne) return;
+  st256(h + j, fr_mul(ld256(h + j), ld256(t + (j & period_mask))));
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -323,6 +351,47 @@ int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const v
   return VDB_OK;
 }
 
+int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(adv_ext_dev && sel_ext_dev && y && acc_dev && k + ext_k <= 28, "bad argument");
+  u256 yv;
+  memcpy(&yv, y, 32);
+  const uint64_t ne = 1ull << (k + ext_k);
+  {
+    VDB_PROF("k_gate_eval");
+    hipLaunchKernelGGL(k_gate_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(adv_ext_dev), as_u256(sel_ext_dev), (uint64_t)n_cols,
+                     k + ext_k, ext_k, yv, as_u256(acc_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_divide_by_vanishing_dev(vdb_fr* h_ext_dev, uint32_t k, uint32_t ext_k) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(h_ext_dev && k + ext_k <= 28 && ext_k >= 1 && ext_k <= 8, "bad argument");
+  Context& cx = ctx();
+  const uint32_t period = 1u << ext_k;
+  // X^n on the coset point zeta * w_ext^j is zeta^n * w_{2^e}^j (zeta^3 = 1, n = 2^k: zeta^n = zeta or zeta^2)
+  u256 zn = host_zeta();
+  for (uint32_t i = 0; i < k; i++) zn = fr_mul(zn, zn);
+  const u256 wp = host_root_of_unity(ext_k);
+  std::vector<u256> t(period);
+  u256 cur = zn;
+  for (uint32_t m = 0; m < period; m++) {
+    t[m] = mont_inv<Fr>(fr_sub(cur, mont_one<Fr>()));  // never zero: the coset misses the 2^k-th roots of unity
+    cur = fr_mul(cur, wp);
+  }
+  u256* dt = (u256*)scratch_get(5, period * sizeof(u256));
+  if (!dt) return VDB_ERR_OOM;
+  VDB_HIP(hipMemcpyAsync(dt, t.data(), period * sizeof(u256), hipMemcpyHostToDevice, cx.stream));
+  const uint64_t ne = 1ull << (k + ext_k);
+  {
+    VDB_PROF("k_mul_periodic");
+    hipLaunchKernelGGL(k_mul_periodic, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(h_ext_dev), ne, dt, period - 1);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipStreamSynchronize(cx.stream));  // t is a host vector
+  return VDB_OK;
+}
 int vdb_lookup_permute_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,
                            vdb_fr* permuted_input_dev, vdb_fr* permuted_table_dev) {
   VDB_REQUIRE_INIT();

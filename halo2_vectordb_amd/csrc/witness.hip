@@ -857,6 +857,20 @@ __global__ __launch_bounds__(256) void k_layout_const_mask(const uint8_t* __rest
   uint64_t len = col < n_bp ? bp[col] + 1 : n_cells - start;
   mask[idx] = row < len ? (flags[start + row] >> 1) & 1 : 0;
 }
+// column-layout image of the gate selectors as field elements: q[col][row] = 1 where a gate starts (bit 0 of the flag byte)
+__global__ __launch_bounds__(256) void k_layout_selectors(const uint8_t* __restrict__ flags, uint64_t n_cells, const uint64_t* __restrict__ starts,
+                                                          const uint64_t* __restrict__ bp, uint64_t n_bp, uint32_t k, u256* __restrict__ q) {
+  const uint64_t rows = 1ull << k;
+  uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (n_bp + 1) * rows) return;
+  uint64_t col = idx >> k, row = idx & (rows - 1);
+  uint64_t start = starts[col];
+  uint64_t len = col < n_bp ? bp[col] + 1 : n_cells - start;
+  // the last cell of a column that is not the last one is the cell the next column starts with again (break points sit on
+  // gate boundaries: it closes a gate here and opens one there), so its selector is enabled in the next column only
+  const uint64_t sel_len = col < n_bp ? len - 1 : len;
+  st256(q + idx, (row < sel_len && (flags[start + row] & 1)) ? mont_one<Fr>() : u256_zero());
+}
 // scalars' = mask ? v : 0 (constant part) or mask ? 0 : v (variable part)
 __global__ __launch_bounds__(256) void k_mask_select(const u256* __restrict__ in, const uint8_t* __restrict__ mask, uint64_t n, int keep_const,
                                                      u256* __restrict__ out) {
@@ -1480,6 +1494,22 @@ int vdb_layout_const_mask_dev(const uint8_t* flags_dev, uint64_t n_cells, const 
   {
     VDB_PROF("k_layout_const_mask");
     hipLaunchKernelGGL(k_layout_const_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, flags_dev, n_cells, dst, dbp, n_bp, k, mask_dev);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  return VDB_OK;
+}
+int vdb_layout_selectors_dev(const uint8_t* flags_dev, uint64_t n_cells, const uint64_t* break_points, uint64_t n_bp, uint32_t k, vdb_fr* q_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(flags_dev && q_dev && (break_points || n_bp == 0) && k <= 28, "bad argument");
+  const uint64_t rows = 1ull << k;
+  uint64_t *dbp, *dst;
+  TRY(upload_break_points(break_points, n_bp, &dbp, &dst));
+  uint64_t total = (n_bp + 1) * rows;
+  {
+    VDB_PROF("k_layout_selectors");
+    hipLaunchKernelGGL(k_layout_selectors, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, flags_dev, n_cells, dst, dbp, n_bp, k,
+                     as_u256(q_dev));
   }
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipStreamSynchronize(ctx().stream));

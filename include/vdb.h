@@ -243,6 +243,16 @@ int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n
 /* EvaluationDomain::extended_to_coeff without the final truncation (the way back for h(X)): in place, per
  * column of 2^(k+ext_k) evaluations on the extended coset -> the 2^(k+ext_k) coefficients. */
 int vdb_extended_to_coeff_dev(vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);
+/* Gate part of the quotient numerator for halo2-base's vertical gate q * (a + b * c - d) with a, b, c, d in
+ * four consecutive rows of one advice column: acc[j] <- Horner over the n_cols columns of (acc * y + q_c[j] * gate_c[j]) on
+ * the extended coset of 2^(k+ext_k) points.  adv_ext_dev, sel_ext_dev: n_cols x 2^(k+ext_k) (vdb_coeff_to_extended_dev of
+ * the advice and selector polynomials); acc_dev: 2^(k+ext_k), read and written (zero it before the first call). */
+int vdb_gate_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *y, vdb_fr *acc_dev);
+/* EvaluationDomain::divide_by_vanishing_poly: h[j] /= (X^n - 1) at the j-th point of the extended coset, in place. */
+int vdb_divide_by_vanishing_dev(vdb_fr *h_ext_dev, uint32_t k, uint32_t ext_k);
+/* column-layout image of the gate selectors as field elements (keygen side; flags as for vdb_layout_const_mask_dev, bit 0):
+ * q_dev: (n_bp + 1) x 2^k, one where a gate starts. */
+int vdb_layout_selectors_dev(const uint8_t *flags_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, vdb_fr *q_dev);
 int vdb_fr_root_of_unity(uint32_t k, vdb_fr *out);
 
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,

@@ -33,6 +33,23 @@ for it in range(3):
     ms_ev = api.timer_stop()
 print(json.dumps({"kernel": "k_eval_polys", "n_cols": n_cols, "n": n, "ms": round(ms_ev, 3), "coeff_per_s": rows / ms_ev * 1e3,
                   "algorithmic_GBps": 32.0 * rows / ms_ev / 1e6, "hbm_frac": 32.0 * rows / ms_ev / 1e6 / 8000.0}))
+# gate numerator on the extended coset: 512 columns of 2^18 (any field elements do for timing)
+gc, k_, e_ = 512, 16, 2
+ne = 1 << (k_ + e_)
+d_adv, d_sel, d_acc = api.DeviceBuffer(gc * ne * 32), api.DeviceBuffer(gc * ne * 32), api.DeviceBuffer(ne * 32)
+for c0 in range(0, gc * ne * 32, raw.nbytes):
+    nb = min(raw.nbytes, gc * ne * 32 - c0)
+    check(lib.vdb_memcpy_d2d(ctypes.c_void_p(d_adv.ptr.value + c0), bufs[0].ptr, ctypes.c_size_t(nb)))
+    check(lib.vdb_memcpy_d2d(ctypes.c_void_p(d_sel.ptr.value + c0), bufs[1].ptr, ctypes.c_size_t(nb)))
+check(lib.vdb_memset_dev(d_acc.ptr, 0, ne * 32))
+for it in range(3):
+    api.timer_start()
+    check(lib.vdb_gate_eval_dev(d_adv.ptr, d_sel.ptr, ctypes.c_size_t(gc), k_, e_, api._p(x), d_acc.ptr))
+    ms_g = api.timer_stop()
+print(json.dumps({"kernel": "k_gate_eval", "n_cols": gc, "ext_rows": ne, "ms": round(ms_g, 3), "cells_per_s": gc * ne / ms_g * 1e3,
+                  "algorithmic_GBps": 64.0 * gc * ne / ms_g / 1e6, "fr_mul_per_s": 3.0 * gc * ne / ms_g * 1e3}))
+for b in (d_adv, d_sel, d_acc):
+    b.free()
 # lookup argument: C4's 1,345 lookup columns of 15-bit cells against the range table
 lk_cols, bits, usable = 1345, 15, n - 6
 vals = rng.integers(0, 1 << bits, size=lk_cols * n, dtype=np.uint64)

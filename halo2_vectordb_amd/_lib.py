@@ -76,6 +76,9 @@ _SIGNATURES = {
     "vdb_gate_eval_dev": [_P, _P, _SZ, _U32, _U32, _P, _P], "vdb_divide_by_vanishing_dev": [_P, _U32, _U32],
     "vdb_layout_selectors_dev": [_P, _U64, _P, _U64, _U32, _P],
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
+    "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
+    "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
+    "vdb_permutation_product_dev": [_P, _P, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_colsrc_build_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _U32, _P],
     "vdb_colsrc_build_lookup_dev": [_P, _U64, _U32, _U32, _U64, _U64, _P, _U32, _P],
     "vdb_msm_batch_src_dev_begin": [_P, _I, _P, _SZ, _SZ, _U32, _P, _P], "vdb_lagrange_to_coeff_src_dev": [_P, _P, _SZ, _U32, _U32],

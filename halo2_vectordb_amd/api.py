@@ -383,6 +383,75 @@ def lookup_permute(inputs, table, usable_rows, max_bits):
             b.free()
 
 
+def fr_delta():
+    """halo2curves bn256 Fr::DELTA (Montgomery)"""
+    out = np.zeros(4, dtype=np.uint64)
+    check(_lib.load().vdb_fr_delta(_p(out)))
+    return out
+
+
+def _with_buffers(arrays, n_out_bytes, call):
+    bufs = [DeviceBuffer(max(a.nbytes, 32)) for a in arrays] + [DeviceBuffer(max(nb, 32)) for nb in n_out_bytes]
+    try:
+        for b, a in zip(bufs, arrays):
+            b.upload(a)
+        call(*[b.ptr for b in bufs])
+        sync()
+        return bufs[len(arrays):]
+    except Exception:
+        for b in bufs[len(arrays):]:
+            b.free()
+        raise
+    finally:
+        for b in bufs[: len(arrays)]:
+            b.free()
+
+
+def permutation_sigma(mapping, k, delta=None):
+    """mapping: (n_cols, 2^k) uint64 words col' << 32 | row'; returns the sigma columns (n_cols, 2^k, 4)"""
+    lib = _lib.init()
+    mapping = np.ascontiguousarray(mapping, dtype=np.uint64)
+    n_cols, n = mapping.shape
+    delta = fr_delta() if delta is None else _fr(delta)
+    (out,) = _with_buffers([mapping], [n_cols * n * 32],
+                           lambda m, o: check(lib.vdb_permutation_sigma_dev(m, _sz(n_cols), ctypes.c_uint32(k), _p(delta), o)))
+    try:
+        return out.download((n_cols, n, 4))
+    finally:
+        out.free()
+
+
+def permutation_product(cols, sigma, usable_rows, chunk_len, beta, gamma, delta=None):
+    """running products of the permutation argument, one column per chunk of chunk_len columns: (n_chunks, 2^k, 4)"""
+    lib = _lib.init()
+    cols, sigma = _fr(cols), _fr(sigma)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    k = n.bit_length() - 1
+    n_chunks = -(-n_cols // chunk_len)
+    delta = fr_delta() if delta is None else _fr(delta)
+    beta, gamma = _fr(beta), _fr(gamma)
+    (out,) = _with_buffers([cols, sigma], [n_chunks * n * 32], lambda c, s, o: check(lib.vdb_permutation_product_dev(
+        c, s, _sz(n_cols), ctypes.c_uint32(k), _sz(usable_rows), _sz(chunk_len), _p(beta), _p(gamma), _p(delta), o)))
+    try:
+        return out.download((n_chunks, n, 4))
+    finally:
+        out.free()
+
+
+def lookup_product(inputs, table, perm_inputs, perm_table, usable_rows, beta, gamma):
+    """running products of the lookup argument, one per input column: (n_cols, n, 4)"""
+    lib = _lib.init()
+    inputs, table, perm_inputs, perm_table = _fr(inputs), _fr(table), _fr(perm_inputs), _fr(perm_table)
+    n_cols, n = inputs.shape[0], inputs.shape[1]
+    beta, gamma = _fr(beta), _fr(gamma)
+    (out,) = _with_buffers([inputs, table, perm_inputs, perm_table], [n_cols * n * 32], lambda a, t, pa, pt, o: check(lib.vdb_lookup_product_dev(
+        a, t, pa, pt, _sz(n_cols), _sz(n), _sz(usable_rows), _p(beta), _p(gamma), o)))
+    try:
+        return out.download((n_cols, n, 4))
+    finally:
+        out.free()
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i]; num, den: (n_cols, n, 4) uint64 (Montgomery Fr)."""
     lib = _lib.init()

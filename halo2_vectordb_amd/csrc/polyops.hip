@@ -35,13 +35,14 @@ __device__ __forceinline__ u256 block_scan_mul(u256 v, u256* sh, bool rev) {
   return v;  // product of the values of threads 0 .. t (in scan order)
 }
 
-__global__ __launch_bounds__(GP_THREADS) void k_grand_product(const u256* __restrict__ num, const u256* __restrict__ den, u256* __restrict__ z, uint64_t n) {
+__global__ __launch_bounds__(GP_THREADS) void k_grand_product(const u256* __restrict__ num, const u256* __restrict__ den, u256* __restrict__ z, uint64_t n,
+                                                              uint64_t stride) {
   __shared__ u256 sh[GP_THREADS];
   __shared__ u256 s_dinv;
   const uint64_t col = blockIdx.x;
-  const u256* nu = num + col * n;
-  const u256* de = den + col * n;
-  u256* zo = z + col * n;
+  const u256* nu = num + col * stride;
+  const u256* de = den + col * stride;
+  u256* zo = z + col * stride;
   const uint64_t rows = n - 1;  // rows that enter the product
   const uint64_t E = (rows + GP_THREADS - 1) / GP_THREADS;
   const uint64_t lo = (uint64_t)threadIdx.x * E < rows ? (uint64_t)threadIdx.x * E : rows;
@@ -310,6 +311,88 @@ __global__ __launch_bounds__(256) void k_mul_periodic(u256* __restrict__ h, uint
   st256(h + j, fr_mul(ld256(h + j), ld256(t + (j & period_mask))));
 }
 
+// ---- product terms of the permutation and lookup arguments (halo2 plonk/permutation/prover.rs and
+// plonk/lookup/prover.rs commit_product, [UPSTREAM-RECALL] for the formulas) -------------------------------------------
+// pw[i] = beta * omega^i: one square-and-multiply per row, once per call
+__global__ __launch_bounds__(256) void k_beta_omega_powers(u256 omega, u256 beta, uint64_t n, u256* __restrict__ pw) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 acc = beta, b = omega;
+  for (uint64_t e = i; e; e >>= 1) {
+    if (e & 1) acc = fr_mul(acc, b);
+    b = fr_mul(b, b);
+  }
+  st256(pw + i, acc);
+}
+// sigma[c][row] = delta^c' * omega^row' for the cell (c', row') the permutation sends (c, row) to; map = c' << 32 | row'
+__global__ __launch_bounds__(256) void k_perm_sigma(const uint64_t* __restrict__ map, uint64_t n_cols, uint64_t n, const u256* __restrict__ wpow /* omega^i */,
+                                                    const u256* __restrict__ dpow /* delta^c */, u256* __restrict__ sigma, int* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cols * n) return;
+  const uint64_t m = map[i], c = m >> 32, r = m & 0xffffffffull;
+  if (c >= n_cols || r >= n) {
+    *err = 1;
+    return;
+  }
+  st256(sigma + i, fr_mul(ld256(dpow + c), ld256(wpow + r)));
+}
+// One thread per (row, chunk of columns):  num = prod_c (v_c + delta^c * beta * omega^row + gamma),
+//                                          den = prod_c (v_c + beta * sigma_c[row] + gamma).
+__global__ __launch_bounds__(256) void k_perm_terms(const u256* __restrict__ cols, const u256* __restrict__ sigma, uint64_t n_cols, uint64_t n, uint64_t rows,
+                                                    uint32_t chunk_len, const u256* __restrict__ bw /* beta omega^row */, u256 beta, u256 gamma, u256 delta,
+                                                    const u256* __restrict__ dstart /* delta^(chunk * chunk_len) */, u256* __restrict__ num,
+                                                    u256* __restrict__ den) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+  if (row >= rows) return;
+  const uint64_t c0 = chunk * chunk_len, c1 = c0 + chunk_len < n_cols ? c0 + chunk_len : n_cols;
+  u256 cur = fr_mul(ld256(bw + row), ld256(dstart + chunk));
+  u256 nu = mont_one<Fr>(), de = nu;
+  for (uint64_t c = c0; c < c1; c++) {
+    const u256 v = fr_add(ld256(cols + c * n + row), gamma);
+    de = fr_mul(de, fr_add(v, fr_mul(beta, ld256(sigma + c * n + row))));
+    nu = fr_mul(nu, fr_add(v, cur));
+    cur = fr_mul(cur, delta);
+  }
+  st256(num + chunk * n + row, nu);
+  st256(den + chunk * n + row, de);
+}
+// num = (A + beta)(S + gamma),  den = (A' + beta)(S' + gamma); the table column is shared by all input columns
+__global__ __launch_bounds__(256) void k_lookup_terms(const u256* __restrict__ a, const u256* __restrict__ tab, const u256* __restrict__ pa, const u256* __restrict__ pt,
+                                                      uint64_t n, uint64_t rows, u256 beta, u256 gamma, u256* __restrict__ num, u256* __restrict__ den) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+  if (row >= rows) return;
+  const uint64_t i = col * n + row;
+  st256(num + i, fr_mul(fr_add(ld256(a + i), beta), fr_add(ld256(tab + row), gamma)));
+  st256(den + i, fr_mul(fr_add(ld256(pa + i), beta), fr_add(ld256(pt + i), gamma)));
+}
+// The permutation product runs on from one chunk of columns to the next: z_c starts where z_{c-1} ended.  The chunks'
+// products are computed independently from one; f[c] = prod_{c' < c} z_c'[last] puts them on one chain.
+__global__ __launch_bounds__(GP_THREADS) void k_chain_factors(const u256* __restrict__ z, uint64_t n_chunks, uint64_t stride, uint64_t last, u256* __restrict__ f) {
+  __shared__ u256 sh[GP_THREADS];
+  const uint64_t E = (n_chunks + GP_THREADS - 1) / GP_THREADS;
+  const uint64_t lo = (uint64_t)threadIdx.x * E < n_chunks ? (uint64_t)threadIdx.x * E : n_chunks;
+  const uint64_t hi = lo + E < n_chunks ? lo + E : n_chunks;
+  u256 t = mont_one<Fr>();
+  for (uint64_t c = lo; c < hi; c++) t = fr_mul(t, ld256(z + c * stride + last));
+  block_scan_mul(t, sh, false);
+  __syncthreads();
+  u256 acc = threadIdx.x ? sh[threadIdx.x - 1] : mont_one<Fr>();
+  for (uint64_t c = lo; c < hi; c++) {
+    st256(f + c, acc);
+    acc = fr_mul(acc, ld256(z + c * stride + last));
+  }
+}
+__global__ __launch_bounds__(256) void k_scale_columns(u256* __restrict__ z, uint64_t stride, uint64_t rows, const u256* __restrict__ f) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y + 1;  // column 0 has factor one
+  if (row >= rows) return;
+  st256(z + col * stride + row, fr_mul(ld256(z + col * stride + row), ld256(f + col)));
+}
+__global__ __launch_bounds__(256) void k_zero_tail(u256* __restrict__ z, uint64_t stride, uint64_t from, uint64_t n) {
+  const uint64_t row = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+  if (row >= n) return;
+  st256(z + col * stride + row, u256_zero());
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -323,7 +406,7 @@ int vdb_grand_product_dev(const vdb_fr* num_dev, const vdb_fr* den_dev, size_t n
   {
     VDB_PROF("k_grand_product");
     hipLaunchKernelGGL(k_grand_product, dim3((unsigned)n_cols), dim3(GP_THREADS), 0, ctx().stream, as_u256(num_dev), as_u256(den_dev), as_u256(z_dev),
-                     (uint64_t)n);
+                     (uint64_t)n, (uint64_t)n);
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
@@ -392,6 +475,121 @@ int vdb_divide_by_vanishing_dev(vdb_fr* h_ext_dev, uint32_t k, uint32_t ext_k) {
   VDB_HIP(hipStreamSynchronize(cx.stream));  // t is a host vector
   return VDB_OK;
 }
+// z columns of `n` entries from the terms in scratch: z[0 .. usable] is the running product, the rest zero
+static int product_columns(const u256* num, const u256* den, size_t n_z, size_t n, size_t usable_rows, u256* z) {
+  Context& cx = ctx();
+  {
+    VDB_PROF("k_grand_product");
+    hipLaunchKernelGGL(k_grand_product, dim3((unsigned)n_z), dim3(GP_THREADS), 0, cx.stream, num, den, z, (uint64_t)usable_rows + 1, (uint64_t)n);
+  }
+  VDB_LAUNCH_CHECK();
+  if (usable_rows + 1 < n) {
+    hipLaunchKernelGGL(k_zero_tail, dim3((unsigned)((n - usable_rows - 1 + 255) / 256), (unsigned)n_z), dim3(256), 0, cx.stream, z, (uint64_t)n,
+                       (uint64_t)usable_rows + 1, (uint64_t)n);
+    VDB_LAUNCH_CHECK();
+  }
+  return VDB_OK;
+}
+
+int vdb_fr_delta(vdb_fr* out) {
+  VDB_ARG(out, "bad argument");
+  u256 e = u256_zero();
+  e.w[0] = 1u << 28;  // GENERATOR^(2^S): generates the odd-order part of the multiplicative group
+  const u256 d = mont_pow<Fr>(host_fr_from_u64(7), e);
+  memcpy(out, &d, 32);
+  return VDB_OK;
+}
+
+int vdb_permutation_sigma_dev(const uint64_t* mapping_dev, size_t n_cols, uint32_t k, const vdb_fr* delta, vdb_fr* sigma_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(mapping_dev && delta && sigma_dev && k <= 28, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  const uint64_t n = 1ull << k;
+  u256 dv;
+  memcpy(&dv, delta, 32);
+  u256* buf = (u256*)scratch_get(5, (n + n_cols + 1) * sizeof(u256));
+  if (!buf) return VDB_ERR_OOM;
+  u256 *wpow = buf, *dpow = buf + n;
+  int* derr = (int*)(buf + n + n_cols);
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), cx.stream));
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k), mont_one<Fr>(), n, wpow);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, cx.stream, dv, mont_one<Fr>(), (uint64_t)n_cols, dpow);
+  {
+    VDB_PROF("k_perm_sigma");
+    hipLaunchKernelGGL(k_perm_sigma, dim3((unsigned)((n_cols * n + 255) / 256)), dim3(256), 0, cx.stream, mapping_dev, (uint64_t)n_cols, n, wpow, dpow,
+                       as_u256(sigma_dev), derr);
+  }
+  VDB_LAUNCH_CHECK();
+  int herr = 0;
+  VDB_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  if (herr) {
+    set_error("permutation mapping points outside the columns");
+    return VDB_ERR_ARG;
+  }
+  return VDB_OK;
+}
+
+int vdb_permutation_product_dev(const vdb_fr* cols_dev, const vdb_fr* sigma_dev, size_t n_cols, uint32_t k, size_t usable_rows, size_t chunk_len,
+                                const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, vdb_fr* z_dev) {
+  VDB_REQUIRE_INIT();
+  const uint64_t n = 1ull << (k <= 28 ? k : 0);
+  VDB_ARG(cols_dev && sigma_dev && beta && gamma && delta && z_dev && k <= 28 && chunk_len >= 1 && usable_rows < n, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  const size_t n_chunks = (n_cols + chunk_len - 1) / chunk_len;
+  u256 bv, gv, dv;
+  memcpy(&bv, beta, 32);
+  memcpy(&gv, gamma, 32);
+  memcpy(&dv, delta, 32);
+  // scratch: beta omega^row (n), delta^(chunk start) and chain factors (n_chunks each), the terms (2 x n_chunks x n)
+  u256* buf = (u256*)scratch_get(5, (n + 2 * n_chunks + 2 * n_chunks * n) * sizeof(u256));
+  if (!buf) return VDB_ERR_OOM;
+  u256 *bw = buf, *dstart = bw + n, *fac = dstart + n_chunks, *num = fac + n_chunks, *den = num + n_chunks * n;
+  u256 dchunk = mont_one<Fr>();
+  for (size_t i = 0; i < chunk_len; i++) dchunk = fr_mul(dchunk, dv);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k), bv, n, bw);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, cx.stream, dchunk, mont_one<Fr>(), (uint64_t)n_chunks, dstart);
+  if (usable_rows) {
+    VDB_PROF("k_perm_terms");
+    hipLaunchKernelGGL(k_perm_terms, dim3((unsigned)((usable_rows + 255) / 256), (unsigned)n_chunks), dim3(256), 0, cx.stream, as_u256(cols_dev), as_u256(sigma_dev),
+                       (uint64_t)n_cols, n, (uint64_t)usable_rows, (uint32_t)chunk_len, bw, bv, gv, dv, dstart, num, den);
+  }
+  VDB_LAUNCH_CHECK();
+  int rc = product_columns(num, den, n_chunks, n, usable_rows, as_u256(z_dev));
+  if (rc) return rc;
+  if (n_chunks > 1) {
+    VDB_PROF("k_chain");
+    hipLaunchKernelGGL(k_chain_factors, dim3(1), dim3(GP_THREADS), 0, cx.stream, as_u256(z_dev), (uint64_t)n_chunks, n, (uint64_t)usable_rows, fac);
+    hipLaunchKernelGGL(k_scale_columns, dim3((unsigned)((usable_rows + 1 + 255) / 256), (unsigned)(n_chunks - 1)), dim3(256), 0, cx.stream, as_u256(z_dev), n,
+                       (uint64_t)usable_rows + 1, fac);
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_lookup_product_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, const vdb_fr* perm_input_dev, const vdb_fr* perm_table_dev, size_t n_cols, size_t n,
+                           size_t usable_rows, const vdb_fr* beta, const vdb_fr* gamma, vdb_fr* z_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(input_dev && table_dev && perm_input_dev && perm_table_dev && beta && gamma && z_dev && n >= 1 && usable_rows < n, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  u256 bv, gv;
+  memcpy(&bv, beta, 32);
+  memcpy(&gv, gamma, 32);
+  u256* buf = (u256*)scratch_get(5, 2 * n_cols * n * sizeof(u256));
+  if (!buf) return VDB_ERR_OOM;
+  u256 *num = buf, *den = buf + n_cols * n;
+  if (usable_rows) {
+    VDB_PROF("k_lookup_terms");
+    hipLaunchKernelGGL(k_lookup_terms, dim3((unsigned)((usable_rows + 255) / 256), (unsigned)n_cols), dim3(256), 0, cx.stream, as_u256(input_dev), as_u256(table_dev),
+                       as_u256(perm_input_dev), as_u256(perm_table_dev), (uint64_t)n, (uint64_t)usable_rows, bv, gv, num, den);
+  }
+  VDB_LAUNCH_CHECK();
+  return product_columns(num, den, n_cols, n, usable_rows, as_u256(z_dev));
+}
+
 int vdb_lookup_permute_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,
                            vdb_fr* permuted_input_dev, vdb_fr* permuted_table_dev) {
   VDB_REQUIRE_INIT();

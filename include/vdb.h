@@ -237,6 +237,26 @@ int vdb_eval_polys_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const v
  * input_dev, permuted_*_dev: n_cols x n; table_dev: one column of n. */
 int vdb_lookup_permute_dev(const vdb_fr *input_dev, const vdb_fr *table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,
                            vdb_fr *permuted_input_dev, vdb_fr *permuted_table_dev);
+/* Lookup argument, running product (halo2 plonk/lookup/prover.rs commit_product): per input column z[0] = 1,
+ * z[i + 1] = z[i] (A[i] + beta)(S[i] + gamma) / ((A'[i] + beta)(S'[i] + gamma)) for i < usable_rows, rows above usable_rows zero
+ * (the caller blinds them).  A, A', S': n_cols x n; S (the table): one column of n.  z[usable_rows] is one exactly when
+ * (A', S') is a valid permutation pair of (A, S). */
+int vdb_lookup_product_dev(const vdb_fr *input_dev, const vdb_fr *table_dev, const vdb_fr *perm_input_dev, const vdb_fr *perm_table_dev, size_t n_cols, size_t n,
+                           size_t usable_rows, const vdb_fr *beta, const vdb_fr *gamma, vdb_fr *z_dev);
+/* Permutation argument.  halo2curves' Fr::DELTA = 7^(2^28). */
+int vdb_fr_delta(vdb_fr *out);
+/* keygen side (halo2 plonk/permutation/keygen.rs build_pk: the sigma columns in Lagrange form): sigma[c][row] =
+ * delta^c' omega^row' for the cell (c', row') that the copy-constraint permutation sends (c, row) to;
+ * mapping_dev: n_cols x 2^k words c' << 32 | row' (the identity where a cell is unconstrained). */
+int vdb_permutation_sigma_dev(const uint64_t *mapping_dev, size_t n_cols, uint32_t k, const vdb_fr *delta, vdb_fr *sigma_dev);
+/* prover side (plonk/permutation/prover.rs commit): the columns are taken in chunks of chunk_len (= constraint degree - 2);
+ * per chunk one product column z with z[i + 1] = z[i] prod_c (v_c[i] + beta delta^c omega^i + gamma) / (v_c[i] + beta
+ * sigma_c[i] + gamma) over the chunk's columns c, i < usable_rows; chunk j starts from the value chunk j - 1 ended on
+ * (z_0[0] = 1); rows above usable_rows are zero (the caller blinds them).  The last chunk's z[usable_rows] is one
+ * exactly when every cell equals the cell the permutation sends it to (up to the soundness error in beta, gamma).
+ * cols_dev, sigma_dev: n_cols x 2^k; z_dev: ceil(n_cols / chunk_len) x 2^k. */
+int vdb_permutation_product_dev(const vdb_fr *cols_dev, const vdb_fr *sigma_dev, size_t n_cols, uint32_t k, size_t usable_rows, size_t chunk_len,
+                                const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, vdb_fr *z_dev);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

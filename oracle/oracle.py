@@ -173,6 +173,67 @@ def grand_product(num, den):
     return z
 
 
+DELTA_INT = pow(7, 1 << 28, R_MOD)      # halo2curves bn256 Fr::DELTA = GENERATOR^(2^S)  [UPSTREAM-RECALL]
+
+
+def permutation_sigma(mapping, k, delta=DELTA_INT):
+    """halo2 plonk/permutation/keygen.rs: sigma[c][row] = delta^c' omega^row' where mapping[c][row] = c' << 32 | row'."""
+    w = fr_to_ints(root_of_unity(k).reshape(1, 4))[0]
+    n_cols, n = mapping.shape
+    wp = [1] * n
+    for i in range(1, n):
+        wp[i] = wp[i - 1] * w % R_MOD
+    dp = [pow(delta, c, R_MOD) for c in range(n_cols)]
+    vals = [dp[int(m) >> 32] * wp[int(m) & 0xFFFFFFFF] % R_MOD for m in mapping.reshape(-1)]
+    return fr_from_ints(vals).reshape(n_cols, n, 4)
+
+
+def permutation_product(cols, sigma, usable_rows, chunk_len, beta, gamma, delta=DELTA_INT):
+    """halo2 plonk/permutation/prover.rs commit ([UPSTREAM-RECALL]), on canonical integers, one inversion per row: per
+    chunk of chunk_len columns z[i+1] = z[i] prod_c (v + delta^c beta omega^i + gamma) / (v + beta sigma + gamma); each
+    chunk starts from the previous chunk's z[usable_rows]; rows above usable_rows are zero."""
+    n_cols, n = cols.shape[0], cols.shape[1]
+    k = n.bit_length() - 1
+    w = fr_to_ints(root_of_unity(k).reshape(1, 4))[0]
+    v = np.array(fr_to_ints(cols.reshape(-1, 4)), dtype=object).reshape(n_cols, n)
+    sg = np.array(fr_to_ints(sigma.reshape(-1, 4)), dtype=object).reshape(n_cols, n)
+    b, g = fr_to_ints(beta.reshape(1, 4))[0], fr_to_ints(gamma.reshape(1, 4))[0]
+    out = []
+    last = 1
+    for c0 in range(0, n_cols, chunk_len):
+        z = [0] * n
+        z[0] = last
+        wi = 1
+        for i in range(usable_rows):
+            num = den = 1
+            for c in range(c0, min(c0 + chunk_len, n_cols)):
+                num = num * (v[c][i] + pow(delta, c, R_MOD) * b % R_MOD * wi + g) % R_MOD
+                den = den * (v[c][i] + b * sg[c][i] + g) % R_MOD
+            z[i + 1] = z[i] * num % R_MOD * pow(den, -1, R_MOD) % R_MOD
+            wi = wi * w % R_MOD
+        last = z[usable_rows]
+        out.append(fr_from_ints(z))
+    return np.stack(out)
+
+
+def lookup_product(inputs, table, perm_inputs, perm_table, usable_rows, beta, gamma):
+    """halo2 plonk/lookup/prover.rs commit_product ([UPSTREAM-RECALL]): z[i+1] = z[i] (A + beta)(S + gamma) /
+    ((A' + beta)(S' + gamma)) for i < usable_rows, rows above zero."""
+    n_cols, n = inputs.shape[0], inputs.shape[1]
+    b, g = fr_to_ints(beta.reshape(1, 4))[0], fr_to_ints(gamma.reshape(1, 4))[0]
+    S = fr_to_ints(table.reshape(-1, 4))
+    out = []
+    for c in range(n_cols):
+        A, PA, PS = fr_to_ints(inputs[c]), fr_to_ints(perm_inputs[c]), fr_to_ints(perm_table[c])
+        z = [0] * n
+        z[0] = 1
+        for i in range(usable_rows):
+            den = (PA[i] + b) * (PS[i] + g) % R_MOD
+            z[i + 1] = z[i] * ((A[i] + b) * (S[i] + g) % R_MOD) % R_MOD * pow(den, -1, R_MOD) % R_MOD
+        out.append(fr_from_ints(z))
+    return np.stack(out)
+
+
 def fr_to_canonical(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     o = np.empty_like(a)

@@ -192,3 +192,109 @@ def test_gate_quotient_vanishes_exactly_when_the_gates_hold(api, O):
     bad[0, row + 3] = O.fr_add(bad[0, row + 3].reshape(1, 4), O.fr_from_ints([1]))[0]
     _, _, _, _, h_bad = _gate_quotient(api, O, bad, flags, len(stream), bp, k, ext, y)
     assert h_bad[2 * n - 2:].any()
+
+
+def _copy_cycles(rng, cols_ints, n_cols, n, usable):
+    """a copy-constraint permutation over the usable rows: cells of equal value are linked into cycles (as halo2's
+    keygen does for every constrain_equal); returns mapping words col' << 32 | row'"""
+    mapping = np.array([[(c << 32) | r for r in range(n)] for c in range(n_cols)], dtype=np.uint64)
+    groups = {}
+    for c in range(n_cols):
+        for r in range(usable):
+            groups.setdefault(cols_ints[c][r], []).append((c, r))
+    n_linked = 0
+    for cells in groups.values():
+        if len(cells) > 1:
+            order = [cells[i] for i in rng.permutation(len(cells))]
+            for (c, r), (c2, r2) in zip(order, order[1:] + order[:1]):
+                mapping[c, r] = (c2 << 32) | r2
+            n_linked += len(cells)
+    return mapping, n_linked
+
+
+@pytest.mark.parametrize("k,n_cols,chunk_len", [(4, 1, 1), (5, 3, 2), (6, 7, 3), (8, 4, 3)])
+def test_permutation_sigma_and_product_match_oracle(api, O, k, n_cols, chunk_len):
+    rng = np.random.default_rng(500 + k)
+    n, usable = 1 << k, (1 << k) - 6
+    vals = rng.integers(0, 3 if k < 6 else 9, size=(n_cols, n))   # few distinct values: long copy cycles
+    cols = O.fr_from_ints([int(v) for v in vals.reshape(-1)]).reshape(n_cols, n, 4)
+    mapping, n_linked = _copy_cycles(rng, vals.tolist(), n_cols, n, usable)
+    assert n_linked >= n_cols * usable // 2
+    sigma = api.permutation_sigma(mapping, k)
+    assert np.array_equal(sigma, O.permutation_sigma(mapping, k))
+    beta, gamma = O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0]
+    z = api.permutation_product(cols, sigma, usable, chunk_len, beta, gamma)
+    assert np.array_equal(z, O.permutation_product(cols, sigma, usable, chunk_len, beta, gamma))
+    one = O.fr_from_ints([1])[0]
+    assert np.array_equal(z[0, 0], one) and np.array_equal(z[-1, usable], one) and not z[:, usable + 1:].any()
+    # a cell that differs from the cell it is tied to: the product no longer closes
+    bad = cols.copy()
+    c, r = [(c, r) for c in range(n_cols) for r in range(usable) if int(mapping[c, r]) != (c << 32) | r][0]
+    bad[c, r] = O.fr_from_ints([1000])[0]
+    zb = api.permutation_product(bad, sigma, usable, chunk_len, beta, gamma)
+    assert not np.array_equal(zb[-1, usable], one)
+    with pytest.raises(api.VdbError):
+        wrong = mapping.copy()
+        wrong[0, 0] = np.uint64(n_cols << 32)
+        api.permutation_sigma(wrong, k)
+
+
+def test_permutation_product_closes_on_a_laid_out_witness(api, O):
+    """the copy constraints the column layout itself creates — the overlap cell that ends one column is the cell that
+    starts the next — at k = 12 on a real distance witness: with exactly those cells tied, the chained
+    product over all chunks returns to one"""
+    rng = np.random.default_rng(77)
+    k = 12
+    n, usable = 1 << k, (1 << k) - 6
+    qa, qb = O.quantize(rng.uniform(-3, 3, (2, 8))), O.quantize(rng.uniform(-3, 3, (2, 8)))
+    w = api.wit_distance("euclidean", qa, qb, L=11, selectors=True)
+    bp = api.layout_plan(w["flags"], k)
+    cols, _ = api.layout_columns(w["stream"], bp, k)
+    n_cols = cols.shape[0]
+    assert n_cols >= 3
+    mapping = np.array([[(c << 32) | r for r in range(n)] for c in range(n_cols)], dtype=np.uint64)
+    for c in range(n_cols - 1):
+        last = int(bp[c])                                 # break point = the row of the cell the next column repeats
+        assert np.array_equal(cols[c, last], cols[c + 1, 0])
+        mapping[c, last], mapping[c + 1, 0] = (c + 1) << 32, (c << 32) | last
+    sigma = api.permutation_sigma(mapping, k)
+    beta, gamma = O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0]
+    z = api.permutation_product(cols, sigma, usable, 3, beta, gamma)
+    one = O.fr_from_ints([1])[0]
+    assert np.array_equal(z[-1, usable], one) and not np.array_equal(z[0, usable], one)
+    # recurrence spot check through the device field product
+    i = 1234
+    wi = O.fr_from_ints([pow(O.fr_to_ints(O.root_of_unity(k).reshape(1, 4))[0], i, O.R_MOD)])
+    num = den = one.reshape(1, 4)
+    dl = O.fr_from_ints([1])
+    for c in range(3):
+        v = O.fr_add(cols[c, i].reshape(1, 4), gamma.reshape(1, 4))
+        num = O.fr_mul(num, O.fr_add(v, O.fr_mul(O.fr_mul(dl, beta.reshape(1, 4)), wi)))
+        den = O.fr_mul(den, O.fr_add(v, O.fr_mul(beta.reshape(1, 4), sigma[c, i].reshape(1, 4))))
+        dl = O.fr_mul(dl, api.fr_delta().reshape(1, 4))
+    assert np.array_equal(O.fr_mul(z[0, i + 1].reshape(1, 4), den), O.fr_mul(z[0, i].reshape(1, 4), num))
+
+
+@pytest.mark.parametrize("n,usable,bits,n_cols", [(64, 58, 4, 2), (1024, 1018, 8, 3), (65536, 65530, 15, 2)])
+def test_lookup_product_closes_and_matches_oracle(api, O, n, usable, bits, n_cols):
+    rng = np.random.default_rng(61 * bits + n_cols)
+    table = _range_table(O, n, bits)
+    ins = np.stack([O.fr_from_ints([int(x) for x in rng.integers(0, 1 << bits, size=n)]) for _ in range(n_cols)])
+    pa, ps = api.lookup_permute(ins, table, usable, bits)
+    beta, gamma = O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0]
+    z = api.lookup_product(ins, table, pa, ps, usable, beta, gamma)
+    one = O.fr_from_ints([1])[0]
+    for c in range(n_cols):
+        assert np.array_equal(z[c, 0], one) and np.array_equal(z[c, usable], one) and not z[c, usable + 1:].any()
+    if n <= 1024:
+        assert np.array_equal(z, O.lookup_product(ins, table, pa, ps, usable, beta, gamma))
+    else:   # the recurrence, through the device field product
+        b, g = np.tile(beta, (usable, 1)), np.tile(gamma, (usable, 1))
+        lhs = O.fr_mul(z[0, 1:usable + 1], O.fr_mul(O.fr_add(pa[0, :usable], b), O.fr_add(ps[0, :usable], g)))
+        rhs = O.fr_mul(z[0, :usable], O.fr_mul(O.fr_add(ins[0, :usable], b), O.fr_add(table[:usable], g)))
+        assert np.array_equal(lhs, rhs)
+    # an input value swapped for another one: the permuted pair no longer matches and the product does not close
+    bad = ins.copy()
+    bad[0, 3] = O.fr_add(bad[0, 3].reshape(1, 4), O.fr_from_ints([1]))[0]
+    zb = api.lookup_product(bad, table, pa, ps, usable, beta, gamma)
+    assert not np.array_equal(zb[0, usable], one)

@@ -70,5 +70,27 @@ for it in range(3):
     ms_lp = api.timer_stop()
 print(json.dumps({"kernel": "k_lp_hist + k_lp_scan + k_lp_rows", "n_cols": lk_cols, "n": n, "bits": bits, "ms": round(ms_lp, 3),
                   "rows_per_s": lk_cols * n / ms_lp * 1e3, "algorithmic_GBps": 96.0 * lk_cols * n / ms_lp / 1e6}))
+# lookup product over the same columns (terms + grand product), then the permutation product of 2,048 advice columns
+beta, gamma = x, x[::-1].copy()
+d_z = api.DeviceBuffer(lk_cols * n * 32)
+for it in range(3):
+    api.timer_start()
+    check(lib.vdb_lookup_product_dev(d_in.ptr, d_tab.ptr, d_oa.ptr, d_os.ptr, ctypes.c_size_t(lk_cols), ctypes.c_size_t(n), ctypes.c_size_t(usable),
+                                     api._p(beta), api._p(gamma), d_z.ptr))
+    ms_lz = api.timer_stop()
+print(json.dumps({"kernel": "k_lookup_terms + k_grand_product", "n_cols": lk_cols, "n": n, "ms": round(ms_lz, 3), "rows_per_s": lk_cols * n / ms_lz * 1e3}))
+for b in (d_in, d_oa, d_os, d_z):
+    b.free()
+chunk = 3
+n_chunks = -(-n_cols // chunk)
+d_pz = api.DeviceBuffer(n_chunks * n * 32)
+delta = api.fr_delta()
+for it in range(3):
+    api.timer_start()
+    check(lib.vdb_permutation_product_dev(bufs[0].ptr, bufs[1].ptr, ctypes.c_size_t(n_cols), 16, ctypes.c_size_t(usable), ctypes.c_size_t(chunk),
+                                          api._p(beta), api._p(gamma), api._p(delta), d_pz.ptr))
+    ms_pz = api.timer_stop()
+print(json.dumps({"kernel": "k_perm_terms + k_grand_product + chain", "n_cols": n_cols, "chunk_len": chunk, "n": n, "ms": round(ms_pz, 3),
+                  "cells_per_s": n_cols * n / ms_pz * 1e3, "algorithmic_GBps": (64.0 * n_cols + 32.0 * n_chunks) * n / ms_pz / 1e6}))
 print(json.dumps({"kernel": "k_grand_product", "n_cols": n_cols, "n": n, "ms": round(ms, 3), "rows_per_s": rows / ms * 1e3, "algorithmic_GBps": 224.0 * rows / ms / 1e6,
                   "fr_mul_per_s": 5.0 * rows / ms * 1e3}))

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
     "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
     "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
+    "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vdb_lookup_eval_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_product_dev": [_P, _P, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_colsrc_build_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _U32, _P],
     "vdb_colsrc_build_lookup_dev": [_P, _U64, _U32, _U32, _U64, _U64, _P, _U32, _P],

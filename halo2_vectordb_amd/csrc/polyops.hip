@@ -393,6 +393,75 @@ __global__ __launch_bounds__(256) void k_zero_tail(u256* __restrict__ z, uint64_
   st256(z + col * stride + row, u256_zero());
 }
 
+// ---- permutation and lookup parts of the quotient numerator on the extended coset (halo2 plonk/evaluation.rs evaluate_h,
+// [UPSTREAM-RECALL] for the order of the terms; each term is folded in as acc = acc * y + term) --------------------------
+// Rotation by one row = a step of 2^e on the coset of 2^(k+e) points.  l0, l_last, l_active = 1 - (l_last + l_blind) are the
+// Lagrange selectors on the coset; bx[j] = beta * X_j.  One thread per extended row, sets / columns in a loop.
+struct QuotArgs {
+  const u256 *l0, *l_last, *l_active;
+  u256 beta, gamma, delta, y;
+  uint32_t log_ne, e;
+  uint64_t last_rot;  // rows between the last usable row and the end: n - usable_rows
+};
+__global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv, const u256* __restrict__ sigma, const u256* __restrict__ z, uint64_t n_cols,
+                                                   uint32_t chunk_len, const u256* __restrict__ bx, QuotArgs q, u256* __restrict__ acc) {
+  const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ne) return;
+  const uint64_t mask = ne - 1, r = 1ull << q.e;
+  const uint64_t n_sets = (n_cols + chunk_len - 1) / chunk_len;
+  const u256 one = mont_one<Fr>();
+  const u256 l0 = ld256(q.l0 + j), ll = ld256(q.l_last + j), la = ld256(q.l_active + j);
+  u256 h = ld256(acc + j);
+  // l0 (1 - z_0)
+  h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, ld256(z + j))));
+  // l_last (z_last^2 - z_last)
+  {
+    const u256 zl = ld256(z + (n_sets - 1) * ne + j);
+    h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zl, zl), zl)));
+  }
+  // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
+  const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
+  for (uint64_t i = 1; i < n_sets; i++) h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(ld256(z + i * ne + j), ld256(z + (i - 1) * ne + jb))));
+  // l_active (z_i(w X) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma))
+  u256 cur = ld256(bx + j);
+  for (uint64_t i = 0; i < n_sets; i++) {
+    const uint64_t c0 = i * chunk_len, c1 = c0 + chunk_len < n_cols ? c0 + chunk_len : n_cols;
+    u256 left = ld256(z + i * ne + ((j + r) & mask)), right = ld256(z + i * ne + j);
+    for (uint64_t c = c0; c < c1; c++) {
+      const u256 v = fr_add(ld256(adv + c * ne + j), q.gamma);
+      left = fr_mul(left, fr_add(v, fr_mul(q.beta, ld256(sigma + c * ne + j))));
+      right = fr_mul(right, fr_add(v, cur));
+      cur = fr_mul(cur, q.delta);
+    }
+    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_sub(left, right)));
+  }
+  st256(acc + j, h);
+}
+__global__ __launch_bounds__(256) void k_lookup_eval(const u256* __restrict__ a, const u256* __restrict__ tab, const u256* __restrict__ pa, const u256* __restrict__ pt,
+                                                     const u256* __restrict__ z, uint64_t n_cols, QuotArgs q, u256* __restrict__ acc) {
+  const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ne) return;
+  const uint64_t mask = ne - 1, r = 1ull << q.e;
+  const u256 one = mont_one<Fr>();
+  const u256 l0 = ld256(q.l0 + j), ll = ld256(q.l_last + j), la = ld256(q.l_active + j);
+  const u256 sg = fr_add(ld256(tab + j), q.gamma);
+  u256 h = ld256(acc + j);
+  for (uint64_t c = 0; c < n_cols; c++) {
+    const uint64_t o = c * ne;
+    const u256 zc = ld256(z + o + j), zn = ld256(z + o + ((j + r) & mask));
+    const u256 av = ld256(a + o + j), pav = ld256(pa + o + j), ptv = ld256(pt + o + j), pap = ld256(pa + o + ((j + ne - r) & mask));
+    h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, zc)));                         // l0 (1 - z)
+    h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zc, zc), zc)));              // l_last (z^2 - z)
+    const u256 left = fr_mul(zn, fr_mul(fr_add(pav, q.beta), fr_add(ptv, q.gamma)));
+    const u256 right = fr_mul(zc, fr_mul(fr_add(av, q.beta), sg));
+    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_sub(left, right)));                     // l_active (z(wX)(a'+b)(s'+g) - z (a+b)(s+g))
+    const u256 d = fr_sub(pav, ptv);
+    h = fr_add(fr_mul(h, q.y), fr_mul(l0, d));                                       // l0 (a' - s')
+    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_mul(d, fr_sub(pav, pap))));             // l_active (a' - s')(a' - a'(w^-1 X))
+  }
+  st256(acc + j, h);
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -588,6 +657,67 @@ int vdb_lookup_product_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, con
   }
   VDB_LAUNCH_CHECK();
   return product_columns(num, den, n_cols, n, usable_rows, as_u256(z_dev));
+}
+
+static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const vdb_fr* l_active, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta,
+                     const vdb_fr* y, uint32_t k, uint32_t ext_k, size_t usable_rows) {
+  q.l0 = as_u256(l0);
+  q.l_last = as_u256(l_last);
+  q.l_active = as_u256(l_active);
+  memcpy(&q.beta, beta, 32);
+  memcpy(&q.gamma, gamma, 32);
+  if (delta) memcpy(&q.delta, delta, 32);
+  else q.delta = mont_one<Fr>();
+  memcpy(&q.y, y, 32);
+  q.log_ne = k + ext_k;
+  q.e = ext_k;
+  q.last_rot = (1ull << k) - usable_rows;
+  return VDB_OK;
+}
+
+int vdb_permutation_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k,
+                             uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev, const vdb_fr* l_active_ext_dev,
+                             const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(adv_ext_dev && sigma_ext_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta && gamma && delta && y && acc_dev, "null pointer");
+  VDB_ARG(k + ext_k <= 28 && chunk_len >= 1 && usable_rows < (1ull << k), "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  QuotArgs q;
+  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, delta, y, k, ext_k, usable_rows);
+  const uint64_t ne = 1ull << (k + ext_k);
+  u256* bx = (u256*)scratch_get(5, ne * sizeof(u256));
+  if (!bx) return VDB_ERR_OOM;
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k + ext_k), fr_mul(q.beta, host_zeta()), ne,
+                     bx);
+  {
+    VDB_PROF("k_perm_eval");
+    hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_dev), as_u256(z_ext_dev),
+                       (uint64_t)n_cols, (uint32_t)chunk_len, bx, q, as_u256(acc_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev, const vdb_fr* perm_input_ext_dev, const vdb_fr* perm_table_ext_dev,
+                        const vdb_fr* z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                        const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* y, vdb_fr* acc_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(input_ext_dev && table_ext_dev && perm_input_ext_dev && perm_table_ext_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta &&
+              gamma && y && acc_dev,
+          "null pointer");
+  VDB_ARG(k + ext_k <= 28, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  QuotArgs q;
+  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, nullptr, y, k, ext_k, 0);
+  const uint64_t ne = 1ull << (k + ext_k);
+  {
+    VDB_PROF("k_lookup_eval");
+    hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
+                       as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, as_u256(acc_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
 }
 
 int vdb_lookup_permute_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, size_t n_cols, size_t n, size_t usable_rows, uint32_t max_bits,

@@ -257,6 +257,20 @@ int vdb_permutation_sigma_dev(const uint64_t *mapping_dev, size_t n_cols, uint32
  * cols_dev, sigma_dev: n_cols x 2^k; z_dev: ceil(n_cols / chunk_len) x 2^k. */
 int vdb_permutation_product_dev(const vdb_fr *cols_dev, const vdb_fr *sigma_dev, size_t n_cols, uint32_t k, size_t usable_rows, size_t chunk_len,
                                 const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, vdb_fr *z_dev);
+/* Permutation and lookup parts of the quotient numerator on the extended coset of 2^(k+ext_k) points (halo2
+ * plonk/evaluation.rs evaluate_h), folded into acc_dev term by term as acc = acc * y + term, after the gates
+ * (vdb_gate_eval_dev).  All *_ext_dev arrays are vdb_coeff_to_extended_dev images: the advice, sigma and product columns;
+ * l0 (Lagrange basis of row 0), l_last (row usable_rows), l_active = 1 - (l_last + sum of the rows above usable_rows).
+ * Permutation terms: l0 (1 - z_0); l_last (z_last^2 - z_last); l0 (z_i - z_{i-1}(w^-(n-usable_rows) X)) for i >= 1; per chunk
+ * l_active (z_i(wX) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma)).
+ * Lookup terms per input column: l0 (1 - z); l_last (z^2 - z); l_active (z(wX)(A' + beta)(S' + gamma) - z (A + beta)(S + gamma));
+ * l0 (A' - S'); l_active (A' - S')(A' - A'(w^-1 X)). */
+int vdb_permutation_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigma_ext_dev, const vdb_fr *z_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k,
+                             uint32_t ext_k, size_t usable_rows, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev, const vdb_fr *l_active_ext_dev,
+                             const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev);
+int vdb_lookup_eval_dev(const vdb_fr *input_ext_dev, const vdb_fr *table_ext_dev, const vdb_fr *perm_input_ext_dev, const vdb_fr *perm_table_ext_dev,
+                        const vdb_fr *z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
+                        const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

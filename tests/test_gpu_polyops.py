@@ -298,3 +298,102 @@ def test_lookup_product_closes_and_matches_oracle(api, O, n, usable, bits, n_col
     bad[0, 3] = O.fr_add(bad[0, 3].reshape(1, 4), O.fr_from_ints([1]))[0]
     zb = api.lookup_product(bad, table, pa, ps, usable, beta, gamma)
     assert not np.array_equal(zb[0, usable], one)
+
+
+def _full_quotient(api, O, k, ext, usable, chunk_len, y, beta, gamma, adv, sel, table, sigma, zp, lk, pa, ps, zl):
+    """gates, then the permutation argument over `adv`, then the lookup argument over the columns `lk` (which are part of
+    `adv`): numerator on the extended coset / (X^n - 1) -> coefficients of h"""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    n, ne = 1 << k, 1 << (k + ext)
+    lag = np.zeros((3, n, 4), dtype=np.uint64)
+    one = O.fr_from_ints([1])[0]
+    lag[0, 0] = one                                       # l0
+    lag[1, usable] = one                                  # l_last
+    lag[2, :usable] = one                                 # l_active = 1 - (l_last + l_blind)
+    ext_of = lambda cols: api.coeff_to_extended(api.lagrange_to_coeff(np.ascontiguousarray(cols)), ext)
+    arrays = dict(adv=ext_of(adv), sel=ext_of(sel), table=ext_of(table.reshape(1, n, 4)), sigma=ext_of(sigma), zp=ext_of(zp), lk=ext_of(lk), pa=ext_of(pa),
+                  ps=ext_of(ps), zl=ext_of(zl), lag=ext_of(lag))
+    d = {}
+    for name, a in arrays.items():
+        d[name] = api.DeviceBuffer(a.nbytes)
+        d[name].upload(a)
+    d_h = api.DeviceBuffer(ne * 32)
+    check(lib.vdb_memset_dev(d_h.ptr, 0, ne * 32))
+    l0, ll, la = (ctypes.c_void_p(d["lag"].ptr.value + i * ne * 32) for i in range(3))
+    n_gate = sel.shape[0]
+    check(lib.vdb_gate_eval_dev(d["adv"].ptr, d["sel"].ptr, ctypes.c_size_t(n_gate), k, ext, api._p(y), d_h.ptr))
+    delta = api.fr_delta()
+    check(lib.vdb_permutation_eval_dev(d["adv"].ptr, d["sigma"].ptr, d["zp"].ptr, ctypes.c_size_t(adv.shape[0]), ctypes.c_size_t(chunk_len), k, ext,
+                                       ctypes.c_size_t(usable), l0, ll, la, api._p(beta), api._p(gamma), api._p(delta), api._p(y), d_h.ptr))
+    check(lib.vdb_lookup_eval_dev(d["lk"].ptr, d["table"].ptr, d["pa"].ptr, d["ps"].ptr, d["zl"].ptr, ctypes.c_size_t(lk.shape[0]), k, ext, l0, ll, la,
+                                  api._p(beta), api._p(gamma), api._p(y), d_h.ptr))
+    check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, ext))
+    check(lib.vdb_extended_to_coeff_dev(d_h.ptr, ctypes.c_size_t(1), k, ext))
+    api.sync()
+    h = d_h.download((ne, 4))
+    for b in list(d.values()) + [d_h]:
+        b.free()
+    return h
+
+
+@pytest.mark.parametrize("chunk_len", [2, 3])
+def test_full_quotient_of_a_laid_out_distance_circuit(api, O, chunk_len):
+    """Gates + permutation argument + lookup argument together, on a real Euclidean-distance witness laid out at k = 10 with
+    its range-check cells in lookup columns: the whole numerator of h(X), built by the device bricks (layout, selectors,
+    lookup permutation, both running products, the three evaluation kernels on the extended coset), is divisible by X^n - 1
+    — deg h <= (chunk_len + 2)(n - 1) - n — and stops being so when a product column or a tied cell is tampered with.
+    The statement is mathematical (the PLONK identities), independent of recalled upstream detail."""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    rng = np.random.default_rng(4242)
+    k, ext, L = 10, 2, 9
+    n, usable = 1 << k, (1 << k) - 6
+    qa, qb = O.quantize(rng.uniform(-3, 3, (3, 6))), O.quantize(rng.uniform(-3, 3, (3, 6)))
+    w = api.wit_distance("euclidean", qa, qb, L=L, selectors=True)
+    bp = api.layout_plan(w["flags"], k)
+    cols, lcols = api.layout_columns(w["stream"], bp, k, lookup=w["lookup"])
+    n_adv, n_lk = cols.shape[0], lcols.shape[0]
+    assert n_adv >= 2 and n_lk >= 1
+    lib = api.init()
+    d_flags, d_q = api.DeviceBuffer(max(w["flags"].nbytes, 32)), api.DeviceBuffer(n_adv * n * 32)
+    d_flags.upload(w["flags"])
+    check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(len(w["stream"])), api._p(bp), ctypes.c_uint64(len(bp)), k, d_q.ptr))
+    sel = d_q.download((n_adv, n, 4))
+    d_flags.free(), d_q.free()
+    blind = lambda shape_cols, rows: O.random_fr(rng, shape_cols * rows).reshape(shape_cols, rows, 4)
+    allc = np.concatenate([cols, lcols])                  # the permutation covers the gate columns and the lookup columns
+    allc[:, usable + 1:] = blind(allc.shape[0], n - usable - 1)
+    table = _range_table(O, n, L)
+    # copy constraints: the overlap cells between consecutive gate columns
+    mapping = np.array([[(c << 32) | r for r in range(n)] for c in range(allc.shape[0])], dtype=np.uint64)
+    for c in range(n_adv - 1):
+        last = int(bp[c])
+        mapping[c, last], mapping[c + 1, 0] = (c + 1) << 32, (c << 32) | last
+    sigma = api.permutation_sigma(mapping, k)
+    beta, gamma, y = O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0]
+    zp = api.permutation_product(allc, sigma, usable, chunk_len, beta, gamma)
+    zp[:, usable + 1:] = blind(zp.shape[0], n - usable - 1)
+    lk = allc[n_adv:]
+    pa, ps = api.lookup_permute(lk, table, usable, L)
+    zl = api.lookup_product(lk, table, pa, ps, usable, beta, gamma)
+    pa[:, usable:], ps[:, usable:] = blind(n_lk, n - usable), blind(n_lk, n - usable)
+    zl[:, usable + 1:] = blind(n_lk, n - usable - 1)
+    args = dict(adv=allc, sel=sel, table=table, sigma=sigma, zp=zp, lk=lk, pa=pa, ps=ps, zl=zl)
+    run = lambda **kw: _full_quotient(api, O, k, ext, usable, chunk_len, y, beta, gamma, **{**args, **kw})
+    bound = (chunk_len + 2) * (n - 1) - n + 1             # number of coefficients h may have
+    h = run()
+    assert h[:bound].any() and not h[bound:].any()
+    # tamper with one value of the lookup product inside the usable rows
+    zl_bad = zl.copy()
+    zl_bad[0, 100] = O.fr_add(zl_bad[0, 100].reshape(1, 4), O.fr_from_ints([1]))[0]
+    assert run(zl=zl_bad)[bound:].any()
+    # break a tie: the first cell of the second gate column no longer equals the overlap cell it repeats (its gate is also
+    # broken, so restrict the claim to: not divisible)
+    adv_bad = allc.copy()
+    adv_bad[1, 0] = O.fr_add(adv_bad[1, 0].reshape(1, 4), O.fr_from_ints([1]))[0]
+    assert run(adv=adv_bad)[bound:].any()
+    # a permutation product computed for other challenges
+    zp_other = api.permutation_product(allc, sigma, usable, chunk_len, gamma, beta)
+    assert run(zp=zp_other)[bound:].any()

@@ -338,17 +338,11 @@ def _full_quotient(api, O, k, ext, usable, chunk_len, y, beta, gamma, adv, sel, 
     return h
 
 
-@pytest.mark.parametrize("chunk_len", [2, 3])
-def test_full_quotient_of_a_laid_out_distance_circuit(api, O, chunk_len):
-    """Gates + permutation argument + lookup argument together, on a real Euclidean-distance witness laid out at k = 10 with
-    its range-check cells in lookup columns: the whole numerator of h(X), built by the device bricks (layout, selectors,
-    lookup permutation, both running products, the three evaluation kernels on the extended coset), is divisible by X^n - 1
-    — deg h <= (chunk_len + 2)(n - 1) - n — and stops being so when a product column or a tied cell is tampered with.
-    The statement is mathematical (the PLONK identities), independent of recalled upstream detail."""
+def _distance_circuit(api, O, rng, chunk_len, k=10, L=9):
+    """a Euclidean-distance witness laid out at 2^k rows with everything the prover rounds derive from it: selectors, sigma
+    columns (overlap cells tied), both arguments' product columns, blinding rows"""
     import ctypes
     from halo2_vectordb_amd._lib import check
-    rng = np.random.default_rng(4242)
-    k, ext, L = 10, 2, 9
     n, usable = 1 << k, (1 << k) - 6
     qa, qb = O.quantize(rng.uniform(-3, 3, (3, 6))), O.quantize(rng.uniform(-3, 3, (3, 6)))
     w = api.wit_distance("euclidean", qa, qb, L=L, selectors=True)
@@ -381,6 +375,21 @@ def test_full_quotient_of_a_laid_out_distance_circuit(api, O, chunk_len):
     pa[:, usable:], ps[:, usable:] = blind(n_lk, n - usable), blind(n_lk, n - usable)
     zl[:, usable + 1:] = blind(n_lk, n - usable - 1)
     args = dict(adv=allc, sel=sel, table=table, sigma=sigma, zp=zp, lk=lk, pa=pa, ps=ps, zl=zl)
+    return args, (beta, gamma, y), usable, n_adv
+
+
+@pytest.mark.parametrize("chunk_len", [2, 3])
+def test_full_quotient_of_a_laid_out_distance_circuit(api, O, chunk_len):
+    """Gates + permutation argument + lookup argument together, on a real Euclidean-distance witness laid out at k = 10 with
+    its range-check cells in lookup columns: the whole numerator of h(X), built by the device bricks (layout, selectors,
+    lookup permutation, both running products, the three evaluation kernels on the extended coset), is divisible by X^n - 1
+    — deg h <= (chunk_len + 2)(n - 1) - n — and stops being so when a product column or a tied cell is tampered with.
+    The statement is mathematical (the PLONK identities), independent of recalled upstream detail."""
+    rng = np.random.default_rng(4242)
+    k, ext = 10, 2
+    n = 1 << k
+    args, (beta, gamma, y), usable, n_adv = _distance_circuit(api, O, rng, chunk_len, k)
+    allc, sigma, zl = args["adv"], args["sigma"], args["zl"]
     run = lambda **kw: _full_quotient(api, O, k, ext, usable, chunk_len, y, beta, gamma, **{**args, **kw})
     bound = (chunk_len + 2) * (n - 1) - n + 1             # number of coefficients h may have
     h = run()
@@ -397,3 +406,55 @@ def test_full_quotient_of_a_laid_out_distance_circuit(api, O, chunk_len):
     # a permutation product computed for other challenges
     zp_other = api.permutation_product(allc, sigma, usable, chunk_len, gamma, beta)
     assert run(zp=zp_other)[bound:].any()
+
+
+def test_verifier_identity_at_a_random_point(api, O):
+    """What a verifier checks: every committed polynomial evaluated at x (and at the rotated points) by vdb_eval_polys_dev,
+    the gate / permutation / lookup expressions recombined from those evaluations with Python integers, against
+    h(x) (x^n - 1) with h from the device quotient pipeline."""
+    rng = np.random.default_rng(777)
+    k, ext, chunk_len = 10, 2, 3
+    n = 1 << k
+    R = O.R_MOD
+    args, (beta, gamma, y), usable, n_adv = _distance_circuit(api, O, rng, chunk_len, k)
+    h = _full_quotient(api, O, k, ext, usable, chunk_len, y, beta, gamma, **args)
+    to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(-1, 4))
+    b, g, yv = to_int(beta)[0], to_int(gamma)[0], to_int(y)[0]
+    w = to_int(O.root_of_unity(k))[0]
+    x = to_int(O.random_fr(rng, 1))[0]
+    delta = to_int(api.fr_delta())[0]
+    lag = np.zeros((3, n, 4), dtype=np.uint64)
+    one = O.fr_from_ints([1])[0]
+    lag[0, 0], lag[1, usable], lag[2, :usable] = one, one, one
+    coeff = {name: api.lagrange_to_coeff(np.ascontiguousarray(a if a.ndim == 3 else a.reshape(1, n, 4))) for name, a in {**args, "lag": lag}.items()}
+    def ev(name, rot=0):
+        pt = x * pow(w, rot % n, R) % R
+        return to_int(api.eval_polys(coeff[name], O.fr_from_ints([pt])[0]))
+    acc = 0
+    a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
+    for c in range(n_adv):
+        acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
+    l0, ll, la = ev("lag")
+    sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -(n - usable))
+    n_cols, n_sets = len(a0), len(z0)
+    acc = (acc * yv + l0 * (1 - z0[0])) % R
+    acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
+    for i in range(1, n_sets):
+        acc = (acc * yv + l0 * (z0[i] - zb[i - 1])) % R
+    cur = b * x % R
+    for i in range(n_sets):
+        left, right = z1[i], z0[i]
+        for c in range(i * chunk_len, min((i + 1) * chunk_len, n_cols)):
+            left = left * (a0[c] + b * sg[c] + g) % R
+            right = right * (a0[c] + cur + g) % R
+            cur = cur * delta % R
+        acc = (acc * yv + la * (left - right)) % R
+    A, S, PA, PS, PAm, Z, Z1 = ev("lk"), ev("table")[0], ev("pa"), ev("ps"), ev("pa", -1), ev("zl"), ev("zl", 1)
+    for c in range(len(A)):
+        acc = (acc * yv + l0 * (1 - Z[c])) % R
+        acc = (acc * yv + ll * (Z[c] * Z[c] - Z[c])) % R
+        acc = (acc * yv + la * (Z1[c] * (PA[c] + b) * (PS[c] + g) - Z[c] * (A[c] + b) * (S + g))) % R
+        acc = (acc * yv + l0 * (PA[c] - PS[c])) % R
+        acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
+    hx = to_int(api.eval_polys(h.reshape(1, -1, 4), O.fr_from_ints([x])[0]))[0]
+    assert acc == hx * (pow(x, n, R) - 1) % R

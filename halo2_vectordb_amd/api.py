@@ -452,6 +452,37 @@ def lookup_product(inputs, table, perm_inputs, perm_table, usable_rows, beta, ga
         out.free()
 
 
+def kate_div(coeffs, x):
+    """(p(X) - p(x)) / (X - x) per polynomial; returns (quotients (n_cols, n, 4), remainders p(x) (n_cols, 4))"""
+    lib = _lib.init()
+    coeffs, x = _fr(coeffs), _fr(x)
+    n_cols, n = coeffs.shape[0], coeffs.shape[1]
+    rem = np.zeros((n_cols, 4), dtype=np.uint64)
+    (out,) = _with_buffers([coeffs], [n_cols * n * 32], lambda c, o: check(lib.vdb_kate_div_dev(c, _sz(n_cols), _sz(n), _p(x), o, _p(rem))))
+    try:
+        return out.download((n_cols, n, 4)), rem
+    finally:
+        out.free()
+
+
+def poly_lincomb(polys, v):
+    """sum_c v^(n_cols-1-c) p_c, coefficient-wise: (n, 4)"""
+    lib = _lib.init()
+    polys, v = _fr(polys), _fr(v)
+    n_cols, n = polys.shape[0], polys.shape[1]
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    bufs = [DeviceBuffer(max(polys.nbytes, 32)), DeviceBuffer(max(zero.nbytes, 32))]
+    try:
+        bufs[0].upload(polys)
+        bufs[1].upload(zero)
+        check(lib.vdb_poly_lincomb_dev(bufs[0].ptr, _sz(n_cols), _sz(n), _p(v), bufs[1].ptr))
+        sync()
+        return bufs[1].download((n, 4))
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def grand_product(num, den):
     """z[c][0] = 1, z[c][i+1] = z[c][i] * num[c][i] / den[c][i]; num, den: (n_cols, n, 4) uint64 (Montgomery Fr)."""
     lib = _lib.init()

@@ -462,6 +462,77 @@ __global__ __launch_bounds__(256) void k_lookup_eval(const u256* __restrict__ a,
   st256(acc + j, h);
 }
 
+// ---- opening proofs: division by a linear factor (halo2 arithmetic::kate_division, [UPSTREAM-RECALL]) and the linear
+// combination of polynomials with powers of a challenge that precedes it -------------------------------------------------
+// q(X) = (p(X) - p(x)) / (X - x):  S(i) = sum_{j >= i} a_j x^(j-i) satisfies S(i) = a_i + x S(i+1); q_{i-1} = S(i), p(x) = S(0).
+// One 256-thread workgroup per polynomial walks it from the top in chunks of 256 x KD_E coefficients; thread t owns KD_E
+// consecutive coefficients (whole cache lines), evaluates them (Horner), the block turns the 256 values into suffix sums with
+// a log-step scan whose multiplier is squared each step, the carry of the chunk above comes in with one more product, and a
+// second Horner walk writes the quotient.  (2 KD_E + 9) / KD_E = 3.1 products per coefficient.
+#define KD_THREADS 256
+#define KD_E 8
+__global__ __launch_bounds__(KD_THREADS) void k_kate_div(const u256* __restrict__ coeff, uint64_t n, u256 x, u256 xe /* x^KD_E */, u256* __restrict__ quot,
+                                                         u256* __restrict__ rem) {
+  __shared__ u256 sh[KD_THREADS];
+  __shared__ u256 s_carry;
+  const uint64_t col = blockIdx.x;
+  const u256* a = coeff + col * n;
+  u256* q = quot + col * n;
+  const uint32_t t = threadIdx.x;
+  const u256 pw = mont_pow<Fr>(xe, u256_from_u64(KD_THREADS - 1 - t));  // x^(E (255 - t))
+  const uint64_t chunk = (uint64_t)KD_THREADS * KD_E;
+  if (t == 0) {
+    s_carry = u256_zero();
+    st256(q + n - 1, u256_zero());
+  }
+  __syncthreads();
+  for (uint64_t c = (n + chunk - 1) / chunk; c-- > 0;) {
+    const uint64_t lo = c * chunk + (uint64_t)t * KD_E;
+    u256 v[KD_E];
+#pragma unroll
+    for (int j = 0; j < KD_E; j++) v[j] = lo + j < n ? ld256(a + lo + j) : u256_zero();
+    u256 T = v[KD_E - 1];
+#pragma unroll
+    for (int j = KD_E - 2; j >= 0; j--) T = fr_add(fr_mul(T, x), v[j]);
+    // inclusive suffix scan R_t = sum_{t' >= t} T_t' X^(t' - t), X = x^E
+    sh[t] = T;
+    __syncthreads();
+    u256 m = xe;
+    for (uint32_t o = 1; o < KD_THREADS; o <<= 1) {
+      const bool on = t + o < KD_THREADS;
+      u256 other = on ? sh[t + o] : u256_zero();
+      __syncthreads();
+      if (on) {
+        T = fr_add(T, fr_mul(m, other));
+        sh[t] = T;
+      }
+      m = fr_mul(m, m);
+      __syncthreads();
+    }
+    const u256 carry = s_carry;
+    u256 s = fr_mul(pw, carry);                                   // S at the first index above this thread's coefficients
+    if (t + 1 < KD_THREADS) s = fr_add(s, sh[t + 1]);
+    __syncthreads();
+    if (t == 0) s_carry = fr_add(T, fr_mul(fr_mul(pw, xe), carry));  // S(c * chunk) = R_0 + X^256 carry
+#pragma unroll
+    for (int j = KD_E - 1; j >= 0; j--) {
+      const uint64_t i = lo + j;
+      s = fr_add(fr_mul(s, x), v[j]);
+      if (i >= 1 && i < n) st256(q + i - 1, s);
+    }
+    __syncthreads();
+  }
+  if (t == 0 && rem) st256(rem + col, s_carry);
+}
+// out = sum_c v^(n_cols-1-c) p_c  (Horner over the polynomials: out = out * v + p_c), one thread per coefficient
+__global__ __launch_bounds__(256) void k_poly_lincomb(const u256* __restrict__ polys, uint64_t n_cols, uint64_t n, u256 v, u256* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 acc = ld256(out + i);
+  for (uint64_t c = 0; c < n_cols; c++) acc = fr_add(fr_mul(acc, v), ld256(polys + c * n + i));
+  st256(out + i, acc);
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -715,6 +786,47 @@ int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev
     VDB_PROF("k_lookup_eval");
     hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
                        as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, as_u256(acc_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_kate_div_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, vdb_fr* quot_dev, vdb_fr* rem_host) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && x && quot_dev && n >= 1, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  u256 xv;
+  memcpy(&xv, x, 32);
+  u256 xe = xv;
+  for (int i = 1; i < KD_E; i <<= 1) xe = fr_mul(xe, xe);  // KD_E is a power of two
+  u256* drem = nullptr;
+  if (rem_host) {
+    drem = (u256*)scratch_get(5, n_cols * sizeof(u256));
+    if (!drem) return VDB_ERR_OOM;
+  }
+  {
+    VDB_PROF("k_kate_div");
+    hipLaunchKernelGGL(k_kate_div, dim3((unsigned)n_cols), dim3(KD_THREADS), 0, cx.stream, as_u256(coeff_dev), (uint64_t)n, xv, xe, as_u256(quot_dev), drem);
+  }
+  VDB_LAUNCH_CHECK();
+  if (rem_host) {
+    VDB_HIP(hipMemcpyAsync(rem_host, drem, n_cols * sizeof(u256), hipMemcpyDeviceToHost, cx.stream));
+    VDB_HIP(hipStreamSynchronize(cx.stream));
+  }
+  return VDB_OK;
+}
+
+int vdb_poly_lincomb_dev(const vdb_fr* polys_dev, size_t n_cols, size_t n, const vdb_fr* v, vdb_fr* acc_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(polys_dev && v && acc_dev, "bad argument");
+  if (n_cols == 0 || n == 0) return VDB_OK;
+  u256 vv;
+  memcpy(&vv, v, 32);
+  {
+    VDB_PROF("k_poly_lincomb");
+    hipLaunchKernelGGL(k_poly_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(polys_dev), (uint64_t)n_cols, (uint64_t)n, vv,
+                       as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

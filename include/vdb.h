@@ -271,6 +271,14 @@ int vdb_permutation_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigma_ext_
 int vdb_lookup_eval_dev(const vdb_fr *input_ext_dev, const vdb_fr *table_ext_dev, const vdb_fr *perm_input_ext_dev, const vdb_fr *perm_table_ext_dev,
                         const vdb_fr *z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
                         const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);
+/* Opening proofs (halo2 poly/kzg/multiopen: both GWC and SHPLONK are built from these two steps and a commit).
+ * vdb_poly_lincomb_dev: acc <- Horner over the n_cols polynomials, acc = acc * v + p_c, coefficient by coefficient (acc_dev:
+ * n coefficients, read and written; zero it first).
+ * vdb_kate_div_dev (arithmetic::kate_division): per polynomial of n coefficients q(X) = (p(X) - p(x)) / (X - x), n coefficients
+ * written (the top one zero); rem_host (may be NULL) receives p(x).  Dividing by a product of linear factors — the vanishing
+ * polynomial of a SHPLONK rotation set — is this call once per point. */
+int vdb_poly_lincomb_dev(const vdb_fr *polys_dev, size_t n_cols, size_t n, const vdb_fr *v, vdb_fr *acc_dev);
+int vdb_kate_div_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *quot_dev, vdb_fr *rem_host);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

@@ -458,3 +458,69 @@ def test_verifier_identity_at_a_random_point(api, O):
         acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
     hx = to_int(api.eval_polys(h.reshape(1, -1, 4), O.fr_from_ints([x])[0]))[0]
     assert acc == hx * (pow(x, n, R) - 1) % R
+
+
+def _kate_div_ints(a, x, R):
+    """halo2 arithmetic::kate_division restated: q_{n-2} = a_{n-1}, q_{i-1} = a_i + x q_i"""
+    q = [0] * len(a)
+    s = 0
+    for i in range(len(a) - 1, 0, -1):
+        s = (a[i] + x * s) % R
+        q[i - 1] = s
+    return q, (a[0] + x * s) % R
+
+
+@pytest.mark.parametrize("n_cols,n", [(1, 1), (2, 2), (3, 7), (2, 2048), (2, 2049), (3, 4100), (2, 65536)])
+def test_kate_division_matches_restatement(api, O, n_cols, n):
+    rng = np.random.default_rng(300 + n)
+    coeffs = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    for x in (O.random_fr(rng, 1)[0], O.fr_from_ints([0])[0], O.fr_from_ints([1])[0]):
+        q, rem = api.kate_div(coeffs, x)
+        xi = O.fr_to_ints(x.reshape(1, 4))[0]
+        assert np.array_equal(rem, api.eval_polys(coeffs, x))
+        for c in range(n_cols if n <= 4100 else 1):
+            want_q, want_r = _kate_div_ints(O.fr_to_ints(coeffs[c]), xi, O.R_MOD)
+            assert O.fr_to_ints(q[c]) == want_q and O.fr_to_ints(rem[c].reshape(1, 4))[0] == want_r
+
+
+def test_poly_lincomb_is_horner_over_the_polynomials(api, O):
+    rng = np.random.default_rng(9)
+    n_cols, n = 5, 3000
+    polys = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    v = O.random_fr(rng, 1)[0]
+    acc = np.zeros((n, 4), dtype=np.uint64)
+    for c in range(n_cols):
+        acc = O.fr_add(O.fr_mul(acc, np.tile(v, (n, 1))), polys[c])
+    assert np.array_equal(api.poly_lincomb(polys, v), acc)
+
+
+def test_kzg_opening_verifies_in_the_exponent(api, O):
+    """a complete batched KZG opening from the bricks: commit the polynomials, combine them with powers of v, divide by
+    (X - x), commit the quotient; the pairing check e(C - [y]G, H) = e(W, [tau - x]H) is verified in the exponent, which the
+    test can do because it knows tau:  C - [y]G == [tau - x] W  as group elements (oracle group arithmetic)."""
+    rng = np.random.default_rng(1234)
+    k, n_polys = 10, 4
+    n = 1 << k
+    tau = 0xC0FFEE1234567
+    g, _ = O.srs_from_tau(k, tau)
+    srs = api.Srs(k, g, None)
+    polys = O.random_fr(rng, n_polys * n).reshape(n_polys, n, 4)
+    commits = api.msm_batch(srs, polys, basis=0)
+    v, x = O.random_fr(rng, 1)[0], O.random_fr(rng, 1)[0]
+    comb = api.poly_lincomb(polys, v)
+    q, rem = api.kate_div(comb.reshape(1, n, 4), x)
+    W = api.msm(srs, q[0], basis=0)
+    srs.free()
+    R = O.R_MOD
+    vi, xi, yi = (O.fr_to_ints(a.reshape(1, 4))[0] for a in (v, x, rem[0]))
+    # the combined evaluation is the same combination of the individual evaluations
+    evals = O.fr_to_ints(api.eval_polys(polys, x))
+    acc = 0
+    for e in evals:
+        acc = (acc * vi + e) % R
+    assert acc == yi
+    # C = sum v^(m-1-c) C_c (the verifier's side), minus [y] G
+    powers = [pow(vi, n_polys - 1 - c, R) for c in range(n_polys)] + [(-yi) % R]
+    lhs = O.msm_naive(O.fr_from_ints(powers), np.concatenate([commits, O.g1_generator().reshape(1, 8)]))
+    rhs = O.msm_naive(O.fr_from_ints([(tau - xi) % R]), W.reshape(1, 8))
+    assert np.array_equal(lhs, rhs) and lhs.any()

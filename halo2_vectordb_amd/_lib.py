@@ -78,6 +78,7 @@ _SIGNATURES = {
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
     "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
     "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
+    "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
     "vdb_lookup_eval_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],

@@ -533,6 +533,14 @@ __global__ __launch_bounds__(256) void k_poly_lincomb(const u256* __restrict__ p
   st256(out + i, acc);
 }
 
+// rows [from, n) of every column <- src (n_cols x (n - from)): the blinding rows the prover appends to the columns it derives
+__global__ __launch_bounds__(256) void k_fill_rows(u256* __restrict__ cols, uint64_t n, uint64_t from, const u256* __restrict__ src, uint64_t total) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t cnt = n - from, c = i / cnt, r = i % cnt;
+  st256(cols + c * n + from + r, ld256(src + i));
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -787,6 +795,17 @@ int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev
     hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
                        as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, as_u256(acc_dev));
   }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_fill_rows_dev(vdb_fr* cols_dev, size_t n_cols, size_t n, size_t from_row, const vdb_fr* src_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cols_dev && src_dev && from_row <= n, "bad argument");
+  const uint64_t total = (uint64_t)n_cols * (n - from_row);
+  if (total == 0) return VDB_OK;
+  hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(cols_dev), (uint64_t)n, (uint64_t)from_row,
+                     as_u256(src_dev), total);
   VDB_LAUNCH_CHECK();
   return VDB_OK;
 }

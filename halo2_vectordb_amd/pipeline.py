@@ -166,6 +166,7 @@ class KmeansHotPath:
         tau = from_ints([self.tau * (1 << 256) % R])[0]
         g, gl = api.srs_setup_unsafe(self.k, tau)
         self.g_lagrange = gl
+        self.g_monomial = g
         self.srs = api.Srs(self.k, None, gl)
         # column sharding over ranks: a block of the advice columns and a block of the lookup columns each
         self.shards = column_shards(self.n_adv_cols, self.n_lk_cols, self.world)
@@ -257,15 +258,16 @@ class KmeansHotPath:
         self.qvec = api.quantize(self.vectors_f64, self.P)
         self.d_vec.upload(self.qvec)
 
-    def _layout(self):
-        """My block of advice columns followed by my block of lookup columns, compact in d_cols."""
+    def _layout(self, dest=None):
+        """My block of advice columns followed by my block of lookup columns, compact in d_cols (or `dest`)."""
         lib, B = self.lib, 32
+        d_cols = self.d_cols if dest is None else dest
         if self.my_adv:
             check(lib.vdb_layout_columns_range_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
-                                                   ctypes.c_uint64(self.a_lo), ctypes.c_uint64(self.a_hi), self.d_cols.ptr, self.d_blind.ptr, N_BLIND))
+                                                   ctypes.c_uint64(self.a_lo), ctypes.c_uint64(self.a_hi), d_cols.ptr, self.d_blind.ptr, N_BLIND))
         if self.my_lk:
             check(lib.vdb_layout_lookup_range_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, ctypes.c_uint64(self.l_lo),
-                                                  ctypes.c_uint64(self.l_hi), self.d_cols.at(self.my_adv * self.rows * B),
+                                                  ctypes.c_uint64(self.l_hi), d_cols.at(self.my_adv * self.rows * B),
                                                   self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND))
 
     def _witness(self, sel=None):

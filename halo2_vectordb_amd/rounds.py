@@ -1,0 +1,268 @@
+"""The prover's rounds after the advice commitments, composed from the device bricks on the buffers the
+k-means hot path leaves resident: lookup permutation -> products -> quotient -> evaluations -> openings, every polynomial
+step on the GPU, nothing but commitments, evaluations and challenges crossing the C ABI.
+
+What this is not: the Fiat–Shamir transcript (f2) — the challenges are arguments — and halo2's exact proof layout: the
+openings are one quotient per rotation point (GWC style; SHPLONK regroups the same divisions), the copy constraints are
+the ones the column layout creates (the overlap cell between consecutive columns), not the gadgets' own cell reuse, and
+the order of the quotient's terms follows plonk/evaluation.rs as recalled ([UPSTREAM-RECALL]; parity unpinned, SURVEY
+§8c).  What the tests hold it to instead is what a verifier checks: the quotient identity at a random point recombined
+from the returned evaluations, and every opening against its commitments in the exponent (tests/test_gpu_rounds.py).
+"""
+import ctypes
+
+import numpy as np
+
+from . import api
+from ._lib import check
+from .pipeline import N_BLIND
+
+B = 32
+EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
+CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def _sz(v):
+    return ctypes.c_size_t(int(v))
+
+
+def _fr_from_int(v):
+    v = v % R_MOD * (1 << 256) % R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def _fr_to_int(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(4)
+    v = sum(int(a[i]) << (64 * i) for i in range(4))
+    return v * pow(1 << 256, -1, R_MOD) % R_MOD
+
+
+class _Poly:
+    """a set of polynomials in the three forms the rounds use; any of them may be absent"""
+
+    def __init__(self, name, n_cols, lag=None, coeff=None, ext=None, commits=None):
+        self.name, self.n_cols, self.lag, self.coeff, self.ext, self.commits = name, n_cols, lag, coeff, ext, commits
+
+    def free(self):
+        for b in (self.lag, self.coeff, self.ext):
+            if b is not None and getattr(b, "_owned", True):
+                b.free()
+
+
+class ProverRounds:
+    def __init__(self, hp):
+        assert hp.world == 1, "the prover rounds run on one rank's full column set"
+        self.hp, self.lib = hp, hp.lib
+        self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
+        self.usable = hp.rows - N_BLIND
+        self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
+        self.n_sets = -(-self.n_cols // CHUNK_LEN)
+        self.delta = api.fr_delta()
+        self.fixed = {}
+
+    # ------------------------------------------------------------------ helpers on device-resident columns
+    def _to_coeff(self, lag_buf, n_cols):
+        """copy of Lagrange-form columns turned into coefficients"""
+        c = api.DeviceBuffer(max(n_cols, 1) * self.rows * B)
+        check(self.lib.vdb_memcpy_d2d(c.ptr, lag_buf.ptr, _sz(n_cols * self.rows * B)))
+        check(self.lib.vdb_lagrange_to_coeff_dev(c.ptr, _sz(n_cols), self.k))
+        return c
+
+    def _to_ext(self, coeff_buf, n_cols):
+        e = api.DeviceBuffer(max(n_cols, 1) * self.ne * B)
+        check(self.lib.vdb_coeff_to_extended_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, EXT_K))
+        return e
+
+    def _commit(self, buf, n_cols, basis):
+        out = np.zeros((n_cols, 8), dtype=np.uint64)
+        srs = self.hp.srs if basis == 1 else self.srs_m
+        check(self.lib.vdb_msm_batch_dev(srs.h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
+        return out
+
+    def _blind(self, buf, n_cols, from_row, rng):
+        cnt = self.rows - from_row
+        raw = rng.integers(0, 1 << 62, size=(n_cols * cnt, 4), dtype=np.uint64)
+        raw[:, 3] &= np.uint64((1 << 61) - 1)                                      # any value below r is a field element
+        d = api.DeviceBuffer(raw.nbytes)
+        d.upload(raw)
+        check(self.lib.vdb_fill_rows_dev(buf.ptr, _sz(n_cols), _sz(self.rows), _sz(from_row), d.ptr))
+        api.sync()
+        d.free()
+
+    def _fixed_poly(self, name, lag_buf, n_cols):
+        coeff = self._to_coeff(lag_buf, n_cols)
+        p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols), commits=self._commit(lag_buf, n_cols, 1))
+        self.fixed[name] = p
+        return p
+
+    # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
+    def keygen(self):
+        hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
+        self.srs_m = api.Srs(k, hp.g_monomial, None)
+        # gate selectors from a flag-recording witness run
+        d_flags = api.DeviceBuffer(hp.n_cells)
+        check(lib.vdb_memset_dev(d_flags.ptr, 0, _sz(hp.n_cells)))
+        hp._witness(sel=d_flags)
+        d_q = api.DeviceBuffer(self.n_adv * rows * B)
+        check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+        d_flags.free()
+        self._fixed_poly("sel", d_q, self.n_adv)
+        # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
+        mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
+        for c in range(self.n_adv - 1):
+            last = int(hp.bp[c])
+            mapping[c, last], mapping[c + 1, 0] = np.uint64((c + 1) << 32), np.uint64((c << 32) | last)
+        d_map = api.DeviceBuffer(mapping.nbytes)
+        d_map.upload(np.ascontiguousarray(mapping))
+        d_sigma = api.DeviceBuffer(self.n_cols * rows * B)
+        check(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_cols), k, api._p(self.delta), d_sigma.ptr))
+        d_map.free()
+        self._fixed_poly("sigma", d_sigma, self.n_cols)
+        # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
+        tab = np.arange(rows, dtype=np.uint64)
+        tab[tab >= (1 << hp.L)] = 0
+        d_tab = api.DeviceBuffer(rows * B)
+        d_tab.upload(api.fr_from_canonical(np.stack([tab, np.zeros_like(tab), np.zeros_like(tab), np.zeros_like(tab)], axis=1)))
+        self._fixed_poly("table", d_tab, 1)
+        lag = np.zeros((3, rows, 4), dtype=np.uint64)
+        one = _fr_from_int(1)
+        lag[0, 0], lag[1, self.usable], lag[2, : self.usable] = one, one, one
+        d_l = api.DeviceBuffer(lag.nbytes)
+        d_l.upload(lag)
+        self._fixed_poly("lag", d_l, 3)
+        api.sync()
+        return self
+
+    # ------------------------------------------------------------------ the rounds
+    def prove(self, challenges, seed=1, timings=None):
+        """challenges: dict of Montgomery field elements beta, gamma, y, x, v (what the transcript would squeeze).
+        Returns dict(commitments, evals, openings): commitments[name] (n, 8); evals[(name, rotation)] list of ints;
+        openings: list of dict(rotation, point, polys=[names in combination order], eval, W)."""
+        hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
+        rng = np.random.default_rng(seed)
+        ch = {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
+        p = {name: api._p(v) for name, v in ch.items()}
+        usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
+        fx = self.fixed
+        T = {} if timings is None else timings
+
+        def stage(name, fn):
+            api.timer_start()
+            r = fn()
+            T[name] = T.get(name, 0.0) + api.timer_stop()
+            return r
+
+        # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
+        adv_commits = hp.step(T).copy()
+        adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
+        d_lag = api.DeviceBuffer(n_cols * rows * B)
+        stage("relayout", lambda: hp._layout(dest=d_lag))
+        lk_lag = ctypes.c_void_p(d_lag.ptr.value + n_adv * rows * B)
+        polys = {"adv": adv}
+
+        # round 2: the lookup argument's permuted columns
+        d_pa, d_ps = api.DeviceBuffer(max(n_lk, 1) * rows * B), api.DeviceBuffer(max(n_lk, 1) * rows * B)
+
+        def permute():
+            check(lib.vdb_lookup_permute_dev(lk_lag, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
+        stage("lookup_permute", permute)
+        self._blind(d_pa, n_lk, usable, rng)
+        self._blind(d_ps, n_lk, usable, rng)
+        polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1)))
+        polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1)))
+
+        # round 3 (beta, gamma): the running products of both arguments
+        d_zp, d_zl = api.DeviceBuffer(n_sets * rows * B), api.DeviceBuffer(max(n_lk, 1) * rows * B)
+
+        def products():
+            check(lib.vdb_permutation_product_dev(d_lag.ptr, fx["sigma"].lag.ptr, _sz(n_cols), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
+                                                  api._p(self.delta), d_zp.ptr))
+            check(lib.vdb_lookup_product_dev(lk_lag, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
+                                             d_zl.ptr))
+        stage("products", products)
+        self._blind(d_zp, n_sets, usable + 1, rng)
+        self._blind(d_zl, n_lk, usable + 1, rng)
+        polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
+        polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit(d_zl, n_lk, 1)))
+        d_lag.free()
+
+        # round 4 (y): the quotient
+        def derived_forms():
+            for name in ("pa", "ps", "zp", "zl"):
+                q = polys[name]
+                check(lib.vdb_lagrange_to_coeff_dev(q.lag.ptr, _sz(q.n_cols), k))      # in place: the Lagrange form is not needed again
+                q.coeff, q.lag = q.lag, None
+                q.ext = self._to_ext(q.coeff, q.n_cols)
+        stage("derived_ntt", derived_forms)
+        d_h = api.DeviceBuffer(ne * B)
+        l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
+
+        def quotient():
+            check(lib.vdb_memset_dev(d_h.ptr, 0, _sz(ne * B)))
+            check(lib.vdb_gate_eval_dev(adv.ext.ptr, fx["sel"].ext.ptr, _sz(n_adv), k, EXT_K, p["y"], d_h.ptr))
+            check(lib.vdb_permutation_eval_dev(adv.ext.ptr, fx["sigma"].ext.ptr, polys["zp"].ext.ptr, _sz(n_cols), _sz(CHUNK_LEN), k, EXT_K, _sz(usable),
+                                               l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr))
+            check(lib.vdb_lookup_eval_dev(ctypes.c_void_p(adv.ext.ptr.value + n_adv * ne * B), fx["table"].ext.ptr, polys["pa"].ext.ptr, polys["ps"].ext.ptr,
+                                          polys["zl"].ext.ptr, _sz(n_lk), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], d_h.ptr))
+            check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
+            check(lib.vdb_extended_to_coeff_dev(d_h.ptr, _sz(1), k, EXT_K))
+        stage("quotient", quotient)
+        n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
+        polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)))
+        for q in ("pa", "ps", "zp", "zl"):
+            polys[q].ext.free()
+            polys[q].ext = None
+
+        # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
+        # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
+        allp = {**polys, **fx}
+        opened = {0: ["adv", "sel", "sigma", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
+                  -N_BLIND: ["zp"]}
+        x_int = _fr_to_int(ch["x"])
+        w_int = _fr_to_int(api.root_of_unity(k))
+        evals, points = {}, {}
+
+        def evaluate():
+            for rot, names in opened.items():
+                pt = x_int * pow(w_int, rot % rows, R_MOD) % R_MOD
+                points[rot] = pt
+                ptm = _fr_from_int(pt)
+                for name in names:
+                    q = allp[name]
+                    out = np.zeros((q.n_cols, 4), dtype=np.uint64)
+                    check(lib.vdb_eval_polys_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(ptm), api._p(out)))
+                    evals[(name, rot)] = out
+        stage("evaluations", evaluate)
+
+        # round 6 (v): one opening per rotation point: combine with powers of v, divide by (X - point), commit
+        openings = []
+        d_comb, d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
+
+        def open_all():
+            for rot, names in opened.items():
+                check(lib.vdb_memset_dev(d_comb.ptr, 0, _sz(rows * B)))
+                for name in names:
+                    q = allp[name]
+                    check(lib.vdb_poly_lincomb_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), p["v"], d_comb.ptr))
+                ptm = _fr_from_int(points[rot])
+                rem = np.zeros((1, 4), dtype=np.uint64)
+                check(lib.vdb_kate_div_dev(d_comb.ptr, _sz(1), _sz(rows), api._p(ptm), d_quot.ptr, api._p(rem)))
+                W = self._commit(d_quot, 1, 0)[0]
+                openings.append(dict(rotation=rot, point=points[rot], polys=list(names), eval=rem[0].copy(), W=W))
+        stage("openings", open_all)
+        d_comb.free(), d_quot.free()
+        api.sync()
+        commitments = {name: q.commits for name, q in allp.items()}
+        for q in ("pa", "ps", "zp", "zl"):
+            polys[q].coeff.free()
+        d_h.free()
+        return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points)
+
+    def free(self):
+        for q in self.fixed.values():
+            q.free()
+        self.fixed = {}
+        if getattr(self, "srs_m", None) is not None:
+            self.srs_m.free()
+            self.srs_m = None

@@ -271,6 +271,9 @@ int vdb_permutation_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigma_ext_
 int vdb_lookup_eval_dev(const vdb_fr *input_ext_dev, const vdb_fr *table_ext_dev, const vdb_fr *perm_input_ext_dev, const vdb_fr *perm_table_ext_dev,
                         const vdb_fr *z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
                         const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);
+/* rows [from_row, n) of each of the n_cols columns <- src_dev (n_cols x (n - from_row) values): the blinding rows of the
+ * columns the prover derives (permuted columns, product columns) */
+int vdb_fill_rows_dev(vdb_fr *cols_dev, size_t n_cols, size_t n, size_t from_row, const vdb_fr *src_dev);
 /* Opening proofs (halo2 poly/kzg/multiopen: both GWC and SHPLONK are built from these two steps and a commit).
  * vdb_poly_lincomb_dev: acc <- Horner over the n_cols polynomials, acc = acc * v + p_c, coefficient by coefficient (acc_dev:
  * n coefficients, read and written; zero it first).

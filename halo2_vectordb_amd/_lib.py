@@ -78,6 +78,9 @@ _SIGNATURES = {
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
     "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
     "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
+    "vdb_transcript_new": [_U32, _U32, _U32, _P], "vdb_transcript_free": [_P], "vdb_transcript_common_scalar": [_P, _P], "vdb_transcript_common_point": [_P, _P],
+    "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
+    "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -98,9 +101,7 @@ def _declare(lib):
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        if name != "vdb_srs_free":
-            fn.restype = ctypes.c_int
-    lib.vdb_srs_free.restype = None
+        fn.restype = None if name in ("vdb_srs_free", "vdb_transcript_free") else ctypes.c_int
 
 
 def check(rc):

@@ -500,6 +500,50 @@ def grand_product(num, den):
             b.free()
 
 
+class Transcript:
+    """Fiat–Shamir transcript + proof bytes (vdb_transcript_*): Poseidon sponge of width t; host code, no GPU needed."""
+
+    def __init__(self, t=5, r_f=8, r_p=60):
+        self.L = _lib.load()
+        self.h = ctypes.c_void_p()
+        check(self.L.vdb_transcript_new(t, r_f, r_p, ctypes.byref(self.h)))
+
+    def common_scalar(self, s):
+        check(self.L.vdb_transcript_common_scalar(self.h, _p(_fr(s))))
+
+    def common_point(self, pt):
+        check(self.L.vdb_transcript_common_point(self.h, _p(np.ascontiguousarray(pt, dtype=np.uint64))))
+
+    def write_scalar(self, s):
+        check(self.L.vdb_transcript_write_scalar(self.h, _p(_fr(s))))
+
+    def write_point(self, pt):
+        check(self.L.vdb_transcript_write_point(self.h, _p(np.ascontiguousarray(pt, dtype=np.uint64))))
+
+    def squeeze(self):
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.L.vdb_transcript_squeeze(self.h, _p(out)))
+        return out
+
+    def proof(self):
+        n = ctypes.c_size_t()
+        check(self.L.vdb_transcript_proof_len(self.h, ctypes.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        check(self.L.vdb_transcript_proof_bytes(self.h, _p(buf), _sz(buf.size)))
+        return buf[: n.value].tobytes()
+
+    def free(self):
+        if self.h:
+            self.L.vdb_transcript_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """A raw HBM allocation owned by the library's context."""
 

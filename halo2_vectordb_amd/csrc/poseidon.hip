@@ -117,6 +117,20 @@ Mat mat_inverse(Mat w) {
 
 }  // namespace
 
+// Plain (unoptimised) parameters for any width: round constants row by row and the Cauchy MDS matrix, Montgomery form.
+// Used by the transcript sponge (transcript.hip), whose width differs from the chip's.
+void poseidon_plain_params(int t, int r_f, int r_p, std::vector<u256>& rc, std::vector<u256>& mds) {
+  GrainLfsr g(254, t, r_f, r_p);
+  rc.resize((size_t)(r_f + r_p) * t);
+  for (auto& c : rc) c = g.next_field(true);
+  std::vector<u256> xs(t), ys(t);
+  for (auto& x : xs) x = g.next_field(false);
+  for (auto& y : ys) y = g.next_field(false);
+  mds.resize((size_t)t * t);
+  for (int i = 0; i < t; i++)
+    for (int j = 0; j < t; j++) mds[(size_t)i * t + j] = mont_inv<Fr>(fr_add(xs[i], ys[j]));
+}
+
 // Builds the optimized schedule used by the halo2-lib Poseidon chip (PSE poseidon `Spec`):
 // round constants folded through M^-1, partial rounds as sparse matrices M = M' * M''.
 void poseidon_build_spec(PoseidonSpec* out) {

@@ -3,6 +3,8 @@
 // witness-trace kernels (b5).  Parameters as the reference's call sites use them:
 // T=3, RATE=2, R_F=8, R_P=57 (/root/reference/examples/merkle.rs:15-18, tests/vectordb/mod.rs:7-10).
 #pragma once
+#include <vector>
+
 #include "field.hpp"
 
 namespace vdb {
@@ -26,6 +28,8 @@ struct PoseidonSpec {
   u256 one;
 };
 
+// host: plain parameters (round constants, MDS) for any width
+void poseidon_plain_params(int t, int r_f, int r_p, std::vector<u256>& rc, std::vector<u256>& mds);
 // host: Grain-LFSR parameter generation + optimisation (poseidon_spec.cpp)
 void poseidon_build_spec(PoseidonSpec* out);
 // device-resident copy (created on first use)

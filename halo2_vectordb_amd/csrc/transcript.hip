@@ -1,0 +1,157 @@
+// Fiat–Shamir transcript and proof byte stream — host code only, sequential and tiny by nature.
+// Stands in for snark_verifier's PoseidonTranscript<NativeLoader, _> as the reference constructs it
+// (/root/reference/src/scaffold/mod.rs:309-310: PoseidonTranscript::<NativeLoader, _>::new::<0>), [UPSTREAM-RECALL]:
+//   * Poseidon sponge over BN254 Fr with T = 5, RATE = 4, R_F = 8, R_P = 60 (snark-verifier-sdk's constants), parameters
+//     from the Grain LFSR as for the chip; state starts [2^64, 0, 0, 0, 0] and is never reset;
+//   * absorbed values are buffered; a squeeze feeds the buffer RATE values at a time — a short chunk gets +1 after its last
+//     value, and when the buffer length is a multiple of RATE (empty included) one more permutation absorbs only that +1 —
+//     and returns state[1] (the same sponge rule as PoseidonChip);
+//   * a G1 point is absorbed as its affine x and y, each reduced into Fr; the identity as (0, 0);
+//   * written to the proof: points compressed to 32 bytes (x little-endian, bit 6 of the last byte = y is odd, the identity
+//     all zero), scalars as 32 little-endian bytes of the canonical value.
+// Parity unpinned: the parameters and encodings above are recalled, the reference holds no proof bytes.
+// The sponge is cross-checked against an independent Python restatement (tests/test_transcript_cpu.py), and at T = 3
+// against the chip's optimised schedule.
+#include <vector>
+
+#include "common.hpp"
+#include "poseidon.hpp"
+
+using namespace vdb;
+
+struct vdb_transcript {
+  int t, rate, r_f, r_p;
+  std::vector<u256> rc, mds, state, buf;
+  std::vector<uint8_t> bytes;
+};
+
+namespace {
+
+void permute(vdb_transcript* tr) {
+  const int t = tr->t, half = tr->r_f / 2;
+  std::vector<u256>& st = tr->state;
+  std::vector<u256> nx(t);
+  for (int r = 0; r < tr->r_f + tr->r_p; r++) {
+    for (int i = 0; i < t; i++) st[i] = fr_add(st[i], tr->rc[(size_t)r * t + i]);
+    const bool full = r < half || r >= half + tr->r_p;
+    for (int i = 0; i < (full ? t : 1); i++) {
+      const u256 x2 = fr_mul(st[i], st[i]);
+      st[i] = fr_mul(fr_mul(x2, x2), st[i]);
+    }
+    for (int i = 0; i < t; i++) {
+      u256 acc = fr_mul(tr->mds[(size_t)i * t], st[0]);
+      for (int j = 1; j < t; j++) acc = fr_add(acc, fr_mul(tr->mds[(size_t)i * t + j], st[j]));
+      nx[i] = acc;
+    }
+    st = nx;
+  }
+}
+
+void absorb_chunk(vdb_transcript* tr, const u256* in, int n_in) {
+  for (int i = 0; i < n_in; i++) tr->state[1 + i] = fr_add(tr->state[1 + i], in[i]);
+  if (n_in < tr->rate) tr->state[1 + n_in] = fr_add(tr->state[1 + n_in], mont_one<Fr>());
+  permute(tr);
+}
+
+// canonical integer of an Fq element (Montgomery in memory) reduced into Fr, Montgomery
+u256 fq_to_fr(const u256& a_mont) {
+  u256 c = from_mont<Fq>(a_mont);
+  const u256 r = mod_p<Fr>();
+  while (u256_geq(c, r)) {
+    u256 d;
+    u256_sub(d, c, r);
+    c = d;
+  }
+  return to_mont<Fr>(c);
+}
+
+void put_le(std::vector<uint8_t>& out, const u256& canonical, uint8_t top_flags) {
+  for (int w = 0; w < 8; w++)
+    for (int b = 0; b < 4; b++) out.push_back((uint8_t)(canonical.w[w] >> (8 * b)));
+  out.back() |= top_flags;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript** out) {
+  VDB_ARG(out && t >= 2 && t <= 16 && r_f >= 2 && r_f % 2 == 0 && r_f <= 64 && r_p <= 256, "bad argument");
+  vdb_transcript* tr = new (std::nothrow) vdb_transcript();
+  if (!tr) return VDB_ERR_OOM;
+  tr->t = (int)t;
+  tr->rate = (int)t - 1;
+  tr->r_f = (int)r_f;
+  tr->r_p = (int)r_p;
+  poseidon_plain_params(tr->t, tr->r_f, tr->r_p, tr->rc, tr->mds);
+  tr->state.assign(t, u256_zero());
+  u256 cap = u256_zero();
+  cap.w[2] = 1;  // 2^64
+  tr->state[0] = to_mont<Fr>(cap);
+  *out = tr;
+  return VDB_OK;
+}
+
+void vdb_transcript_free(vdb_transcript* tr) { delete tr; }
+
+int vdb_transcript_common_scalar(vdb_transcript* tr, const vdb_fr* s) {
+  VDB_ARG(tr && s, "null pointer");
+  u256 v;
+  memcpy(&v, s, 32);
+  tr->buf.push_back(v);
+  return VDB_OK;
+}
+
+int vdb_transcript_common_point(vdb_transcript* tr, const vdb_g1* p) {
+  VDB_ARG(tr && p, "null pointer");
+  u256 xy[2];
+  memcpy(xy, p, 64);
+  tr->buf.push_back(fq_to_fr(xy[0]));
+  tr->buf.push_back(fq_to_fr(xy[1]));
+  return VDB_OK;
+}
+
+int vdb_transcript_write_scalar(vdb_transcript* tr, const vdb_fr* s) {
+  int rc = vdb_transcript_common_scalar(tr, s);
+  if (rc) return rc;
+  u256 v;
+  memcpy(&v, s, 32);
+  put_le(tr->bytes, from_mont<Fr>(v), 0);
+  return VDB_OK;
+}
+
+int vdb_transcript_write_point(vdb_transcript* tr, const vdb_g1* p) {
+  int rc = vdb_transcript_common_point(tr, p);
+  if (rc) return rc;
+  u256 xy[2];
+  memcpy(xy, p, 64);
+  const u256 x = from_mont<Fq>(xy[0]), y = from_mont<Fq>(xy[1]);
+  const bool identity = u256_is_zero(x) && u256_is_zero(y);
+  put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? 0x40 : 0);
+  return VDB_OK;
+}
+
+int vdb_transcript_squeeze(vdb_transcript* tr, vdb_fr* out) {
+  VDB_ARG(tr && out, "null pointer");
+  const size_t n = tr->buf.size();
+  for (size_t i = 0; i < n; i += tr->rate) absorb_chunk(tr, tr->buf.data() + i, (int)(n - i < (size_t)tr->rate ? n - i : (size_t)tr->rate));
+  if (n % tr->rate == 0) absorb_chunk(tr, nullptr, 0);
+  tr->buf.clear();
+  memcpy(out, &tr->state[1], 32);
+  return VDB_OK;
+}
+
+int vdb_transcript_proof_len(const vdb_transcript* tr, size_t* len) {
+  VDB_ARG(tr && len, "null pointer");
+  *len = tr->bytes.size();
+  return VDB_OK;
+}
+
+int vdb_transcript_proof_bytes(const vdb_transcript* tr, uint8_t* out, size_t cap) {
+  VDB_ARG(tr && (out || tr->bytes.empty()), "null pointer");
+  VDB_ARG(cap >= tr->bytes.size(), "buffer too small");
+  if (!tr->bytes.empty()) memcpy(out, tr->bytes.data(), tr->bytes.size());
+  return VDB_OK;
+}
+
+}  // extern "C"

@@ -300,6 +300,22 @@ int vdb_divide_by_vanishing_dev(vdb_fr *h_ext_dev, uint32_t k, uint32_t ext_k);
 int vdb_layout_selectors_dev(const uint8_t *flags_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, vdb_fr *q_dev);
 int vdb_fr_root_of_unity(uint32_t k, vdb_fr *out);
 
+/* ---- f2 Fiat–Shamir transcript + proof byte stream: stands in for snark_verifier's PoseidonTranscript<NativeLoader, _>
+ *      (src/scaffold/mod.rs:309-310) and the proof writer behind gen_snark_shplonk (src/scaffold/mod.rs:296).  Host code.
+ *      Poseidon sponge of width t (the reference's transcript: t = 5, r_f = 8, r_p = 60 [UPSTREAM-RECALL]); values are
+ *      buffered and absorbed at the next squeeze, which returns state[1]; `write_*` = `common_*` + append to the proof
+ *      (points: 32 bytes, x little-endian, bit 6 of the last byte = y odd; scalars: 32 bytes little-endian canonical). */
+typedef struct vdb_transcript vdb_transcript;
+int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript **out);
+void vdb_transcript_free(vdb_transcript *tr);
+int vdb_transcript_common_scalar(vdb_transcript *tr, const vdb_fr *s);
+int vdb_transcript_common_point(vdb_transcript *tr, const vdb_g1 *p);
+int vdb_transcript_write_scalar(vdb_transcript *tr, const vdb_fr *s);
+int vdb_transcript_write_point(vdb_transcript *tr, const vdb_g1 *p);
+int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
+int vdb_transcript_proof_len(const vdb_transcript *tr, size_t *len);
+int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t cap);
+
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,
  *      R_P=57 as examples/merkle.rs:15-18; call sites src/gadget/vectordb.rs:180-182, 213-215) --- */
 int vdb_poseidon_hash_many(const vdb_fr *inputs, size_t n_msgs, size_t msg_len, vdb_fr *digests);

@@ -1,0 +1,88 @@
+"""Fiat–Shamir transcript (host code of the product library, no GPU involved) against the independent
+Python restatement of the Poseidon sponge in oracle/pyref.py.  Parity unpinned beyond that: width, round numbers and
+encodings are [UPSTREAM-RECALL] (the reference holds no transcript or proof bytes)."""
+import numpy as np
+import pytest
+
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    return a
+
+
+def _sponge(P, R, t, msgs_and_squeezes):
+    """the documented rule on python ints: buffered absorb, RATE per permutation, +1 after a short chunk, an extra
+    permutation when the buffer length is a multiple of RATE; state persists over squeezes"""
+    rate = t - 1
+    st = [1 << 64] + [0] * rate
+    outs = []
+    for msg in msgs_and_squeezes:
+        chunks = [msg[i:i + rate] for i in range(0, len(msg), rate)]
+        if len(msg) % rate == 0:
+            chunks.append([])
+        for ch in chunks:
+            for i, v in enumerate(ch):
+                st[1 + i] = (st[1 + i] + v) % R
+            if len(ch) < rate:
+                st[1 + len(ch)] = (st[1 + len(ch)] + 1) % R
+            st = P.permute(st)
+        outs.append(st[1])
+    return outs
+
+
+@pytest.mark.parametrize("t,r_f,r_p", [(5, 8, 60), (3, 8, 57), (4, 8, 56)])
+def test_sponge_matches_python_restatement(api, O, PY, t, r_f, r_p):
+    rng = np.random.default_rng(t)
+    P = PY.Poseidon(t, r_f, r_p)
+    batches = [[int(v) for v in rng.integers(1, 1 << 62, size=m)] for m in (0, 1, t - 1, t, 2 * (t - 1), 7, 0)]
+    tr = api.Transcript(t, r_f, r_p)
+    got = []
+    for msg in batches:
+        for v in msg:
+            tr.common_scalar(O.fr_from_ints([v])[0])
+        got.append(O.fr_to_ints(tr.squeeze().reshape(1, 4))[0])
+    tr.free()
+    assert got == _sponge(P, O.R_MOD, t, batches)
+
+
+def test_width_three_sponge_is_the_chip_hash(api, O, PY):
+    """one squeeze of a fresh width-3 transcript == PoseidonChip's hash of the same message (oracle C restatement, which
+    runs the optimised schedule): the plain and the optimised permutations agree"""
+    rng = np.random.default_rng(8)
+    for m in (1, 2, 5, 8):
+        msg = O.random_fr(rng, m)
+        tr = api.Transcript(3, 8, 57)
+        for v in msg:
+            tr.common_scalar(v)
+        got = tr.squeeze()
+        tr.free()
+        assert np.array_equal(got, O.poseidon_hash_many(msg.reshape(1, m, 4))[0])
+
+
+def test_points_and_proof_bytes(api, O, PY):
+    pts = O.g1_mul_generator([5, 123456789, 0])
+    tr = api.Transcript()
+    for p in pts:
+        tr.write_point(p)
+    s = O.fr_from_ints([0xDEADBEEF12345])[0]
+    tr.write_scalar(s)
+    ch = O.fr_to_ints(tr.squeeze().reshape(1, 4))[0]
+    proof = tr.proof()
+    tr.free()
+    assert len(proof) == 4 * 32
+    absorbed = []
+    for i, p in enumerate(pts):
+        x, y = O.fq_to_ints(p.reshape(2, 4))
+        absorbed += [x % O.R_MOD, y % O.R_MOD]
+        enc = int.from_bytes(proof[32 * i: 32 * i + 32], "little")
+        assert enc & ((1 << 254) - 1) == x and (enc >> 254) == ((y & 1) if (x or y) else 0)
+        if x or y:
+            assert (y * y - x * x * x - 3) % Q_MOD == 0
+    assert int.from_bytes(proof[96:], "little") == 0xDEADBEEF12345
+    absorbed.append(0xDEADBEEF12345)
+    assert ch == _sponge(PY.Poseidon(5, 8, 60), O.R_MOD, 5, [absorbed])[0]
+    # bit 6 of the last byte is bit 254 of the little-endian integer
+    assert all((proof[32 * i + 31] >> 7) == 0 for i in range(4))

@@ -135,14 +135,35 @@ class ProverRounds:
         return self
 
     # ------------------------------------------------------------------ the rounds
-    def prove(self, challenges, seed=1, timings=None):
-        """challenges: dict of Montgomery field elements beta, gamma, y, x, v (what the transcript would squeeze).
-        Returns dict(commitments, evals, openings): commitments[name] (n, 8); evals[(name, rotation)] list of ints;
-        openings: list of dict(rotation, point, polys=[names in combination order], eval, W)."""
+    def prove(self, challenges=None, seed=1, timings=None):
+        """challenges: dict of Montgomery field elements beta, gamma, y, x, v, or None to derive them with the Fiat–Shamir
+        transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the fixed commitments
+        (in place of the verifying key's digest); advice commitments -> theta (squeezed as halo2 does, unused: the lookups
+        are single-column); permuted input / table commitments -> beta, gamma; product commitments -> y; the quotient's
+        pieces -> x; all evaluations, rotation by rotation -> v; the opening quotients.
+        Returns dict(commitments, evals, openings, points, proof): commitments[name] (n, 8); evals[(name, rotation)] list
+        of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W)."""
         hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
         rng = np.random.default_rng(seed)
-        ch = {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
+        tr = api.Transcript() if challenges is None else None
+        ch = {} if challenges is None else {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
         p = {name: api._p(v) for name, v in ch.items()}
+
+        def squeeze(*names):
+            if tr is not None:
+                for name in names:
+                    ch[name] = tr.squeeze()
+                    p[name] = api._p(ch[name])
+
+        def write_points(points):
+            if tr is not None:
+                for pt in points:
+                    tr.write_point(pt)
+
+        if tr is not None:
+            for name in ("sel", "sigma", "table", "lag"):
+                for pt in self.fixed[name].commits:
+                    tr.common_point(pt)
         usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
         fx = self.fixed
         T = {} if timings is None else timings
@@ -155,6 +176,8 @@ class ProverRounds:
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
         adv_commits = hp.step(T).copy()
+        write_points(adv_commits)
+        squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
         d_lag = api.DeviceBuffer(n_cols * rows * B)
         stage("relayout", lambda: hp._layout(dest=d_lag))
@@ -171,6 +194,9 @@ class ProverRounds:
         self._blind(d_ps, n_lk, usable, rng)
         polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1)))
         polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1)))
+        for a, b in zip(polys["pa"].commits, polys["ps"].commits):
+            write_points([a, b])
+        squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
         d_zp, d_zl = api.DeviceBuffer(n_sets * rows * B), api.DeviceBuffer(max(n_lk, 1) * rows * B)
@@ -186,6 +212,9 @@ class ProverRounds:
         polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
         polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit(d_zl, n_lk, 1)))
         d_lag.free()
+        write_points(polys["zp"].commits)
+        write_points(polys["zl"].commits)
+        squeeze("y")
 
         # round 4 (y): the quotient
         def derived_forms():
@@ -213,6 +242,8 @@ class ProverRounds:
         for q in ("pa", "ps", "zp", "zl"):
             polys[q].ext.free()
             polys[q].ext = None
+        write_points(polys["h"].commits)
+        squeeze("x")
 
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
@@ -234,6 +265,12 @@ class ProverRounds:
                     check(lib.vdb_eval_polys_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(ptm), api._p(out)))
                     evals[(name, rot)] = out
         stage("evaluations", evaluate)
+        if tr is not None:
+            for rot, names in opened.items():
+                for name in names:
+                    for e in evals[(name, rot)]:
+                        tr.write_scalar(e)
+        squeeze("v")
 
         # round 6 (v): one opening per rotation point: combine with powers of v, divide by (X - point), commit
         openings = []
@@ -252,12 +289,18 @@ class ProverRounds:
                 openings.append(dict(rotation=rot, point=points[rot], polys=list(names), eval=rem[0].copy(), W=W))
         stage("openings", open_all)
         d_comb.free(), d_quot.free()
+        write_points([op["W"] for op in openings])
+        proof = None
+        if tr is not None:
+            proof = tr.proof()
+            tr.free()
         api.sync()
         commitments = {name: q.commits for name, q in allp.items()}
         for q in ("pa", "ps", "zp", "zl"):
             polys[q].coeff.free()
         d_h.free()
-        return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points)
+        return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points,
+                    proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened)
 
     def free(self):
         for q in self.fixed.values():

@@ -1,57 +1,54 @@
 """The prover rounds after the advice commitments (halo2_vectordb_amd/rounds.py), end to end on a small k-means circuit:
-everything a verifier would check, checked — the quotient identity at the evaluation point recombined from the returned
-evaluations, and every opening against its commitments in the exponent (the test knows tau).  Parity unpinned: the
-reference holds no vectors for the prover rounds; these are the PLONK / KZG identities themselves."""
+everything a verifier would check, checked — the quotient identity at the evaluation point recombined from the
+evaluations, and every opening against its commitments in the exponent (the test knows tau) — once with the challenges
+handed in, once from nothing but the proof bytes and the fixed commitments, replaying the Fiat–Shamir transcript.
+Parity unpinned: the reference holds no vectors for the prover rounds; these are the PLONK / KZG
+identities themselves."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
 @pytest.fixture(scope="module")
-def proved(O):
+def circuit():
     from halo2_vectordb_amd import api
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds
     api.init(0)
     hp = KmeansHotPath(n=8, dim=4, K=2, I=1, k=11, L=10, tau=TAU).setup()
     pr = ProverRounds(hp).keygen()
-    rng = np.random.default_rng(99)
-    ch = {name: O.random_fr(rng, 1)[0] for name in ("beta", "gamma", "y", "x", "v")}
-    timings = {}
-    out = pr.prove(ch, seed=5, timings=timings)
-    yield hp, pr, ch, out, timings
+    yield hp, pr
     pr.free()
     hp.free()
 
 
-def test_round_outputs_have_the_expected_shape(proved):
-    hp, pr, ch, out, timings = proved
-    assert pr.n_adv >= 2 and pr.n_lk >= 1
-    c = out["commitments"]
-    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (4, 8) and c["pa"].shape == (pr.n_lk, 8)
-    assert len(out["openings"]) == 6
-    for name in ("witness", "commit_msm", "ntt", "lookup_permute", "products", "quotient", "evaluations", "openings"):
-        assert timings[name] > 0
+@pytest.fixture(scope="module")
+def proved(circuit, O):
+    hp, pr = circuit
+    rng = np.random.default_rng(99)
+    ch = {name: O.random_fr(rng, 1)[0] for name in ("beta", "gamma", "y", "x", "v")}
+    timings = {}
+    out = pr.prove(ch, seed=5, timings=timings)
+    return ch, out, timings
 
 
-def test_quotient_identity_from_the_returned_evaluations(proved, O):
-    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND
-    hp, pr, ch, out, _ = proved
+def check_quotient_identity(O, meta, ch, evals):
+    """gates + permutation + lookup expressions from the evaluations == h(x) (x^n - 1)"""
     R = O.R_MOD
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     b, g, yv, x = (to_int(ch[n]) for n in ("beta", "gamma", "y", "x"))
-    delta = to_int(pr.delta)
-    ev = lambda name, rot=0: out["evals"][(name, rot)]
-    n, n_adv = pr.rows, pr.n_adv
+    delta, n, n_adv, chunk, n_blind = meta["delta"], meta["rows"], meta["n_adv"], meta["chunk_len"], meta["n_blind"]
+    ev = lambda name, rot=0: evals[(name, rot)]
     acc = 0
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
     l0, ll, la = ev("lag")
-    sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
+    sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
     n_cols, n_sets = len(a0), len(z0)
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
@@ -60,7 +57,7 @@ def test_quotient_identity_from_the_returned_evaluations(proved, O):
     cur = b * x % R
     for i in range(n_sets):
         left, right = z1[i], z0[i]
-        for c in range(i * CHUNK_LEN, min((i + 1) * CHUNK_LEN, n_cols)):
+        for c in range(i * chunk, min((i + 1) * chunk, n_cols)):
             left = left * (a0[c] + b * sg[c] + g) % R
             right = right * (a0[c] + cur + g) % R
             cur = cur * delta % R
@@ -74,34 +71,152 @@ def test_quotient_identity_from_the_returned_evaluations(proved, O):
         acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
     xn = pow(x, n, R)
     hx = sum(h_i * pow(xn, i, R) for i, h_i in enumerate(ev("h"))) % R
-    assert acc == hx * (xn - 1) % R and acc != 0
+    return acc == hx * (xn - 1) % R and acc != 0
 
 
-def test_every_opening_verifies_in_the_exponent(proved, O):
-    """sum_i v^(m-1-i) C_i - [eval] G == [tau - point] W for each rotation point, with eval also equal to the same
-    combination of the individual evaluations"""
-    hp, pr, ch, out, _ = proved
+def check_openings(O, v_int, commitments, evals, openings):
+    """sum_i v^(m-1-i) C_i - [eval] G == [tau - point] W for each rotation point"""
     R = O.R_MOD
-    v = O.fr_to_ints(ch["v"].reshape(1, 4))[0]
     G = O.g1_generator().reshape(1, 8)
-    for op in out["openings"]:
-        commits = np.concatenate([out["commitments"][name] for name in op["polys"]])
-        evs = [e for name in op["polys"] for e in out["evals"][(name, op["rotation"])]]
+    for op in openings:
+        commits = np.concatenate([commitments[name] for name in op["polys"]])
+        evs = [e for name in op["polys"] for e in evals[(name, op["rotation"])]]
         m = len(evs)
-        assert commits.shape[0] == m
+        if commits.shape[0] != m:
+            return False
         comb = 0
         for e in evs:
-            comb = (comb * v + e) % R
-        assert comb == O.fr_to_ints(op["eval"].reshape(1, 4))[0]
-        scalars = [pow(v, m - 1 - i, R) for i in range(m)] + [(-comb) % R]
+            comb = (comb * v_int + e) % R
+        scalars = [pow(v_int, m - 1 - i, R) for i in range(m)] + [(-comb) % R]
         lhs = O.msm_naive(O.fr_from_ints(scalars), np.concatenate([commits, G]))
         rhs = O.msm_naive(O.fr_from_ints([(TAU - op["point"]) % R]), op["W"].reshape(1, 8))
-        assert np.array_equal(lhs, rhs) and lhs.any()
+        if not (np.array_equal(lhs, rhs) and lhs.any()):
+            return False
+    return True
 
 
-def test_advice_commitments_are_the_hot_path_commitments(proved, O):
-    hp, pr, ch, out, _ = proved
+def _meta(pr):
+    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND
+    import halo2_vectordb_amd.rounds as rounds
+    return dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=CHUNK_LEN, n_blind=N_BLIND,
+                delta=rounds._fr_to_int(pr.delta))
+
+
+def test_round_outputs_have_the_expected_shape(circuit, proved):
+    hp, pr = circuit
+    ch, out, timings = proved
+    assert pr.n_adv >= 2 and pr.n_lk >= 1
+    c = out["commitments"]
+    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (4, 8) and c["pa"].shape == (pr.n_lk, 8)
+    assert len(out["openings"]) == 6 and out["proof"] is None
+    for name in ("witness", "commit_msm", "ntt", "lookup_permute", "products", "quotient", "evaluations", "openings"):
+        assert timings[name] > 0
+
+
+def test_quotient_identity_from_the_returned_evaluations(circuit, proved, O):
+    ch, out, _ = proved
+    assert check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"])
+    wrong = dict(out["evals"])
+    wrong[("zl", 1)] = [(e + 1) % O.R_MOD for e in wrong[("zl", 1)]]
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
+
+
+def test_every_opening_verifies_in_the_exponent(circuit, proved, O):
+    ch, out, _ = proved
+    v = O.fr_to_ints(ch["v"].reshape(1, 4))[0]
+    for op in out["openings"]:     # the combined evaluation the division returned is the combination of the individual ones
+        comb = 0
+        for name in op["polys"]:
+            for e in out["evals"][(name, op["rotation"])]:
+                comb = (comb * v + e) % O.R_MOD
+        assert comb == O.fr_to_ints(op["eval"].reshape(1, 4))[0]
+    assert check_openings(O, v, out["commitments"], out["evals"], out["openings"])
+    bad = dict(out["evals"])
+    bad[("adv", 2)] = [(e + 1) % O.R_MOD for e in bad[("adv", 2)]]
+    assert not check_openings(O, v, out["commitments"], bad, out["openings"])
+
+
+def test_advice_commitments_are_the_hot_path_commitments(circuit, proved, O):
+    hp, pr = circuit
+    _, out, _ = proved
     hp.relayout()
     cols = hp.download_columns([0, pr.n_adv - 1, pr.n_adv])
     want = O.msm_batch(cols, hp.g_lagrange)
     assert np.array_equal(out["commitments"]["adv"][[0, pr.n_adv - 1, pr.n_adv]], want)
+
+
+def _decompress(O, enc_bytes):
+    enc = int.from_bytes(enc_bytes, "little")
+    if enc == 0:
+        return np.zeros(8, dtype=np.uint64)
+    x, odd = enc & ((1 << 254) - 1), (enc >> 254) & 1
+    y = pow((x * x * x + 3) % Q_MOD, (Q_MOD + 1) // 4, Q_MOD)
+    assert (y * y - x * x * x - 3) % Q_MOD == 0
+    if (y & 1) != odd:
+        y = Q_MOD - y
+    return O.fq_from_ints([x, y]).reshape(8)
+
+
+def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
+    """prove with the Fiat–Shamir transcript; then a verifier that sees only the proof bytes, the fixed commitments and the
+    circuit's shape: parse, replay the transcript for the challenges, check the quotient identity and every opening"""
+    from halo2_vectordb_amd import api
+    hp, pr = circuit
+    out = pr.prove(None, seed=11)
+    proof, meta, opened = out["proof"], _meta(pr), out["opened"]
+    fixed = {name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")}
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+              "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
+    n_evals = sum(counts[name] for names in opened.values() for name in names)
+    n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
+    assert len(proof) == 32 * (n_points + n_evals)
+
+    # ---- the verifier
+    pos = 0
+    def take_points(m):
+        nonlocal pos
+        pts = np.stack([_decompress(O, proof[pos + 32 * i: pos + 32 * i + 32]) for i in range(m)])
+        pos += 32 * m
+        return pts
+    tr = api.Transcript()
+    for name in ("sel", "sigma", "table", "lag"):
+        for pt in fixed[name]:
+            tr.common_point(pt)
+    commitments = dict(fixed)
+    def absorb(pts):
+        for pt in pts:
+            tr.common_point(pt)
+        return pts
+    commitments["adv"] = absorb(take_points(counts["adv"]))
+    ch = {"theta": tr.squeeze()}
+    pairs = absorb(take_points(2 * meta["n_lk"]))
+    commitments["pa"], commitments["ps"] = pairs[0::2], pairs[1::2]
+    ch["beta"], ch["gamma"] = tr.squeeze(), tr.squeeze()
+    commitments["zp"] = absorb(take_points(counts["zp"]))
+    commitments["zl"] = absorb(take_points(counts["zl"]))
+    ch["y"] = tr.squeeze()
+    commitments["h"] = absorb(take_points(4))
+    ch["x"] = tr.squeeze()
+    evals = {}
+    for rot, names in opened.items():
+        for name in names:
+            vals = []
+            for _ in range(counts[name]):
+                e = int.from_bytes(proof[pos: pos + 32], "little")
+                pos += 32
+                assert e < O.R_MOD
+                tr.common_scalar(O.fr_from_ints([e])[0])
+                vals.append(e)
+            evals[(name, rot)] = vals
+    ch["v"] = tr.squeeze()
+    Ws = take_points(len(opened))
+    assert pos == len(proof)
+    tr.free()
+    x = O.fr_to_ints(ch["x"].reshape(1, 4))[0]
+    w = O.fr_to_ints(O.root_of_unity(meta["k"]).reshape(1, 4))[0]
+    openings = [dict(rotation=rot, polys=names, point=x * pow(w, rot % meta["rows"], O.R_MOD) % O.R_MOD, W=Ws[i]) for i, (rot, names) in enumerate(opened.items())]
+    # the challenges the prover used are the ones the proof bytes determine
+    for name in ("beta", "gamma", "y", "x", "v"):
+        assert np.array_equal(ch[name], out["challenges"][name])
+    assert check_quotient_identity(O, meta, ch, evals)
+    assert check_openings(O, O.fr_to_ints(ch["v"].reshape(1, 4))[0], commitments, evals, openings)

@@ -81,9 +81,11 @@ _SIGNATURES = {
     "vdb_transcript_new": [_U32, _U32, _U32, _P], "vdb_transcript_free": [_P], "vdb_transcript_common_scalar": [_P, _P], "vdb_transcript_common_point": [_P, _P],
     "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
+    "vdb_scratch_release": [],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vdb_permutation_eval_range_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _SZ],
     "vdb_lookup_eval_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_product_dev": [_P, _P, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_colsrc_build_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _U32, _P],

@@ -231,6 +231,20 @@ int vdb_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   VDB_HIP(hipStreamSynchronize(ctx().stream));
   return VDB_OK;
 }
+int vdb_scratch_release(void) {
+  VDB_REQUIRE_INIT();
+  Context& c = ctx();
+  VDB_ARG(!c.msm_pending, "a deferred MSM is still open (vdb_msm_batch_end)");
+  VDB_HIP(hipStreamSynchronize(c.stream));
+  VDB_HIP(hipStreamSynchronize(c.aux));
+  for (int i = 0; i < 6; i++) {
+    if (c.scratch[i]) VDB_HIP(hipFree(c.scratch[i]));
+    c.scratch[i] = nullptr;
+    c.scratch_bytes[i] = 0;
+  }
+  return VDB_OK;
+}
+
 int vdb_memcpy_d2d(void* dst, const void* src, size_t bytes) {
   VDB_REQUIRE_INIT();
   VDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream));

@@ -403,8 +403,12 @@ struct QuotArgs {
   uint32_t log_ne, e;
   uint64_t last_rot;  // rows between the last usable row and the end: n - usable_rows
 };
+// Sets [set_lo, set_hi) of the product terms; the terms that involve only the product columns come with set_lo == 0.
+// `sigma` points at the first column of set_lo (the sigma cosets may be produced block by block); bx = beta X delta^(set_lo
+// chunk_len) on entry.
 __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv, const u256* __restrict__ sigma, const u256* __restrict__ z, uint64_t n_cols,
-                                                   uint32_t chunk_len, const u256* __restrict__ bx, QuotArgs q, u256* __restrict__ acc) {
+                                                   uint32_t chunk_len, uint64_t set_lo, uint64_t set_hi, const u256* __restrict__ bx, u256 dstart, QuotArgs q,
+                                                   u256* __restrict__ acc) {
   const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
   const uint64_t mask = ne - 1, r = 1ull << q.e;
@@ -412,24 +416,27 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
   const u256 one = mont_one<Fr>();
   const u256 l0 = ld256(q.l0 + j), ll = ld256(q.l_last + j), la = ld256(q.l_active + j);
   u256 h = ld256(acc + j);
-  // l0 (1 - z_0)
-  h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, ld256(z + j))));
-  // l_last (z_last^2 - z_last)
-  {
-    const u256 zl = ld256(z + (n_sets - 1) * ne + j);
-    h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zl, zl), zl)));
+  if (set_lo == 0) {
+    // l0 (1 - z_0)
+    h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, ld256(z + j))));
+    // l_last (z_last^2 - z_last)
+    {
+      const u256 zl = ld256(z + (n_sets - 1) * ne + j);
+      h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zl, zl), zl)));
+    }
+    // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
+    const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
+    for (uint64_t i = 1; i < n_sets; i++) h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(ld256(z + i * ne + j), ld256(z + (i - 1) * ne + jb))));
   }
-  // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
-  const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
-  for (uint64_t i = 1; i < n_sets; i++) h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(ld256(z + i * ne + j), ld256(z + (i - 1) * ne + jb))));
   // l_active (z_i(w X) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma))
-  u256 cur = ld256(bx + j);
-  for (uint64_t i = 0; i < n_sets; i++) {
+  u256 cur = fr_mul(ld256(bx + j), dstart);
+  const uint64_t cb = set_lo * chunk_len;  // first column of the sigma block
+  for (uint64_t i = set_lo; i < set_hi; i++) {
     const uint64_t c0 = i * chunk_len, c1 = c0 + chunk_len < n_cols ? c0 + chunk_len : n_cols;
     u256 left = ld256(z + i * ne + ((j + r) & mask)), right = ld256(z + i * ne + j);
     for (uint64_t c = c0; c < c1; c++) {
       const u256 v = fr_add(ld256(adv + c * ne + j), q.gamma);
-      left = fr_mul(left, fr_add(v, fr_mul(q.beta, ld256(sigma + c * ne + j))));
+      left = fr_mul(left, fr_add(v, fr_mul(q.beta, ld256(sigma + (c - cb) * ne + j))));
       right = fr_mul(right, fr_add(v, cur));
       cur = fr_mul(cur, q.delta);
     }
@@ -754,13 +761,16 @@ static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const 
   return VDB_OK;
 }
 
-int vdb_permutation_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k,
-                             uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev, const vdb_fr* l_active_ext_dev,
-                             const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev) {
+int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
+                                   uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                                   const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
+                                   size_t set_lo, size_t set_hi) {
   VDB_REQUIRE_INIT();
-  VDB_ARG(adv_ext_dev && sigma_ext_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta && gamma && delta && y && acc_dev, "null pointer");
+  VDB_ARG(adv_ext_dev && sigma_ext_block_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta && gamma && delta && y && acc_dev,
+          "null pointer");
   VDB_ARG(k + ext_k <= 28 && chunk_len >= 1 && usable_rows < (1ull << k), "bad argument");
   if (n_cols == 0) return VDB_OK;
+  VDB_ARG(set_lo <= set_hi && set_hi <= (n_cols + chunk_len - 1) / chunk_len, "bad set range");
   Context& cx = ctx();
   QuotArgs q;
   quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, delta, y, k, ext_k, usable_rows);
@@ -771,11 +781,22 @@ int vdb_permutation_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_
                      bx);
   {
     VDB_PROF("k_perm_eval");
-    hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_dev), as_u256(z_ext_dev),
-                       (uint64_t)n_cols, (uint32_t)chunk_len, bx, q, as_u256(acc_dev));
+    u256 e = u256_zero();
+    const uint64_t pw = (uint64_t)set_lo * chunk_len;
+    e.w[0] = (uint32_t)pw;
+    e.w[1] = (uint32_t)(pw >> 32);
+    hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_block_dev),
+                       as_u256(z_ext_dev), (uint64_t)n_cols, (uint32_t)chunk_len, (uint64_t)set_lo, (uint64_t)set_hi, bx, mont_pow<Fr>(q.delta, e), q,
+                       as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
+}
+int vdb_permutation_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k,
+                             uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev, const vdb_fr* l_active_ext_dev,
+                             const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev) {
+  return vdb_permutation_eval_range_dev(adv_ext_dev, sigma_ext_dev, z_ext_dev, n_cols, chunk_len, k, ext_k, usable_rows, l0_ext_dev, l_last_ext_dev, l_active_ext_dev,
+                                        beta, gamma, delta, y, acc_dev, 0, chunk_len ? (n_cols + chunk_len - 1) / chunk_len : 0);
 }
 
 int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev, const vdb_fr* perm_input_ext_dev, const vdb_fr* perm_table_ext_dev,

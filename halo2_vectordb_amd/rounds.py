@@ -20,6 +20,7 @@ from .pipeline import N_BLIND
 B = 32
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
+BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
@@ -38,6 +39,19 @@ def _fr_to_int(a):
     return v * pow(1 << 256, -1, R_MOD) % R_MOD
 
 
+class _View:
+    """a stretch of a pooled device allocation (same surface as api.DeviceBuffer; freeing it is a no-op)"""
+
+    def __init__(self, buf, offset, nbytes):
+        self.ptr, self.nbytes = ctypes.c_void_p(buf.ptr.value + int(offset)), int(nbytes)
+
+    def at(self, offset):
+        return ctypes.c_void_p(self.ptr.value + int(offset))
+
+    def free(self):
+        pass
+
+
 class _Poly:
     """a set of polynomials in the three forms the rounds use; any of them may be absent"""
 
@@ -51,8 +65,10 @@ class _Poly:
 
 
 class ProverRounds:
-    def __init__(self, hp):
+    def __init__(self, hp, block_cols=BLOCK_COLS):
         assert hp.world == 1, "the prover rounds run on one rank's full column set"
+        assert block_cols % CHUNK_LEN == 0
+        self.block_cols = block_cols
         self.hp, self.lib = hp, hp.lib
         self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
         self.usable = hp.rows - N_BLIND
@@ -90,9 +106,15 @@ class ProverRounds:
         api.sync()
         d.free()
 
-    def _fixed_poly(self, name, lag_buf, n_cols):
+    def _fixed_poly(self, name, lag_buf, n_cols, keep_lag=True, keep_ext=True):
+        """commitment and coefficient form of a fixed polynomial; its extended coset only when it is small (the selector and
+        sigma cosets — 4x the columns — are produced block by block inside the quotient instead of being held)"""
         coeff = self._to_coeff(lag_buf, n_cols)
-        p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols), commits=self._commit(lag_buf, n_cols, 1))
+        p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=self._commit(lag_buf, n_cols, 1))
+        if not keep_lag:
+            api.sync()
+            lag_buf.free()
+            p.lag = None
         self.fixed[name] = p
         return p
 
@@ -107,7 +129,7 @@ class ProverRounds:
         d_q = api.DeviceBuffer(self.n_adv * rows * B)
         check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
         d_flags.free()
-        self._fixed_poly("sel", d_q, self.n_adv)
+        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
         mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
         for c in range(self.n_adv - 1):
@@ -118,7 +140,7 @@ class ProverRounds:
         d_sigma = api.DeviceBuffer(self.n_cols * rows * B)
         check(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_cols), k, api._p(self.delta), d_sigma.ptr))
         d_map.free()
-        self._fixed_poly("sigma", d_sigma, self.n_cols)
+        self._fixed_poly("sigma", d_sigma, self.n_cols, keep_ext=False)
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
         tab[tab >= (1 << hp.L)] = 0
@@ -132,6 +154,17 @@ class ProverRounds:
         d_l.upload(lag)
         self._fixed_poly("lag", d_l, 3)
         api.sync()
+        # the working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
+        # [pa | ps | zp | zl] in Lagrange / coefficient form, their extended cosets, a block of fixed cosets, h.  The
+        # Lagrange image of the advice columns is dead before the derived cosets exist and shares their memory.  The
+        # library's MSM scratch is released first so that it is re-sized to what is left.
+        check(lib.vdb_scratch_release())
+        n_der = 3 * self.n_lk + self.n_sets
+        self.pool_der = api.DeviceBuffer(max(n_der, 1) * rows * B)
+        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, self.n_cols * rows) * B)
+        self.d_blk = api.DeviceBuffer(min(self.n_cols, max(self.block_cols, 510)) * self.ne * B)
+        self.d_h = api.DeviceBuffer(self.ne * B)
+        self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         return self
 
     # ------------------------------------------------------------------ the rounds
@@ -179,13 +212,18 @@ class ProverRounds:
         write_points(adv_commits)
         squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
-        d_lag = api.DeviceBuffer(n_cols * rows * B)
+        d_lag = _View(self.pool_ext, 0, n_cols * rows * B)
         stage("relayout", lambda: hp._layout(dest=d_lag))
         lk_lag = ctypes.c_void_p(d_lag.ptr.value + n_adv * rows * B)
         polys = {"adv": adv}
 
         # round 2: the lookup argument's permuted columns
-        d_pa, d_ps = api.DeviceBuffer(max(n_lk, 1) * rows * B), api.DeviceBuffer(max(n_lk, 1) * rows * B)
+        counts = {"pa": n_lk, "ps": n_lk, "zp": n_sets, "zl": n_lk}
+        der, ext_of, off = {}, {}, 0
+        for name, m in counts.items():
+            der[name], ext_of[name] = _View(self.pool_der, off * rows * B, m * rows * B), _View(self.pool_ext, off * ne * B, m * ne * B)
+            off += m
+        d_pa, d_ps, d_zp, d_zl = der["pa"], der["ps"], der["zp"], der["zl"]
 
         def permute():
             check(lib.vdb_lookup_permute_dev(lk_lag, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
@@ -199,8 +237,6 @@ class ProverRounds:
         squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
-        d_zp, d_zl = api.DeviceBuffer(n_sets * rows * B), api.DeviceBuffer(max(n_lk, 1) * rows * B)
-
         def products():
             check(lib.vdb_permutation_product_dev(d_lag.ptr, fx["sigma"].lag.ptr, _sz(n_cols), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
                                                   api._p(self.delta), d_zp.ptr))
@@ -211,7 +247,6 @@ class ProverRounds:
         self._blind(d_zl, n_lk, usable + 1, rng)
         polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
         polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit(d_zl, n_lk, 1)))
-        d_lag.free()
         write_points(polys["zp"].commits)
         write_points(polys["zl"].commits)
         squeeze("y")
@@ -222,16 +257,28 @@ class ProverRounds:
                 q = polys[name]
                 check(lib.vdb_lagrange_to_coeff_dev(q.lag.ptr, _sz(q.n_cols), k))      # in place: the Lagrange form is not needed again
                 q.coeff, q.lag = q.lag, None
-                q.ext = self._to_ext(q.coeff, q.n_cols)
+                q.ext = ext_of[name]
+                check(lib.vdb_coeff_to_extended_dev(q.coeff.ptr, q.ext.ptr, _sz(q.n_cols), k, EXT_K))
         stage("derived_ntt", derived_forms)
-        d_h = api.DeviceBuffer(ne * B)
+        d_h = self.d_h
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
+
+        blk = min(n_cols, self.block_cols)
+        d_blk = self.d_blk
 
         def quotient():
             check(lib.vdb_memset_dev(d_h.ptr, 0, _sz(ne * B)))
-            check(lib.vdb_gate_eval_dev(adv.ext.ptr, fx["sel"].ext.ptr, _sz(n_adv), k, EXT_K, p["y"], d_h.ptr))
-            check(lib.vdb_permutation_eval_dev(adv.ext.ptr, fx["sigma"].ext.ptr, polys["zp"].ext.ptr, _sz(n_cols), _sz(CHUNK_LEN), k, EXT_K, _sz(usable),
-                                               l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr))
+            # the selector and sigma cosets are produced from their coefficients a block of columns at a time
+            for c0 in range(0, n_adv, blk):
+                nb = min(blk, n_adv - c0)
+                check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
+                check(lib.vdb_gate_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
+            for c0 in range(0, n_cols, blk):
+                nb = min(blk, n_cols - c0)
+                check(lib.vdb_coeff_to_extended_dev(fx["sigma"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
+                check(lib.vdb_permutation_eval_range_dev(adv.ext.ptr, d_blk.ptr, polys["zp"].ext.ptr, _sz(n_cols), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la,
+                                                         p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr, _sz(c0 // CHUNK_LEN),
+                                                         _sz(-(-(c0 + nb) // CHUNK_LEN))))
             check(lib.vdb_lookup_eval_dev(ctypes.c_void_p(adv.ext.ptr.value + n_adv * ne * B), fx["table"].ext.ptr, polys["pa"].ext.ptr, polys["ps"].ext.ptr,
                                           polys["zl"].ext.ptr, _sz(n_lk), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], d_h.ptr))
             check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
@@ -239,9 +286,6 @@ class ProverRounds:
         stage("quotient", quotient)
         n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)))
-        for q in ("pa", "ps", "zp", "zl"):
-            polys[q].ext.free()
-            polys[q].ext = None
         write_points(polys["h"].commits)
         squeeze("x")
 
@@ -274,7 +318,7 @@ class ProverRounds:
 
         # round 6 (v): one opening per rotation point: combine with powers of v, divide by (X - point), commit
         openings = []
-        d_comb, d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
+        d_comb, d_quot = self.d_comb, self.d_quot
 
         def open_all():
             for rot, names in opened.items():
@@ -288,7 +332,6 @@ class ProverRounds:
                 W = self._commit(d_quot, 1, 0)[0]
                 openings.append(dict(rotation=rot, point=points[rot], polys=list(names), eval=rem[0].copy(), W=W))
         stage("openings", open_all)
-        d_comb.free(), d_quot.free()
         write_points([op["W"] for op in openings])
         proof = None
         if tr is not None:
@@ -296,9 +339,6 @@ class ProverRounds:
             tr.free()
         api.sync()
         commitments = {name: q.commits for name, q in allp.items()}
-        for q in ("pa", "ps", "zp", "zl"):
-            polys[q].coeff.free()
-        d_h.free()
         return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points,
                     proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened)
 
@@ -306,6 +346,11 @@ class ProverRounds:
         for q in self.fixed.values():
             q.free()
         self.fixed = {}
+        for name in ("pool_der", "pool_ext", "d_blk", "d_h", "d_comb", "d_quot"):
+            b = getattr(self, name, None)
+            if b is not None:
+                b.free()
+                setattr(self, name, None)
         if getattr(self, "srs_m", None) is not None:
             self.srs_m.free()
             self.srs_m = None

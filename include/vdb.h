@@ -59,6 +59,9 @@ int vdb_malloc(void **dptr, size_t bytes);
 int vdb_free(void *dptr);
 int vdb_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* Frees the library's cached work buffers (MSM buckets and sort records — up to half of the free HBM —, NTT staging); they
+ * are re-created on demand.  For callers that need the memory between two phases.  Waits for queued work. */
+int vdb_scratch_release(void);
 int vdb_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous on the library stream */
 int vdb_memset_dev(void *dst_dev, int value, size_t bytes);
 int vdb_sync(void);
@@ -268,6 +271,13 @@ int vdb_permutation_product_dev(const vdb_fr *cols_dev, const vdb_fr *sigma_dev,
 int vdb_permutation_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigma_ext_dev, const vdb_fr *z_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k,
                              uint32_t ext_k, size_t usable_rows, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev, const vdb_fr *l_active_ext_dev,
                              const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev);
+/* the same for the sets [set_lo, set_hi) only (the terms that involve nothing but the product columns come with set_lo == 0):
+ * sigma_ext_block_dev holds the cosets of columns set_lo * chunk_len onwards, so that the sigma cosets can be produced block
+ * by block from their coefficients instead of being kept resident; calls must be made in ascending order of the sets. */
+int vdb_permutation_eval_range_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigma_ext_block_dev, const vdb_fr *z_ext_dev, size_t n_cols, size_t chunk_len,
+                                   uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
+                                   const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev,
+                                   size_t set_lo, size_t set_hi);
 int vdb_lookup_eval_dev(const vdb_fr *input_ext_dev, const vdb_fr *table_ext_dev, const vdb_fr *perm_input_ext_dev, const vdb_fr *perm_table_ext_dev,
                         const vdb_fr *z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
                         const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);

@@ -162,7 +162,10 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     circuit's shape: parse, replay the transcript for the challenges, check the quotient identity and every opening"""
     from halo2_vectordb_amd import api
     hp, pr = circuit
+    assert pr.n_cols > 2 * 30
+    pr.block_cols = 30            # the selector / sigma cosets in several blocks (sets 0-9, 10-19, ...)
     out = pr.prove(None, seed=11)
+    pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")}
     counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage times of the prover rounds (halo2_vectordb_amd/rounds.py) on a k-means circuit at 2^16 rows.
-usage: rounds_bench.py [I]   — I k-means iterations of the BASELINE C4 shape (K=4, 256 x 128); the full I = 8 needs more
-HBM than one card has once every fixed polynomial is also held on the extended coset, so the default is I = 2."""
+usage: rounds_bench.py [I]   — I k-means iterations of the BASELINE C4 shape (K=4, 256 x 128)
+(I = 8 is the BASELINE C4 circuit; the default I = 2 runs in a fraction of the memory and time)."""
 import json
 import os
 import sys

@@ -524,3 +524,37 @@ def test_kzg_opening_verifies_in_the_exponent(api, O):
     lhs = O.msm_naive(O.fr_from_ints(powers), np.concatenate([commits, O.g1_generator().reshape(1, 8)]))
     rhs = O.msm_naive(O.fr_from_ints([(tau - xi) % R]), W.reshape(1, 8))
     assert np.array_equal(lhs, rhs) and lhs.any()
+
+
+def test_prover_round_entry_points_reject_bad_arguments_and_accept_empty_batches(api, O):
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    rng = np.random.default_rng(3)
+    one_fr = O.fr_from_ints([1])[0]
+    buf = api.DeviceBuffer(64 * 32)
+    buf.upload(O.random_fr(rng, 64))
+    sz = ctypes.c_size_t
+    # empty batches are no-ops
+    check(lib.vdb_permutation_product_dev(buf.ptr, buf.ptr, sz(0), 4, sz(10), sz(3), api._p(one_fr), api._p(one_fr), api._p(one_fr), buf.ptr))
+    check(lib.vdb_lookup_product_dev(buf.ptr, buf.ptr, buf.ptr, buf.ptr, sz(0), sz(16), sz(10), api._p(one_fr), api._p(one_fr), buf.ptr))
+    check(lib.vdb_kate_div_dev(buf.ptr, sz(0), sz(16), api._p(one_fr), buf.ptr, None))
+    check(lib.vdb_poly_lincomb_dev(buf.ptr, sz(0), sz(16), api._p(one_fr), buf.ptr))
+    check(lib.vdb_fill_rows_dev(buf.ptr, sz(2), sz(16), sz(16), buf.ptr))
+    # bad arguments come back as VDB_ERR_ARG, never as a fault
+    for call in (lambda: lib.vdb_permutation_product_dev(buf.ptr, buf.ptr, sz(2), 4, sz(16), sz(3), api._p(one_fr), api._p(one_fr), api._p(one_fr), buf.ptr),   # usable_rows == n
+                 lambda: lib.vdb_permutation_product_dev(buf.ptr, buf.ptr, sz(2), 4, sz(10), sz(0), api._p(one_fr), api._p(one_fr), api._p(one_fr), buf.ptr),   # chunk_len 0
+                 lambda: lib.vdb_lookup_product_dev(buf.ptr, buf.ptr, buf.ptr, buf.ptr, sz(1), sz(16), sz(16), api._p(one_fr), api._p(one_fr), buf.ptr),
+                 lambda: lib.vdb_kate_div_dev(None, sz(1), sz(16), api._p(one_fr), buf.ptr, None),
+                 lambda: lib.vdb_fill_rows_dev(buf.ptr, sz(1), sz(16), sz(17), buf.ptr),
+                 lambda: lib.vdb_permutation_eval_range_dev(buf.ptr, buf.ptr, buf.ptr, sz(6), sz(3), 2, 2, sz(2), buf.ptr, buf.ptr, buf.ptr, api._p(one_fr), api._p(one_fr),
+                                                            api._p(one_fr), api._p(one_fr), buf.ptr, sz(1), sz(3))):   # set range beyond the 2 sets
+        assert call() == -3           # VDB_ERR_ARG
+    # usable_rows = 0: the products are the constant one at row 0 and zero elsewhere
+    cols = O.random_fr(rng, 2 * 16).reshape(2, 16, 4)
+    z = api.permutation_product(cols, cols, 0, 3, one_fr, one_fr)
+    assert np.array_equal(z[0, 0], one_fr) and not z[:, 1:].any()
+    # a chunk longer than the column count is one set
+    z = api.permutation_product(cols, cols, 10, 5, one_fr, one_fr)
+    assert z.shape[0] == 1
+    buf.free()

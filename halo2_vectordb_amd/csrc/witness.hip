@@ -777,6 +777,9 @@ __global__ __launch_bounds__(64) void k_mk_leaf_trace(Streams stq, const FpTable
     uint32_t o = 2 * q;
     pos += perm_cells(o < D ? (int)(D - o < 2 ? D - o : 2) : 0);
   }
+  // a rank that holds a block of columns emits only the permutations whose cells fall into its stretch of the stream
+  // (the sponge states they start from were computed by k_mk_leaf_states)
+  if (!stq.touches(pos, pos + perm_cells(cnt), 0, 0)) return;
   WCtx c = make_ctx(stq, T, pos, 0);
   u256 st[PSD_T];
   for (int i = 0; i < PSD_T; i++) st[i] = states[((size_t)v * nperm + p) * PSD_T + i];
@@ -789,9 +792,16 @@ __global__ __launch_bounds__(64) void k_mk_node(Streams stq, const FpTables* __r
                                                 uint32_t n_out, uint64_t base, u256* __restrict__ out_lv) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= n_out) return;
-  WCtx c = make_ctx(stq, T, base + (uint64_t)t * (perm_cells(2) + perm_cells(0)), 0);
+  const uint64_t p0 = base + (uint64_t)t * (perm_cells(2) + perm_cells(0));
   u256 st[PSD_T] = {sp->cap, u256_zero(), u256_zero()};
   u256 in[PSD_RATE] = {in_lv[2 * t], in_lv[2 * t + 1]};
+  if (!stq.touches(p0, p0 + perm_cells(2) + perm_cells(0), 0, 0)) {  // outside the rank's window: the digest only
+    psd_permute_absorb(sp, st, in, 2);
+    psd_permute_absorb(sp, st, in, 0);
+    out_lv[t] = st[1];
+    return;
+  }
+  WCtx c = make_ctx(stq, T, p0, 0);
   trace_permutation(c, T, sp, st, in, 2);
   trace_permutation(c, T, sp, st, in, 0);
   out_lv[t] = st[1];

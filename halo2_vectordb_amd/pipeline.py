@@ -126,18 +126,14 @@ class KmeansHotPath:
         vec, self.seed = sift_like_vectors(self.seed, n, dim, K)
         self.vectors_f64 = vec
         self.qvec = api.quantize(vec, self.P)
-        cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
-        check(lib.vdb_wit_kmeans_size(self.metric, self.P, self.L, n, dim, K, I, 0, ctypes.byref(cells), ctypes.byref(lk)))
-        self.n_in = n * dim                       # ctx.assign_witnesses(quantize_vector(v)) for every vector
-        self.n_cells = self.n_in + cells.value
-        self.n_lookup = lk.value
+        self.n_in, n_gadget_cells, self.n_lookup = self._circuit_size()
+        self.n_cells = self.n_in + n_gadget_cells
         B = 32
         self.d_vec = api.DeviceBuffer(self.qvec.nbytes)
         self.d_vec.upload(self.qvec)
         self.d_stream = api.DeviceBuffer(self.n_cells * B)
         self.d_lookup = api.DeviceBuffer(max(self.n_lookup, 1) * B)
-        self.d_cent = api.DeviceBuffer(K * dim * B)
-        self.d_ind = api.DeviceBuffer(n * K * B)
+        self._alloc_outputs()
         # keygen-style run: record gate starts, derive break points (the reference pins them in configs/*.json)
         d_sel = api.DeviceBuffer(self.n_cells)
         check(lib.vdb_memset_dev(d_sel.ptr, 0, ctypes.c_size_t(self.n_cells)))
@@ -247,6 +243,17 @@ class KmeansHotPath:
         api.sync()
         return self
 
+    # ------------------------------------------------------------------ what is specific to the k-means circuit
+    def _circuit_size(self):
+        """(cells of ctx.assign_witnesses(quantize_vector(v)) for every vector, cells the gadget emits, lookup cells)"""
+        cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.lib.vdb_wit_kmeans_size(self.metric, self.P, self.L, self.n, self.dim, self.K, self.I, 0, ctypes.byref(cells), ctypes.byref(lk)))
+        return self.n * self.dim, cells.value, lk.value
+
+    def _alloc_outputs(self):
+        self.d_cent = api.DeviceBuffer(self.K * self.dim * 32)
+        self.d_ind = api.DeviceBuffer(self.n * self.K * 32)
+
     def write_pinning(self, path):
         """configs/{name}.json of the Keygen arm (src/scaffold/mod.rs:272)."""
         from .io import write_pinning
@@ -273,7 +280,8 @@ class KmeansHotPath:
     def _witness(self, sel=None):
         lib = self.lib
         # [assign_witnesses(vectors)] [kmeans cells]
-        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
+        if self.n_in:
+            check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
         windowed = sel is None and self.shard_witness and self.world > 1
         if windowed:
             # window in the coordinates of the pointers handed to the call (the kmeans cells start n_in cells into the stream)
@@ -367,3 +375,42 @@ class KmeansHotPath:
                 b.free()
         if getattr(self, "srs", None) is not None:
             self.srs.free()
+
+
+class MerkleHotPath(KmeansHotPath):
+    """merkle_commitment over N x D vectors (src/gadget/vectordb.rs:165-223; examples/merkle.rs) through the same hot
+    path: Poseidon trace on the GPU -> commit -> NTT.  No lookup cells; every column is dense (Poseidon states), so equal
+    column counts per rank are balanced already; a rank that holds a block of columns traces only the permutations whose
+    cells fall into it (the sponge states and the tree's digests are computed by every rank, value only)."""
+
+    def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1)):
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard)
+        self.balance_shards = False
+
+    def _circuit_size(self):
+        cells = ctypes.c_uint64()
+        check(self.lib.vdb_wit_merkle_size(self.n, self.dim, 0, ctypes.byref(cells)))
+        return 0, cells.value, 0
+
+    def _alloc_outputs(self):
+        self.d_root = api.DeviceBuffer(32)
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        windowed = sel is None and self.shard_witness and self.world > 1
+        if windowed:   # only the permutations whose cells fall into this rank's columns are traced; the digests are computed everywhere
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(self.win_adv[0]), ctypes.c_uint64(self.win_adv[1]), ctypes.c_uint64(0), ctypes.c_uint64(0)))
+        try:
+            check(lib.vdb_wit_merkle_dev(self.d_vec.ptr, self.n, self.dim, 0, self.d_stream.ptr, sel.ptr if sel is not None else None, self.d_root.ptr))
+        finally:
+            if windowed:
+                check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
+
+    def results(self):
+        return self.d_root.download((4,))
+
+    def free(self):
+        super().free()
+        if getattr(self, "d_root", None) is not None:
+            self.d_root.free()
+            self.d_root = None

@@ -133,13 +133,15 @@ def coeff_to_extended(cols, ext_k=2):
 class Srs:
     """Device-resident KZG bases + fixed-base window tables (vdb_srs_load)."""
 
-    def __init__(self, k, g=None, g_lagrange=None):
+    def __init__(self, k, g=None, g_lagrange=None, window_bits=0):
+        """window_bits: Pippenger window (0 = default, tuned for witness columns; 14 suits columns of full-width scalars)"""
         self.L = _lib.init()
         self.k = k
         h = ctypes.c_void_p()
         ga = np.ascontiguousarray(g, dtype=np.uint64) if g is not None else None
         gl = np.ascontiguousarray(g_lagrange, dtype=np.uint64) if g_lagrange is not None else None
-        check(self.L.vdb_srs_load(ctypes.c_uint32(k), _p(ga) if ga is not None else None, _p(gl) if gl is not None else None, ctypes.byref(h)))
+        check(self.L.vdb_srs_load_window(ctypes.c_uint32(k), _p(ga) if ga is not None else None, _p(gl) if gl is not None else None,
+                                         ctypes.c_uint32(window_bits), ctypes.byref(h)))
         self.h = h
 
     def info(self):

@@ -677,7 +677,7 @@ static uint32_t pick_window(uint32_t k) {
   const char* env = getenv("VDB_MSM_C");
   if (env) {
     int v = atoi(env);
-    if (v >= 2 && v <= 16) return (uint32_t)v;
+    if (v >= 2 && v <= 14) return (uint32_t)v;
   }
   // measured on the C4 witness columns (profiles/): per-task overhead of the many light buckets outweighs the
   // extra digits of a smaller window; c = 11 is the optimum for k = 16
@@ -850,14 +850,17 @@ int vdb_srs_setup_unsafe(uint32_t k, const vdb_fr* tau, vdb_g1* g_out, vdb_g1* g
   return VDB_OK;
 }
 
-int vdb_srs_load(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, vdb_srs** out) {
+int vdb_srs_load(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, vdb_srs** out) { return vdb_srs_load_window(k, g, g_lagrange, 0, out); }
+int vdb_srs_load_window(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, uint32_t window_bits, vdb_srs** out) {
   VDB_REQUIRE_INIT();
   VDB_ARG(out && (g || g_lagrange) && k >= 1 && k <= 24, "bad argument");
+  // the counting sort keeps three counters per bucket in LDS: 2^(c-1) buckets must fit 160 KB
+  VDB_ARG(window_bits == 0 || (window_bits >= 2 && window_bits <= 14), "window_bits must be 0 (default) or 2..14");
   Context& cx = ctx();
   vdb_srs* s = new vdb_srs();
   s->k = k;
   s->n = (size_t)1 << k;
-  s->c = pick_window(k);
+  s->c = window_bits ? window_bits : pick_window(k);
   s->W = (254 + s->c - 1) / s->c;
   s->B = 1u << (s->c - 1);
   s->table[0] = s->table[1] = nullptr;

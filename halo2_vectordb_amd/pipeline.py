@@ -116,6 +116,7 @@ class KmeansHotPath:
         self.shard_witness = True   # generate only the witness cells this rank's columns hold (values are computed everywhere)
         self.balance_shards = True  # equalise estimated time per rank instead of column count
         self.virtual_layout = True  # commit and transform straight from the witness stream (no stream -> column copy)
+        self.msm_window_bits = 0    # 0 = the library's default (11 bits for k > 8: most witness scalars are short)
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self, pinning=None):
@@ -163,7 +164,7 @@ class KmeansHotPath:
         g, gl = api.srs_setup_unsafe(self.k, tau)
         self.g_lagrange = gl
         self.g_monomial = g
-        self.srs = api.Srs(self.k, None, gl)
+        self.srs = api.Srs(self.k, None, gl, window_bits=self.msm_window_bits)
         # column sharding over ranks: a block of the advice columns and a block of the lookup columns each
         self.shards = column_shards(self.n_adv_cols, self.n_lk_cols, self.world)
         if self.world > 1 and self.balance_shards:
@@ -386,6 +387,7 @@ class MerkleHotPath(KmeansHotPath):
     def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1)):
         super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard)
         self.balance_shards = False
+        self.msm_window_bits = 14   # every scalar is a full-width Poseidon state: 19 windows instead of 24
 
     def _circuit_size(self):
         cells = ctypes.c_uint64()

@@ -90,9 +90,9 @@ class ProverRounds:
         check(self.lib.vdb_coeff_to_extended_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, EXT_K))
         return e
 
-    def _commit(self, buf, n_cols, basis):
+    def _commit(self, buf, n_cols, basis, dense=True):
         out = np.zeros((n_cols, 8), dtype=np.uint64)
-        srs = self.hp.srs if basis == 1 else self.srs_m
+        srs = self.hp.srs if basis == 1 and not dense else (self.srs_few if basis == 0 and n_cols <= 8 else self.srs_m)
         check(self.lib.vdb_msm_batch_dev(srs.h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
         return out
 
@@ -121,7 +121,9 @@ class ProverRounds:
     # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
     def keygen(self):
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
-        self.srs_m = api.Srs(k, hp.g_monomial, None)
+        # the derived columns (products, quotient, opening quotients) and the fixed sigma columns hold full-width scalars
+        self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
+        self.srs_few = api.Srs(k, hp.g_monomial, None)     # a handful of columns: the bucket folding dominates, fewer buckets win
         # gate selectors from a flag-recording witness run
         d_flags = api.DeviceBuffer(hp.n_cells)
         check(lib.vdb_memset_dev(d_flags.ptr, 0, _sz(hp.n_cells)))
@@ -230,8 +232,8 @@ class ProverRounds:
         stage("lookup_permute", permute)
         self._blind(d_pa, n_lk, usable, rng)
         self._blind(d_ps, n_lk, usable, rng)
-        polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1)))
-        polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1)))
+        polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1, dense=False)))
+        polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1, dense=False)))
         for a, b in zip(polys["pa"].commits, polys["ps"].commits):
             write_points([a, b])
         squeeze("beta", "gamma")
@@ -351,6 +353,7 @@ class ProverRounds:
             if b is not None:
                 b.free()
                 setattr(self, name, None)
-        if getattr(self, "srs_m", None) is not None:
-            self.srs_m.free()
-            self.srs_m = None
+        for name in ("srs_m", "srs_few"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).free()
+                setattr(self, name, None)

@@ -175,6 +175,10 @@ int vdb_mask_select_dev(const vdb_fr *in_dev, const uint8_t *mask_dev, uint64_t 
 /* Uploads the bases (caller keeps ownership of the host arrays; either may be NULL) and precomputes
  * the fixed-base window tables 2^(c*j) * G_i in HBM. */
 int vdb_srs_load(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, vdb_srs **out);
+/* the same with an explicit Pippenger window (2..14 bits; 0 = the default, 11 bits for k > 8, tuned for witness columns whose
+ * scalars are mostly short).  Columns of full-width scalars (Poseidon traces, the product columns of the permutation and
+ * lookup arguments, quotient and opening polynomials) commit ~15 % faster with 14 bits: 19 windows instead of 24. */
+int vdb_srs_load_window(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, uint32_t window_bits, vdb_srs **out);
 /* "unsafe" trusted setup with a caller-supplied tau, the construction ParamsKZG::setup performs behind
  * gen_srs(k) (src/scaffold/mod.rs:260-261: "unsafe" message); tau is a Montgomery Fr.  Test/bench SRS. */
 int vdb_srs_setup_unsafe(uint32_t k, const vdb_fr *tau, vdb_g1 *g_out, vdb_g1 *g_lagrange_out);

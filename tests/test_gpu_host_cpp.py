@@ -34,3 +34,36 @@ def test_example_kmeans_matches_oracle(O):
         cf = np.array([vecs[fid == k].mean(axis=0) for k in range(2)])
     assert ids == list(fid)
     assert np.allclose(got, cf, rtol=1e-6)
+
+
+def test_example_prove_commits_what_the_oracle_commits(O, tmp_path):
+    """the Prove arm in compiled code (host/example_prove.cpp): witness -> commit from the stream -> NTTs through the C ABI
+    alone; the commitments of the first / last advice column and the first lookup column are recomputed by the oracle's MSM
+    from the Lagrange columns the program dumps, over the SRS of the same tau; the cell counts are the oracle's"""
+    exe = os.path.join(ROOT, "halo2_vectordb_amd", "host", "example_prove")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "halo2_vectordb_amd", "csrc"), "../host/example_prove"])
+    rng = np.random.default_rng(77)
+    n, dim, K, I, k, L = 12, 6, 2, 2, 11, 10
+    vecs = rng.integers(0, 219, size=(n, dim)).astype(np.float64)
+    txt = f"{n} {dim} {K} {I} {k} {L}\n" + "\n".join(" ".join(repr(float(x)) for x in v) for v in vecs) + "\n"
+    tau, dump = 987654321987654321, tmp_path / "dump.bin"
+    out = subprocess.run([exe, str(tau), str(dump)], input=txt, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    words = out.stdout.split()
+    qv = O.quantize(vecs)
+    c = O.Ctx()
+    c.assign_witnesses(qv)
+    c.kmeans("euclidean", qv, K, I, L=L)
+    assert int(words[1]) == len(c) and int(words[3]) == c.n_lookup
+    raw = np.fromfile(dump, dtype=np.uint64)
+    n_adv, n_lk, rows = (int(x) for x in raw[:3])
+    assert rows == 1 << k and n_adv == int(words[5]) and n_lk == int(words[7]) and n_adv >= 2 and n_lk >= 1
+    commits = raw[3: 3 + (n_adv + n_lk) * 8].reshape(-1, 8)
+    cols = raw[3 + (n_adv + n_lk) * 8:].reshape(3, rows, 4)
+    _, gl = O.srs_from_tau(k, tau)
+    want = O.msm_batch(cols, gl)
+    assert np.array_equal(commits[[0, n_adv - 1, n_adv]], want)
+    # the first advice column starts with the assigned vectors, the lookup column with range-checked cells
+    assert np.array_equal(cols[0, : n * dim], qv.reshape(-1, 4))
+    assert np.array_equal(cols[2, :8], c.lookup()[:8])

@@ -212,7 +212,7 @@ def test_virtual_layout_matches_the_copied_layout(api, O, k, metric):
 def test_merkle_hot_path_c3_and_column_shards(api, O):
     """C3 (merkle_commitment over 1024 x 128 at k = 15) through the resident hot path: the root the trace ends in is the
     hash-only root, sampled commitments equal the oracle's MSM of the laid-out columns, and two column shards reproduce
-    the unsharded commitments (the way C5's 2^18-row circuits are cut to fit: tools/c5_merkle.py)."""
+    the unsharded commitments (the way C5's 2^18-row circuits are cut to fit: tools/c5_subcircuits.py)."""
     from halo2_vectordb_amd.pipeline import MerkleHotPath
     hp = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED).setup()
     assert hp.n_lk_cols == 0 and hp.n_cells == 1024 * (64 * 2256 + 2250) + 1023 * (2256 + 2250)

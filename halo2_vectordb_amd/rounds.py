@@ -296,6 +296,8 @@ class ProverRounds:
         allp = {**polys, **fx}
         opened = {0: ["adv", "sel", "sigma", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
+        opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
+        opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
         x_int = _fr_to_int(ch["x"])
         w_int = _fr_to_int(api.root_of_unity(k))
         evals, points = {}, {}

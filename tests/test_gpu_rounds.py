@@ -42,7 +42,7 @@ def check_quotient_identity(O, meta, ch, evals):
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     b, g, yv, x = (to_int(ch[n]) for n in ("beta", "gamma", "y", "x"))
     delta, n, n_adv, chunk, n_blind = meta["delta"], meta["rows"], meta["n_adv"], meta["chunk_len"], meta["n_blind"]
-    ev = lambda name, rot=0: evals[(name, rot)]
+    ev = lambda name, rot=0: evals.get((name, rot), [])
     acc = 0
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
@@ -223,3 +223,23 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
         assert np.array_equal(ch[name], out["challenges"][name])
     assert check_quotient_identity(O, meta, ch, evals)
     assert check_openings(O, O.fr_to_ints(ch["v"].reshape(1, 4))[0], commitments, evals, openings)
+
+
+def test_rounds_on_a_merkle_circuit_without_lookups(O):
+    """the same rounds on merkle_commitment (Poseidon trace, no lookup columns, every column dense): proof bytes from the
+    transcript, quotient identity and openings checked from the returned values"""
+    from halo2_vectordb_amd.pipeline import MerkleHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU).setup()      # 6 leaves (padded to 8), 3 + 1 permutations per leaf
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.n_lk == 0 and pr.n_adv >= 3
+        out = pr.prove(None, seed=3)
+        meta = _meta(pr)
+        assert out["commitments"]["pa"].shape == (0, 8) and len(out["proof"]) > 0
+        assert check_quotient_identity(O, meta, out["challenges"], out["evals"])
+        v = O.fr_to_ints(out["challenges"]["v"].reshape(1, 4))[0]
+        assert check_openings(O, v, out["commitments"], out["evals"], out["openings"])
+    finally:
+        pr.free()
+        hp.free()

@@ -1288,6 +1288,20 @@ int vdb_wit_nearest(int metric, uint32_t P, uint32_t L, const vdb_fr* query, con
   return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
 }
 
+int vdb_wit_nearest_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* query_dev, const vdb_fr* vectors_dev, size_t n, size_t dim, vdb_fr* stream_dev,
+                        vdb_fr* lookup_dev, uint8_t* selector_dev, vdb_fr* indicator_dev, vdb_fr* result_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(query_dev && vectors_dev && stream_dev && lookup_dev && indicator_dev && result_dev && n > 0 && dim > 0, "null pointer or empty input");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  int* derr = (int*)scratch_get(1, 64);
+  if (!derr) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, 0, ~0ull, 0, ~0ull};
+  TRY(wit_nearest_dev(fp, metric, as_u256(query_dev), as_u256(vectors_dev), n, dim, st, 0, 0, as_u256(indicator_dev), as_u256(result_dev)));
+  return check_err_flag(derr);
+}
+
 int vdb_wit_kmeans_size(int metric, uint32_t P, uint32_t L, size_t n, size_t dim, size_t K, size_t I, int zero_cached, uint64_t* cells,
                         uint64_t* lookups) {
   VDB_REQUIRE_INIT();

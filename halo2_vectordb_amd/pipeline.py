@@ -124,7 +124,7 @@ class KmeansHotPath:
         points are used as they are — the Prove arm of the reference (src/scaffold/mod.rs:285-287) — after checking that
         they describe this circuit; otherwise they are derived from the keygen-style run, like the Keygen arm."""
         lib, n, dim, K, I = self.lib, self.n, self.dim, self.K, self.I
-        vec, self.seed = sift_like_vectors(self.seed, n, dim, K)
+        vec, self.seed = self._input_vectors()
         self.vectors_f64 = vec
         self.qvec = api.quantize(vec, self.P)
         self.n_in, n_gadget_cells, self.n_lookup = self._circuit_size()
@@ -245,6 +245,10 @@ class KmeansHotPath:
         return self
 
     # ------------------------------------------------------------------ what is specific to the k-means circuit
+    def _input_vectors(self):
+        """(f64 rows that ctx.assign_witnesses puts at the head of the stream, seed actually used)"""
+        return sift_like_vectors(self.seed, self.n, self.dim, self.K)
+
     def _circuit_size(self):
         """(cells of ctx.assign_witnesses(quantize_vector(v)) for every vector, cells the gadget emits, lookup cells)"""
         cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
@@ -416,3 +420,43 @@ class MerkleHotPath(KmeansHotPath):
         if getattr(self, "d_root", None) is not None:
             self.d_root.free()
             self.d_root = None
+
+
+class NearestHotPath(KmeansHotPath):
+    """nearest_vector(query, vectors) (src/gadget/vectordb.rs:122-163; tests/vectordb/mod.rs:220-247 assigns the query, then the
+    vectors) through the same hot path.  The running minimum is one chain over all vectors, so every rank emits the whole
+    witness and takes its block of columns."""
+
+    def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1)):
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard)
+        self.shard_witness = False
+
+    def _input_vectors(self):
+        vec, seed = sift_like_vectors(self.seed, self.n, self.dim)
+        query, _ = sift_like_vectors(seed + 1000, 1, self.dim)
+        return np.concatenate([query, vec]), seed
+
+    def _circuit_size(self):
+        cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.lib.vdb_wit_nearest_size(self.metric, self.P, self.L, self.n, self.dim, ctypes.byref(cells), ctypes.byref(lk)))
+        return (self.n + 1) * self.dim, cells.value, lk.value
+
+    def _alloc_outputs(self):
+        self.d_ind = api.DeviceBuffer(self.n * 32)
+        self.d_res = api.DeviceBuffer(self.dim * 32)
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
+        check(lib.vdb_wit_nearest_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.d_vec.at(self.dim * 32), self.n, self.dim, self.d_stream.at(self.n_in * 32),
+                                      self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_ind.ptr,
+                                      self.d_res.ptr))
+
+    def results(self):
+        return self.d_ind.download((self.n, 4)), self.d_res.download((self.dim, 4))
+
+    def free(self):
+        super().free()
+        if getattr(self, "d_res", None) is not None:
+            self.d_res.free()
+            self.d_res = None

@@ -110,6 +110,10 @@ int vdb_wit_nearest(int metric, uint32_t precision_bits, uint32_t lookup_bits, c
                     vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *indicator_out, vdb_fr *result_out);
 /* VectorDBChip::kmeans::<K, I> (src/gadget/vectordb.rs:225-362): centroids K x dim, indicators n x K
  * (quantized 1.0 / 0).  zero_cached: Context::load_zero already called earlier in this context. */
+/* the same on device-resident buffers (query_dev: dim, vectors_dev: n x dim; outputs stay in HBM); always emits the whole
+ * stream (the rank window of vdb_wit_set_window is not applied: the running minimum is one sequential chain) */
+int vdb_wit_nearest_dev(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *query_dev, const vdb_fr *vectors_dev, size_t n, size_t dim,
+                        vdb_fr *stream_dev, vdb_fr *lookup_dev, uint8_t *selector_dev, vdb_fr *indicator_dev, vdb_fr *result_dev);
 int vdb_wit_kmeans_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
                         uint64_t *cells, uint64_t *lookups);
 int vdb_wit_kmeans(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors, size_t n, size_t dim, size_t K, size_t I,

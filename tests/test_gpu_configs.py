@@ -229,3 +229,23 @@ def test_merkle_hot_path_c3_and_column_shards(api, O):
         parts.append(h.step().copy())
         h.free()
     assert sum(len(p) for p in parts) == n_adv and np.array_equal(np.concatenate(parts), full)
+
+
+def test_nearest_hot_path_c2(api, O):
+    """C2 (nearest_vector over 64 x 128 + query at k = 14) through the resident hot path (vdb_wit_nearest_dev): same cells as the
+    host-buffer entry point behind [query | vectors], same indicator / result, sampled commitments equal the oracle's MSM"""
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    hp = NearestHotPath(n=64, dim=128, k=14, L=13, tau=0xC2).setup()
+    got = hp.step().copy()
+    ref = api.wit_nearest("euclidean", hp.qvec[0], hp.qvec[1:], L=13)
+    assert hp.n_cells == 65 * 128 + ref["stream"].shape[0] and hp.n_lookup == ref["lookup"].shape[0]
+    ind, res = hp.results()
+    assert np.array_equal(ind, ref["indicator"]) and np.array_equal(res, ref["result"])
+    want = int(np.argmin(np.linalg.norm(hp.vectors_f64[1:] - hp.vectors_f64[0], axis=1)))
+    assert [int(v) for v in O.fr_to_ints(ind)].index(1) == want
+    hp.relayout()
+    pick = [0, 1, hp.n_adv_cols - 1, hp.n_adv_cols, hp.n_cols - 1]
+    cols = hp.download_columns(pick)
+    assert np.array_equal(cols[0][: 65 * 128], hp.qvec.reshape(-1, 4)[: 65 * 128])
+    assert np.array_equal(got[pick], O.msm_batch(cols, hp.g_lagrange))
+    hp.free()

@@ -4,7 +4,7 @@ the database Merkle commitment (1.54 G cells, 5,876 columns, 49 GB 
 (0.95 G + 0.19 G cells, 3,615 + 713 columns) — through the hot path on ONE card, as the `world` column shards an 8-GPU job
 would run side by side, here one after the other (each shard: witness cells of its columns -> commit -> transforms).
 Prints per-shard and summed times; the Merkle root is checked against the hash-only kernel.
-usage: c5_subcircuits.py [merkle|kmeans] [n] [world] [k]"""
+usage: c5_subcircuits.py [merkle|kmeans|nearest] [n] [world] [k]"""
 import json
 import os
 import sys
@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from halo2_vectordb_amd import api
 from halo2_vectordb_amd._lib import check
-from halo2_vectordb_amd.pipeline import KmeansHotPath, MerkleHotPath
+from halo2_vectordb_amd.pipeline import KmeansHotPath, MerkleHotPath, NearestHotPath
 
 which = sys.argv[1] if len(sys.argv) > 1 else "merkle"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
@@ -27,6 +27,8 @@ for rank in range(world):
     t0 = time.time()
     if which == "merkle":
         hp = MerkleHotPath(n=n, dim=128, k=k, seed=20260005, col_shard=(rank, world)).setup()
+    elif which == "nearest":     # the query's nearest vector inside one cluster of ~n vectors
+        hp = NearestHotPath(n=n, dim=128, k=k, L=k - 1, seed=20260005, col_shard=(rank, world)).setup()
     else:       # tests/demo/mod.rs:52: kmeans::<2, 1>; LOOKUP_BITS = k - 1
         hp = KmeansHotPath(n=n, dim=128, K=2, I=1, k=k, L=k - 1, seed=20260005, col_shard=(rank, world)).setup()
     t_setup = time.time() - t0
@@ -43,7 +45,8 @@ for rank in range(world):
     hp.free()
     check(lib.vdb_scratch_release())            # the next shard's keygen-style setup needs the memory
 tot = sum(r["wall_ms"] for r in per_rank)
-name = f"merkle_commitment {n}x128 k={k} (BASELINE C5, database Merkle)" if which == "merkle" else f"kmeans<2,1> {n}x128 k={k} L={k - 1} (BASELINE C5)"
+name = {"merkle": f"merkle_commitment {n}x128 k={k} (BASELINE C5, database Merkle)", "kmeans": f"kmeans<2,1> {n}x128 k={k} L={k - 1} (BASELINE C5)",
+        "nearest": f"nearest_vector in a cluster of {n}x128 k={k} L={k - 1} (BASELINE C5)"}[which]
 print(json.dumps({"workload": name, "cells": cells, "columns": cols, "shards": world,
                   **({"root_matches_hash_only_kernel": bool(root_ok)} if which == "merkle" else {}), "sum_ms": round(tot, 1), "max_shard_ms": max(r["wall_ms"] for r in per_rank),
                   "constraints_per_s_one_card": cells / tot * 1e3, "per_shard": per_rank}))

@@ -28,6 +28,21 @@ HD L9 l9_split(const u256& a) {
   }
   return r;
 }
+// 32 * a as nine limbs (a < 2^256, so 32 a < 2^261): the second operand that keeps a nine-limb product of two values in
+// ordinary Montgomery form (R = 2^256) in that form: (x R)(32 y R) / 2^261 = x y R
+HD L9 l9_split32(const u256& a) {
+  L9 r;
+  r.l[0] = (a.w[0] << 5) & 0x1fffffffu;
+#pragma unroll
+  for (int k = 1; k < 9; k++) {
+    int pb = 29 * k - 5, wb = pb >> 5, ob = pb & 31;
+    uint32_t lo = a.w[wb];
+    uint32_t hi = wb + 1 < 8 ? a.w[wb + 1 < 8 ? wb + 1 : 0] : 0u;
+    r.l[k] = ob ? ((lo >> ob) | (hi << (32 - ob))) : lo;
+    if (k < 8) r.l[k] &= 0x1fffffffu;
+  }
+  return r;
+}
 // exactly normalised limbs of a value below 2^256 -> eight words
 HD u256 l9_pack(const L9& L) {
   u256 r;

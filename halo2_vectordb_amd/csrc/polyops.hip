@@ -290,19 +290,28 @@ __global__ __launch_bounds__(256) void k_lp_rows(const uint32_t* __restrict__ in
 // with powers of the challenge y (halo2 evaluates them column after column by Horner's rule: acc = acc * y + gate,
 // [UPSTREAM-RECALL] for the order only).  On the extended coset of size 2^(k+e) a rotation by one row is a step of 2^e.
 // One thread per extended row, columns in a loop: consecutive lanes read consecutive rows of the same column.
+// The accumulator and the gate value live in nine-limb form (limb9.hpp): b c is one product with the second factor
+// re-limbed as 32 c, a + b c - d is added without carries (limbs below 4.1 * 2^29, value below 5 r), and h y + q g is ONE
+// reduction over two products (l9_mul2: limbs of h and g together below 6 * 2^29; the result is normalised and below
+// (2 r * r + 5 r * 32 r) / 2^261 + r < 2 r).  2.4 reductions' worth per cell instead of 3 full field products.
+struct GateK {
+  uint32_t c2[9];  // 2 r written with dominating limbs (l9_offset_limbs): subtracting a canonical value
+};
 __global__ __launch_bounds__(256) void k_gate_eval(const u256* __restrict__ adv, const u256* __restrict__ sel, uint64_t n_cols, uint32_t log_ne, uint32_t e,
-                                                   u256 y, u256* __restrict__ acc) {
+                                                   u256 y32 /* 32 y */, GateK gk, u256* __restrict__ acc) {
   const uint64_t ne = 1ull << log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
   const uint64_t mask = ne - 1, r = 1ull << e;
-  u256 h = ld256(acc + j);
+  const L9 Y = l9_split(y32);
+  L9 h = l9_split(ld256(acc + j));
   for (uint64_t c = 0; c < n_cols; c++) {
     const u256* a = adv + c * ne;
-    const u256 q = ld256(sel + c * ne + j);
-    u256 g = fr_sub(fr_add(ld256(a + j), fr_mul(ld256(a + ((j + r) & mask)), ld256(a + ((j + 2 * r) & mask)))), ld256(a + ((j + 3 * r) & mask)));
-    h = fr_add(fr_mul(h, y), fr_mul(q, g));
+    const L9 q32 = l9_split32(ld256(sel + c * ne + j));
+    const L9 bc = l9_mul<Fr>(l9_split(ld256(a + ((j + r) & mask))), l9_split32(ld256(a + ((j + 2 * r) & mask))));
+    const L9 g = l9_sub(l9_add(l9_split(ld256(a + j)), bc), l9_split(ld256(a + ((j + 3 * r) & mask))), gk.c2);
+    h = l9_mul2<Fr>(h, Y, g, q32);
   }
-  st256(acc + j, h);
+  st256(acc + j, l9_canon<Fr>(h));
 }
 // h[j] *= t[j mod 2^e],  t[m] = 1 / (zeta^n * w_{2^e}^m - 1): division by the vanishing polynomial X^n - 1 on the coset
 __global__ __launch_bounds__(256) void k_mul_periodic(u256* __restrict__ h, uint64_t ne, const u256* __restrict__ t, uint32_t period_mask) {
@@ -597,8 +606,10 @@ int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size
   const uint64_t ne = 1ull << (k + ext_k);
   {
     VDB_PROF("k_gate_eval");
+    GateK gk;
+    l9_offset_limbs<FrParams>(2, gk.c2);
     hipLaunchKernelGGL(k_gate_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(adv_ext_dev), as_u256(sel_ext_dev), (uint64_t)n_cols,
-                     k + ext_k, ext_k, yv, as_u256(acc_dev));
+                     k + ext_k, ext_k, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

@@ -406,15 +406,24 @@ __global__ __launch_bounds__(256) void k_zero_tail(u256* __restrict__ z, uint64_
 // [UPSTREAM-RECALL] for the order of the terms; each term is folded in as acc = acc * y + term) --------------------------
 // Rotation by one row = a step of 2^e on the coset of 2^(k+e) points.  l0, l_last, l_active = 1 - (l_last + l_blind) are the
 // Lagrange selectors on the coset; bx[j] = beta * X_j.  One thread per extended row, sets / columns in a loop.
+// All arithmetic in nine-limb form (limb9.hpp) on representatives scaled by 2^261 instead of 2^256: a value loaded from
+// memory (x 2^256, below r) enters as 32 times itself — the same bits re-limbed (l9_split32), no arithmetic —, constants are
+// scaled on the host, a nine-limb product of two such values is again such a value, sums and differences add limbs without
+// carries, and `h y + l t` is one reduction over two products (l9_mul2).  One product by 2^256 per thread at the very end
+// returns to the memory form.  Bounds (value in multiples of r, before the + r of a product): a loaded value is below 32,
+// a product of two loaded values below 32 * 32 * r / 2^261 = 6.1, any product with a reduced factor far below that; the
+// offsets added by subtractions (c34 = 34 r when a loaded value is subtracted, c9 = 9 r for products) keep limbs below
+// 3 * 2^29 and values below 70 r, all far below 2^261 = 169 r.
 struct QuotArgs {
   const u256 *l0, *l_last, *l_active;
-  u256 beta, gamma, delta, y;
+  u256 beta, gamma, delta, y;  // scaled: 32 * value
   uint32_t log_ne, e;
   uint64_t last_rot;  // rows between the last usable row and the end: n - usable_rows
+  uint32_t c9[9], c34[9];
 };
 // Sets [set_lo, set_hi) of the product terms; the terms that involve only the product columns come with set_lo == 0.
-// `sigma` points at the first column of set_lo (the sigma cosets may be produced block by block); bx = beta X delta^(set_lo
-// chunk_len) on entry.
+// `sigma` points at the first column of set_lo (the sigma cosets may be produced block by block); bx = beta X, dstart =
+// 32 delta^(set_lo chunk_len).
 __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv, const u256* __restrict__ sigma, const u256* __restrict__ z, uint64_t n_cols,
                                                    uint32_t chunk_len, uint64_t set_lo, uint64_t set_hi, const u256* __restrict__ bx, u256 dstart, QuotArgs q,
                                                    u256* __restrict__ acc) {
@@ -422,60 +431,67 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
   if (j >= ne) return;
   const uint64_t mask = ne - 1, r = 1ull << q.e;
   const uint64_t n_sets = (n_cols + chunk_len - 1) / chunk_len;
-  const u256 one = mont_one<Fr>();
-  const u256 l0 = ld256(q.l0 + j), ll = ld256(q.l_last + j), la = ld256(q.l_active + j);
-  u256 h = ld256(acc + j);
+  const L9 Y = l9_split(q.y), B = l9_split(q.beta), G = l9_split(q.gamma), D = l9_split(q.delta);
+  const L9 L0 = l9_split32(ld256(q.l0 + j)), LL = l9_split32(ld256(q.l_last + j)), LA = l9_split32(ld256(q.l_active + j));
+  L9 h = l9_split32(ld256(acc + j));
   if (set_lo == 0) {
     // l0 (1 - z_0)
-    h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, ld256(z + j))));
+    h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(mont_one<Fr>()), l9_split32(ld256(z + j)), q.c34), L0);
     // l_last (z_last^2 - z_last)
     {
-      const u256 zl = ld256(z + (n_sets - 1) * ne + j);
-      h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zl, zl), zl)));
+      const L9 zl = l9_split32(ld256(z + (n_sets - 1) * ne + j));
+      h = l9_mul2<Fr>(h, Y, l9_sub(l9_mul<Fr>(zl, zl), zl, q.c34), LL);
     }
     // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
     const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
-    for (uint64_t i = 1; i < n_sets; i++) h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(ld256(z + i * ne + j), ld256(z + (i - 1) * ne + jb))));
+    for (uint64_t i = 1; i < n_sets; i++)
+      h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(ld256(z + i * ne + j)), l9_split32(ld256(z + (i - 1) * ne + jb)), q.c34), L0);
   }
   // l_active (z_i(w X) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma))
-  u256 cur = fr_mul(ld256(bx + j), dstart);
+  L9 cur = l9_mul<Fr>(l9_split32(ld256(bx + j)), l9_split(dstart));
   const uint64_t cb = set_lo * chunk_len;  // first column of the sigma block
   for (uint64_t i = set_lo; i < set_hi; i++) {
     const uint64_t c0 = i * chunk_len, c1 = c0 + chunk_len < n_cols ? c0 + chunk_len : n_cols;
-    u256 left = ld256(z + i * ne + ((j + r) & mask)), right = ld256(z + i * ne + j);
+    L9 left = l9_split32(ld256(z + i * ne + ((j + r) & mask))), right = l9_split32(ld256(z + i * ne + j));
     for (uint64_t c = c0; c < c1; c++) {
-      const u256 v = fr_add(ld256(adv + c * ne + j), q.gamma);
-      left = fr_mul(left, fr_add(v, fr_mul(q.beta, ld256(sigma + (c - cb) * ne + j))));
-      right = fr_mul(right, fr_add(v, cur));
-      cur = fr_mul(cur, q.delta);
+      const L9 v = l9_add(l9_split32(ld256(adv + c * ne + j)), G);
+      left = l9_mul<Fr>(l9_add(v, l9_mul<Fr>(l9_split32(ld256(sigma + (c - cb) * ne + j)), B)), left);
+      right = l9_mul<Fr>(l9_add(v, cur), right);
+      cur = l9_mul<Fr>(cur, D);
     }
-    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_sub(left, right)));
+    h = l9_mul2<Fr>(h, Y, l9_sub(left, right, q.c9), LA);
   }
-  st256(acc + j, h);
+  st256(acc + j, l9_canon<Fr>(l9_mul<Fr>(h, l9_split(mont_one<Fr>()))));
 }
 __global__ __launch_bounds__(256) void k_lookup_eval(const u256* __restrict__ a, const u256* __restrict__ tab, const u256* __restrict__ pa, const u256* __restrict__ pt,
-                                                     const u256* __restrict__ z, uint64_t n_cols, QuotArgs q, u256* __restrict__ acc) {
+                                                     const u256* __restrict__ z, uint64_t n_cols, QuotArgs q, u256 beta_m, u256 gamma_m /* memory form */,
+                                                     u256* __restrict__ acc) {
   const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
   const uint64_t mask = ne - 1, r = 1ull << q.e;
-  const u256 one = mont_one<Fr>();
-  const u256 l0 = ld256(q.l0 + j), ll = ld256(q.l_last + j), la = ld256(q.l_active + j);
-  const u256 sg = fr_add(ld256(tab + j), q.gamma);
-  u256 h = ld256(acc + j);
+  const L9 Y = l9_split(q.y), B = l9_split(q.beta);
+  const L9 L0 = l9_split32(ld256(q.l0 + j)), LL = l9_split32(ld256(q.l_last + j)), LA = l9_split32(ld256(q.l_active + j));
+  const L9 ONE = l9_split32(mont_one<Fr>());
+  // second factors of a product must be normalised: sums that serve as one are made in memory form first
+  const L9 sg = l9_split32(fr_add(ld256(tab + j), gamma_m));
+  L9 h = l9_split32(ld256(acc + j));
   for (uint64_t c = 0; c < n_cols; c++) {
     const uint64_t o = c * ne;
-    const u256 zc = ld256(z + o + j), zn = ld256(z + o + ((j + r) & mask));
-    const u256 av = ld256(a + o + j), pav = ld256(pa + o + j), ptv = ld256(pt + o + j), pap = ld256(pa + o + ((j + ne - r) & mask));
-    h = fr_add(fr_mul(h, q.y), fr_mul(l0, fr_sub(one, zc)));                         // l0 (1 - z)
-    h = fr_add(fr_mul(h, q.y), fr_mul(ll, fr_sub(fr_mul(zc, zc), zc)));              // l_last (z^2 - z)
-    const u256 left = fr_mul(zn, fr_mul(fr_add(pav, q.beta), fr_add(ptv, q.gamma)));
-    const u256 right = fr_mul(zc, fr_mul(fr_add(av, q.beta), sg));
-    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_sub(left, right)));                     // l_active (z(wX)(a'+b)(s'+g) - z (a+b)(s+g))
-    const u256 d = fr_sub(pav, ptv);
-    h = fr_add(fr_mul(h, q.y), fr_mul(l0, d));                                       // l0 (a' - s')
-    h = fr_add(fr_mul(h, q.y), fr_mul(la, fr_mul(d, fr_sub(pav, pap))));             // l_active (a' - s')(a' - a'(w^-1 X))
+    const L9 zc = l9_split32(ld256(z + o + j)), zn = l9_split32(ld256(z + o + ((j + r) & mask)));
+    const u256 pav_m = ld256(pa + o + j), ptv_m = ld256(pt + o + j);
+    const L9 av = l9_split32(ld256(a + o + j)), pav = l9_split32(pav_m), ptv = l9_split32(ptv_m);
+    h = l9_mul2<Fr>(h, Y, l9_sub(ONE, zc, q.c34), L0);                                     // l0 (1 - z)
+    h = l9_mul2<Fr>(h, Y, l9_sub(l9_mul<Fr>(zc, zc), zc, q.c34), LL);                      // l_last (z^2 - z)
+    const L9 left = l9_mul<Fr>(l9_mul<Fr>(l9_add(pav, B), l9_split32(fr_add(ptv_m, gamma_m))), zn);
+    const L9 right = l9_mul<Fr>(l9_mul<Fr>(l9_add(av, B), sg), zc);
+    h = l9_mul2<Fr>(h, Y, l9_sub(left, right, q.c9), LA);                                  // l_active (z(wX)(a'+b)(s'+g) - z (a+b)(s+g))
+    const L9 d = l9_sub(pav, ptv, q.c34);
+    h = l9_mul2<Fr>(h, Y, d, L0);                                                          // l0 (a' - s')
+    const L9 e = l9_split32(fr_sub(pav_m, ld256(pa + o + ((j + ne - r) & mask))));
+    h = l9_mul2<Fr>(h, Y, l9_mul<Fr>(d, e), LA);                                           // l_active (a' - s')(a' - a'(w^-1 X))
   }
-  st256(acc + j, h);
+  (void)beta_m;
+  st256(acc + j, l9_canon<Fr>(l9_mul<Fr>(h, l9_split(mont_one<Fr>()))));
 }
 
 // ---- opening proofs: division by a linear factor (halo2 arithmetic::kate_division, [UPSTREAM-RECALL]) and the linear
@@ -761,11 +777,19 @@ static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const 
   q.l0 = as_u256(l0);
   q.l_last = as_u256(l_last);
   q.l_active = as_u256(l_active);
-  memcpy(&q.beta, beta, 32);
-  memcpy(&q.gamma, gamma, 32);
-  if (delta) memcpy(&q.delta, delta, 32);
-  else q.delta = mont_one<Fr>();
-  memcpy(&q.y, y, 32);
+  const u256 m32 = host_fr_from_u64(32);
+  u256 t;
+  memcpy(&t, beta, 32);
+  q.beta = fr_mul(t, m32);
+  memcpy(&t, gamma, 32);
+  q.gamma = fr_mul(t, m32);
+  if (delta) memcpy(&t, delta, 32);
+  else t = mont_one<Fr>();
+  q.delta = fr_mul(t, m32);
+  memcpy(&t, y, 32);
+  q.y = fr_mul(t, m32);
+  l9_offset_limbs<FrParams>(9, q.c9);
+  l9_offset_limbs<FrParams>(34, q.c34);
   q.log_ne = k + ext_k;
   q.e = ext_k;
   q.last_rot = (1ull << k) - usable_rows;
@@ -788,7 +812,10 @@ int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigm
   const uint64_t ne = 1ull << (k + ext_k);
   u256* bx = (u256*)scratch_get(5, ne * sizeof(u256));
   if (!bx) return VDB_ERR_OOM;
-  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k + ext_k), fr_mul(q.beta, host_zeta()), ne,
+  u256 beta_m, delta_m;
+  memcpy(&beta_m, beta, 32);
+  memcpy(&delta_m, delta, 32);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k + ext_k), fr_mul(beta_m, host_zeta()), ne,
                      bx);
   {
     VDB_PROF("k_perm_eval");
@@ -797,8 +824,8 @@ int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigm
     e.w[0] = (uint32_t)pw;
     e.w[1] = (uint32_t)(pw >> 32);
     hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_block_dev),
-                       as_u256(z_ext_dev), (uint64_t)n_cols, (uint32_t)chunk_len, (uint64_t)set_lo, (uint64_t)set_hi, bx, mont_pow<Fr>(q.delta, e), q,
-                       as_u256(acc_dev));
+                       as_u256(z_ext_dev), (uint64_t)n_cols, (uint32_t)chunk_len, (uint64_t)set_lo, (uint64_t)set_hi, bx,
+                       fr_mul(mont_pow<Fr>(delta_m, e), host_fr_from_u64(32)), q, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
@@ -821,11 +848,14 @@ int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev
   if (n_cols == 0) return VDB_OK;
   QuotArgs q;
   quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, nullptr, y, k, ext_k, 0);
+  u256 beta_m, gamma_m;
+  memcpy(&beta_m, beta, 32);
+  memcpy(&gamma_m, gamma, 32);
   const uint64_t ne = 1ull << (k + ext_k);
   {
     VDB_PROF("k_lookup_eval");
     hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
-                       as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, as_u256(acc_dev));
+                       as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, beta_m, gamma_m, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

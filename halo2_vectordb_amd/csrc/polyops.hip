@@ -557,12 +557,15 @@ __global__ __launch_bounds__(KD_THREADS) void k_kate_div(const u256* __restrict_
   if (t == 0 && rem) st256(rem + col, s_carry);
 }
 // out = sum_c v^(n_cols-1-c) p_c  (Horner over the polynomials: out = out * v + p_c), one thread per coefficient
-__global__ __launch_bounds__(256) void k_poly_lincomb(const u256* __restrict__ polys, uint64_t n_cols, uint64_t n, u256 v, u256* __restrict__ out) {
+// (nine-limb Horner on 2^261-scaled representatives, as in the quotient kernels: acc * v is one product, the coefficient
+// enters as 32 times itself without arithmetic and is added without carries — acc stays below 34 r, limbs below 2 * 2^29)
+__global__ __launch_bounds__(256) void k_poly_lincomb(const u256* __restrict__ polys, uint64_t n_cols, uint64_t n, u256 v32 /* 32 v */, u256* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u256 acc = ld256(out + i);
-  for (uint64_t c = 0; c < n_cols; c++) acc = fr_add(fr_mul(acc, v), ld256(polys + c * n + i));
-  st256(out + i, acc);
+  const L9 V = l9_split(v32);
+  L9 acc = l9_split32(ld256(out + i));
+  for (uint64_t c = 0; c < n_cols; c++) acc = l9_add(l9_mul<Fr>(acc, V), l9_split32(ld256(polys + c * n + i)));
+  st256(out + i, l9_canon<Fr>(l9_mul<Fr>(acc, l9_split(mont_one<Fr>()))));
 }
 
 // rows [from, n) of every column <- src (n_cols x (n - from)): the blinding rows the prover appends to the columns it derives
@@ -906,8 +909,8 @@ int vdb_poly_lincomb_dev(const vdb_fr* polys_dev, size_t n_cols, size_t n, const
   memcpy(&vv, v, 32);
   {
     VDB_PROF("k_poly_lincomb");
-    hipLaunchKernelGGL(k_poly_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(polys_dev), (uint64_t)n_cols, (uint64_t)n, vv,
-                       as_u256(acc_dev));
+    hipLaunchKernelGGL(k_poly_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(polys_dev), (uint64_t)n_cols, (uint64_t)n,
+                       fr_mul(vv, host_fr_from_u64(32)), as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

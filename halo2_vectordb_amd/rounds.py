@@ -359,3 +359,42 @@ class ProverRounds:
             if getattr(self, name, None) is not None:
                 getattr(self, name).free()
                 setattr(self, name, None)
+
+
+def quotient_identity_holds(pr, challenges, evals):
+    """What a verifier checks first: the gate, permutation and lookup expressions recombined from the evaluations at x (and the
+    rotated points) equal h(x) (x^n - 1).  `pr`: the ProverRounds that produced them (for the circuit's shape); `challenges`,
+    `evals`: as returned by ProverRounds.prove.  Plain integer arithmetic on the host."""
+    R = R_MOD
+    b, g, yv, x = (_fr_to_int(challenges[name]) for name in ("beta", "gamma", "y", "x"))
+    delta, n, n_adv = _fr_to_int(pr.delta), pr.rows, pr.n_adv
+    ev = lambda name, rot=0: evals.get((name, rot), [])
+    acc = 0
+    a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
+    for c in range(n_adv):
+        acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
+    l0, ll, la = ev("lag")
+    sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
+    n_cols, n_sets = len(a0), len(z0)
+    acc = (acc * yv + l0 * (1 - z0[0])) % R
+    acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
+    for i in range(1, n_sets):
+        acc = (acc * yv + l0 * (z0[i] - zb[i - 1])) % R
+    cur = b * x % R
+    for i in range(n_sets):
+        left, right = z1[i], z0[i]
+        for c in range(i * CHUNK_LEN, min((i + 1) * CHUNK_LEN, n_cols)):
+            left = left * (a0[c] + b * sg[c] + g) % R
+            right = right * (a0[c] + cur + g) % R
+            cur = cur * delta % R
+        acc = (acc * yv + la * (left - right)) % R
+    A, S, PA, PS, PAm, Z, Z1 = a0[n_adv:], ev("table")[0], ev("pa"), ev("ps"), ev("pa", -1), ev("zl"), ev("zl", 1)
+    for c in range(len(PA)):
+        acc = (acc * yv + l0 * (1 - Z[c])) % R
+        acc = (acc * yv + ll * (Z[c] * Z[c] - Z[c])) % R
+        acc = (acc * yv + la * (Z1[c] * (PA[c] + b) * (PS[c] + g) - Z[c] * (A[c] + b) * (S + g))) % R
+        acc = (acc * yv + l0 * (PA[c] - PS[c])) % R
+        acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
+    xn = pow(x, n, R)
+    hx = sum(h_i * pow(xn, i, R) for i, h_i in enumerate(ev("h"))) % R
+    return acc == hx * (xn - 1) % R and acc != 0

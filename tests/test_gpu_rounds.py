@@ -114,8 +114,10 @@ def test_round_outputs_have_the_expected_shape(circuit, proved):
 
 
 def test_quotient_identity_from_the_returned_evaluations(circuit, proved, O):
+    from halo2_vectordb_amd.rounds import quotient_identity_holds
     ch, out, _ = proved
     assert check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"])
+    assert quotient_identity_holds(circuit[1], out["challenges"], out["evals"])      # the library-side helper agrees
     wrong = dict(out["evals"])
     wrong[("zl", 1)] = [(e + 1) % O.R_MOD for e in wrong[("zl", 1)]]
     assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)

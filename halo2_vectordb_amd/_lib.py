@@ -84,6 +84,7 @@ _SIGNATURES = {
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
     "vdb_scratch_release": [],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
+    "vdb_poly_axpy_dev": [_P, _P, _P, _SZ],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_eval_range_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _SZ],

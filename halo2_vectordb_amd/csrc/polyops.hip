@@ -575,6 +575,12 @@ __global__ __launch_bounds__(256) void k_fill_rows(u256* __restrict__ cols, uint
   const uint64_t cnt = n - from, c = i / cnt, r = i % cnt;
   st256(cols + c * n + from + r, ld256(src + i));
 }
+// acc += a * x, coefficient by coefficient (the scaled sums of SHPLONK's linearisation polynomial)
+__global__ __launch_bounds__(256) void k_poly_axpy(u256* __restrict__ acc, u256 a, const u256* __restrict__ x, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st256(acc + i, fr_add(ld256(acc + i), fr_mul(a, ld256(x + i))));
+}
 
 }  // namespace vdb
 
@@ -871,6 +877,17 @@ int vdb_fill_rows_dev(vdb_fr* cols_dev, size_t n_cols, size_t n, size_t from_row
   if (total == 0) return VDB_OK;
   hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(cols_dev), (uint64_t)n, (uint64_t)from_row,
                      as_u256(src_dev), total);
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_poly_axpy_dev(vdb_fr* acc_dev, const vdb_fr* a, const vdb_fr* x_dev, size_t n) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(acc_dev && a && x_dev, "null pointer");
+  if (n == 0) return VDB_OK;
+  u256 av;
+  memcpy(&av, a, 32);
+  hipLaunchKernelGGL(k_poly_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(acc_dev), av, as_u256(x_dev), (uint64_t)n);
   VDB_LAUNCH_CHECK();
   return VDB_OK;
 }

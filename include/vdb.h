@@ -298,6 +298,8 @@ int vdb_fill_rows_dev(vdb_fr *cols_dev, size_t n_cols, size_t n, size_t from_row
  * vdb_kate_div_dev (arithmetic::kate_division): per polynomial of n coefficients q(X) = (p(X) - p(x)) / (X - x), n coefficients
  * written (the top one zero); rem_host (may be NULL) receives p(x).  Dividing by a product of linear factors — the vanishing
  * polynomial of a SHPLONK rotation set — is this call once per point. */
+/* acc <- acc + a * x over n coefficients (SHPLONK's linearisation polynomial is a sum of polynomials with unrelated scalars) */
+int vdb_poly_axpy_dev(vdb_fr *acc_dev, const vdb_fr *a, const vdb_fr *x_dev, size_t n);
 int vdb_poly_lincomb_dev(const vdb_fr *polys_dev, size_t n_cols, size_t n, const vdb_fr *v, vdb_fr *acc_dev);
 int vdb_kate_div_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *quot_dev, vdb_fr *rem_host);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */

@@ -32,7 +32,7 @@ def proved(circuit, O):
     rng = np.random.default_rng(99)
     ch = {name: O.random_fr(rng, 1)[0] for name in ("beta", "gamma", "y", "x", "v")}
     timings = {}
-    out = pr.prove(ch, seed=5, timings=timings)
+    out = pr.prove(ch, seed=5, timings=timings, multiopen="gwc")
     return ch, out, timings
 
 
@@ -166,7 +166,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     hp, pr = circuit
     assert pr.n_cols > 2 * 30
     pr.block_cols = 30            # the selector / sigma cosets in several blocks (sets 0-9, 10-19, ...)
-    out = pr.prove(None, seed=11)
+    out = pr.prove(None, seed=11, multiopen="gwc")
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")}
@@ -236,7 +236,7 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
     pr = ProverRounds(hp).keygen()
     try:
         assert pr.n_lk == 0 and pr.n_adv >= 3
-        out = pr.prove(None, seed=3)
+        out = pr.prove(None, seed=3, multiopen="gwc")
         meta = _meta(pr)
         assert out["commitments"]["pa"].shape == (0, 8) and len(out["proof"]) > 0
         assert check_quotient_identity(O, meta, out["challenges"], out["evals"])
@@ -245,3 +245,69 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
     finally:
         pr.free()
         hp.free()
+
+
+def _interpolate(pts, vals, R):
+    coeffs = [0] * len(pts)
+    for i, (xi, yi) in enumerate(zip(pts, vals)):
+        basis, denom = [1], 1
+        for j, xj in enumerate(pts):
+            if j != i:
+                basis = [(a - xj * b) % R for a, b in zip([0] + basis, basis + [0])]
+                denom = denom * (xi - xj) % R
+        scale = yi * pow(denom, -1, R) % R
+        coeffs = [(c + scale * b) % R for c, b in zip(coeffs, basis)]
+    return coeffs
+
+
+def test_shplonk_multiopen_verifies_in_the_exponent(circuit, O):
+    """the multi-open the reference's gen_snark_shplonk runs: two commitments for all rotation sets.  The verifier's side,
+    from the proof's commitments and evaluations and the challenges:
+        sum_S v^(m-1-s) Z_{T - S}(u) (C_S - [r_S(u)] G) - Z_T(u) W1 == [tau - u] W2,   C_S = the set's commitments combined with yo"""
+    from halo2_vectordb_amd.rounds import quotient_identity_holds
+    hp, pr = circuit
+    out = pr.prove(None, seed=21)            # multiopen="shplonk" is the default
+    op, R = out["openings"], O.R_MOD
+    assert op["kind"] == "shplonk" and all(r == 0 for r in op["remainders"]) and len(op["remainders"]) >= 2
+    assert quotient_identity_holds(pr, out["challenges"], out["evals"])
+    assert len(out["proof"]) % 32 == 0
+    to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
+    yo, v, u = (to_int(out["challenges"][n]) for n in ("yo", "v", "u"))
+    pts = out["points"]
+    sets = op["sets"]
+    m = len(sets)
+    assert sorted(len(rots) for rots, _ in sets) == [1, 2, 2, 3, 4]     # fixed & h; pa; zl; zp; advice
+    all_rots = sorted({rot for rots, _ in sets for rot in rots})
+    def vanish(rots, x):
+        acc = 1
+        for rot in rots:
+            acc = acc * (x - pts[rot]) % R
+        return acc
+    scalars, bases, g_scalar = [], [], 0
+    for s_i, (rots, names) in enumerate(sets):
+        commits = np.concatenate([out["commitments"][name] for name in names])
+        k_cols = commits.shape[0]
+        vals = []
+        for rot in rots:
+            acc = 0
+            for name in names:
+                for e in out["evals"][(name, rot)]:
+                    acc = (acc * yo + e) % R
+            vals.append(acc)
+        r = _interpolate([pts[rot] for rot in rots], vals, R)
+        r_u = 0
+        for c in reversed(r):
+            r_u = (r_u * u + c) % R
+        coef = pow(v, m - 1 - s_i, R) * vanish([rot for rot in all_rots if rot not in rots], u) % R
+        scalars += [coef * pow(yo, k_cols - 1 - i, R) % R for i in range(k_cols)]
+        bases.append(commits)
+        g_scalar = (g_scalar - coef * r_u) % R
+    scalars += [g_scalar, (-vanish(all_rots, u)) % R]
+    bases += [O.g1_generator().reshape(1, 8), op["W1"].reshape(1, 8)]
+    lhs = O.msm_naive(O.fr_from_ints(scalars), np.concatenate(bases))
+    rhs = O.msm_naive(O.fr_from_ints([(TAU - u) % R]), op["W2"].reshape(1, 8))
+    assert np.array_equal(lhs, rhs) and lhs.any()
+    # a wrong evaluation in the proof breaks the equation
+    bad = (g_scalar + 1) % R
+    lhs_bad = O.msm_naive(O.fr_from_ints(scalars[:-2] + [bad, scalars[-1]]), np.concatenate(bases))
+    assert not np.array_equal(lhs_bad, rhs)

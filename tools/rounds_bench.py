@@ -21,9 +21,9 @@ hp = KmeansHotPath(I=I).setup()
 pr = ProverRounds(hp).keygen()
 t_setup = time.time() - t0
 rng = np.random.default_rng(1)
-raw = rng.integers(1, 1 << 62, size=(5, 4), dtype=np.uint64)
+raw = rng.integers(1, 1 << 62, size=(7, 4), dtype=np.uint64)
 raw[:, 3] &= np.uint64((1 << 60) - 1)
-ch = dict(zip(("beta", "gamma", "y", "x", "v"), raw))
+ch = dict(zip(("beta", "gamma", "y", "x", "v", "yo", "u"), raw))
 best = None
 for it in range(2):
     T = {}

@@ -67,7 +67,7 @@ _SIGNATURES = {
     "vdb_layout_lookup_dev": [_P, _U64, _U32, _U32, _P, _U64, _P, _U32],
     "vdb_layout_columns_range_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _P, _U32],
     "vdb_layout_lookup_range_dev": [_P, _U64, _U32, _U32, _U64, _U64, _P, _P, _U32], "vdb_wit_set_window": [_U64, _U64, _U64, _U64],
-    "vdb_srs_load": [_U32, _P, _P, _P], "vdb_srs_load_window": [_U32, _P, _P, _U32, _P], "vdb_srs_setup_unsafe": [_U32, _P, _P, _P], "vdb_srs_free": [_P], "vdb_srs_info": [_P, _P, _P, _P],
+    "vdb_g1_sum": [_P, _SZ, _SZ, _P], "vdb_srs_load": [_U32, _P, _P, _P], "vdb_srs_load_window": [_U32, _P, _P, _U32, _P], "vdb_srs_setup_unsafe": [_U32, _P, _P, _P], "vdb_srs_free": [_P], "vdb_srs_info": [_P, _P, _P, _P],
     "vdb_msm": [_P, _I, _P, _SZ, _P], "vdb_msm_batch": [_P, _I, _P, _SZ, _SZ, _P], "vdb_msm_batch_dev": [_P, _I, _P, _SZ, _SZ, _P],
     "vdb_msm_batch_masked_dev": [_P, _I, _P, _SZ, _SZ, _P, _P, _P], "vdb_layout_const_mask_dev": [_P, _U64, _P, _U64, _U32, _P],
     "vdb_mask_select_dev": [_P, _P, _U64, _I, _P],

@@ -673,6 +673,16 @@ __global__ __launch_bounds__(64) void k_srs_setup(u256 tau, u256 omega, u256 tn_
   }
 }
 
+// out[c] = sum_m parts[m][c]: the combine step of a point-sharded MSM (each rank commits its slice of the rows of every
+// column; the partial commitments are gathered and added — SURVEY §8e "alternative")
+__global__ __launch_bounds__(64) void k_g1_sum(const Affine* __restrict__ parts, uint32_t m, uint64_t n, Affine* __restrict__ out) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  XYZZ acc = xyzz_identity();
+  for (uint32_t i = 0; i < m; i++) xyzz_add_mixed(acc, ld_affine(parts + (uint64_t)i * n + c), false);
+  st_affine(out + c, xyzz_to_affine(acc));
+}
+
 static uint32_t pick_window(uint32_t k) {
   const char* env = getenv("VDB_MSM_C");
   if (env) {
@@ -891,6 +901,23 @@ int vdb_srs_load_window(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, u
     VDB_HIP(hipStreamSynchronize(cx.stream));
   }
   *out = s;
+  return VDB_OK;
+}
+int vdb_g1_sum(const vdb_g1* parts, size_t m, size_t n, vdb_g1* out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(parts && out && m >= 1 && m <= 0xffffffffull, "bad argument");
+  if (n == 0) return VDB_OK;
+  Context& cx = ctx();
+  Affine* d = (Affine*)scratch_get(0, (m + 1) * n * sizeof(Affine));
+  if (!d) return VDB_ERR_OOM;
+  VDB_HIP(hipMemcpyAsync(d, parts, m * n * sizeof(Affine), hipMemcpyHostToDevice, cx.stream));
+  {
+    VDB_PROF("k_g1_sum");
+    hipLaunchKernelGGL(k_g1_sum, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, cx.stream, d, (uint32_t)m, (uint64_t)n, d + m * n);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(out, d + m * n, n * sizeof(Affine), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
   return VDB_OK;
 }
 void vdb_srs_free(vdb_srs* s) {

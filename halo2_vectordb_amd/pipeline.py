@@ -97,6 +97,53 @@ def gather_commitments(dist, local, shards, device):
     return np.concatenate(adv + lk)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The alternative partition of SURVEY §8(e): ONE set of columns, the POINTS (rows) split over the ranks.  Only of use when
+# there are fewer columns than GPUs (never at the BASELINE configs, where columns are sharded instead); it is what
+# BASELINE.json's "all-reduce only for the final bucket reduction" describes.  RCCL has no curve reduction operator: the
+# exchange is an all_gather of the per-rank partial commitments (64 B per column and rank) followed by world - 1 group
+# additions per column on every rank (vdb_g1_sum) — exact and order independent after the affine normalisation.
+def point_shard(rows, rank, world):
+    return rows * rank // world, rows * (rank + 1) // world
+
+
+def point_sharded_partials(srs_shard, cols_dev, n_cols, rows, lo, hi):
+    """Commitments of rows [lo, hi) of n_cols device-resident columns (stride `rows`) against an Srs that holds exactly the
+    bases of those rows: (n_cols, 8)."""
+    lib = srs_shard.L
+    desc = np.zeros((n_cols, 3), dtype=np.uint64)                    # vdb_colsrc {src, len, blind}
+    base = cols_dev.ptr.value if hasattr(cols_dev, "ptr") else int(cols_dev)
+    desc[:, 0] = base + (np.arange(n_cols, dtype=np.uint64) * np.uint64(rows) + np.uint64(lo)) * np.uint64(32)
+    desc[:, 1] = hi - lo
+    d_src = api.DeviceBuffer(desc.nbytes)
+    d_src.upload(desc)
+    out = np.zeros((n_cols, 8), dtype=np.uint64)
+    try:
+        check(lib.vdb_msm_batch_src_dev_begin(srs_shard.h, 1, d_src.ptr, ctypes.c_size_t(n_cols), ctypes.c_size_t(hi - lo), 0, None, None))
+        check(lib.vdb_msm_batch_end(api._p(out), ctypes.c_size_t(n_cols)))
+    finally:
+        d_src.free()
+    return out
+
+
+def combine_partials(parts):
+    """(world, n_cols, 8) partial commitments -> (n_cols, 8): the group sum per column (on the device)."""
+    parts = np.ascontiguousarray(parts, dtype=np.uint64)
+    world, n_cols = parts.shape[0], parts.shape[1]
+    out = np.zeros((n_cols, 8), dtype=np.uint64)
+    check(api._lib.init().vdb_g1_sum(api._p(parts), ctypes.c_size_t(world), ctypes.c_size_t(n_cols), api._p(out)))
+    return out
+
+
+def allgather_partials(dist, local, device):
+    """all_gather of every rank's (n_cols, 8) partial commitments -> (world, n_cols, 8) on the host"""
+    import torch
+    mine = torch.from_numpy(np.ascontiguousarray(local).view(np.int64)).to(device)
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    return np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
+
+
 class KmeansHotPath:
     """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
 

@@ -187,6 +187,10 @@ int vdb_srs_load_window(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, u
  * gen_srs(k) (src/scaffold/mod.rs:260-261: "unsafe" message); tau is a Montgomery Fr.  Test/bench SRS. */
 int vdb_srs_setup_unsafe(uint32_t k, const vdb_fr *tau, vdb_g1 *g_out, vdb_g1 *g_lagrange_out);
 void vdb_srs_free(vdb_srs *srs);
+/* out[c] = parts[0][c] + ... + parts[m-1][c] in G1 (host arrays, m x n and n affine points; the identity is (0, 0)): the
+ * combine step of a point-sharded MSM — each GPU commits its slice of the rows of every column against the matching slice of
+ * the bases, the partial commitments are all-gathered and added.  RCCL has no curve reduction operator. */
+int vdb_g1_sum(const vdb_g1 *parts, size_t m, size_t n, vdb_g1 *out);
 int vdb_srs_info(const vdb_srs *srs, uint32_t *k, uint32_t *window_bits, uint32_t *windows);
 
 /* ---- b2 MSM: replaces halo2 arithmetic::best_multiexp(&[Fr], &[G1Affine]) -> G1 and

@@ -75,3 +75,38 @@ def test_balanced_shards_partition_and_balance():
     spans = balanced_ranges(cost, 4)
     sums = [cost[a:b].sum() for a, b in spans]
     assert max(sums) - min(sums) <= 3.0 + 1e-9
+
+
+def _partials_worker(rank, world, port, n_cols, q):
+    import torch.distributed as dist
+    from halo2_vectordb_amd.pipeline import allgather_partials, point_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = (np.arange(n_cols * 8, dtype=np.uint64).reshape(n_cols, 8) + np.uint64(1000 * rank)) * np.uint64(0x9E3779B97F4A7C15)
+    parts = allgather_partials(dist, local, "cpu")
+    q.put((rank, point_shard(1 << 16, rank, world), parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_point_sharded_partials_allgather_world2():
+    """the exchange step of the point-sharded MSM (the alternative partition): every rank ends up with all ranks'
+    partial commitments in rank order; the row slices partition the rows.  (The group sums are GPU work: tests/test_gpu_msm.py.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_partials_worker, args=(r, 2, port, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([(np.arange(24, dtype=np.uint64).reshape(3, 8) + np.uint64(1000 * r)) * np.uint64(0x9E3779B97F4A7C15) for r in range(2)])
+    assert all(np.array_equal(parts, want) for _, _, parts in res)
+    assert [sl for _, sl, _ in res] == [(0, 1 << 15), (1 << 15, 1 << 16)]

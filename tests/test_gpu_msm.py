@@ -148,3 +148,37 @@ def test_srs_setup_unsafe(api, O):
     g, gl = api.srs_setup_unsafe(k, O.fr_from_ints([tau])[0])
     wg, wgl = O.srs_from_tau(k, tau)
     assert np.array_equal(g, wg) and np.array_equal(gl, wgl)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_point_sharded_msm_combines_to_the_whole_commitment(O, world):
+    """SURVEY §8(e), the alternative partition: the rows of every column split over `world` ranks (emulated one after the
+    other), each committing its slice against the matching slice of the bases; the partial commitments added per column
+    (vdb_g1_sum) are the whole commitments.  Three columns (fewer than ranks at world = 8: the case the partition is for),
+    one of them all zero (identity partials)."""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.pipeline import combine_partials, point_shard, point_sharded_partials
+    api.init(0)
+    k, n_cols = 10, 3
+    rows = 1 << k
+    rng = np.random.default_rng(88 + world)
+    _, gl = O.srs_from_tau(k, 0xFACE)
+    cols = O.random_fr(rng, n_cols * rows).reshape(n_cols, rows, 4)
+    cols[1] = 0
+    cols[2, : rows // 2] = 0            # ranks whose slice is all zero return the identity
+    want = O.msm_batch(cols, gl)
+    d = api.DeviceBuffer(cols.nbytes)
+    d.upload(cols)
+    parts = []
+    for rank in range(world):
+        lo, hi = point_shard(rows, rank, world)
+        srs = api.Srs(k - int(np.log2(world)), None, gl[lo:hi])
+        parts.append(point_sharded_partials(srs, d, n_cols, rows, lo, hi))
+        srs.free()
+    d.free()
+    parts = np.stack(parts)
+    assert not parts[:, 1].any() and not parts[0, 2].any()
+    got = combine_partials(parts)
+    assert np.array_equal(got, want) and not got[1].any()
+    # the sum is order independent
+    assert np.array_equal(combine_partials(parts[::-1]), want)

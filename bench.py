@@ -56,6 +56,16 @@ def pmc_traffic_per_launch(kernel):
     return (2.0 * fetch / nf + write / nw) * 1024.0, os.path.basename(files[-1])
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(hp, cols_sample, commitments_sample):
     """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload."""
     from oracle import oracle as O  # test infrastructure: allowed here as the cpu_baseline leg only
@@ -82,7 +92,7 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     total_cells = hp.n_cells + hp.n_lookup
     t_full = t_wit * hp.I + (t_msm + t_ntt) * hp.n_cols / ns
     return {
-        "value": total_cells / t_full, "unit": "constraints/s", "cores": cores, "kind": "port",
+        "value": total_cells / t_full, "unit": "constraints/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
         "sample": (f"oracle C restatement: 1 of {hp.I} k-means iterations of witness gen single-threaded ({t_wit:.2f} s, "
                    f"{cells_one_iter} cells), Pippenger MSM + iNTT/coset-NTT of {ns} of {hp.n_cols} real columns on {cores} threads "
                    f"({t_msm:.2f} s + {t_ntt:.2f} s), extrapolated linearly to the full job"),

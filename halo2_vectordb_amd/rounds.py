@@ -160,6 +160,10 @@ class ProverRounds:
         d_l.upload(lag)
         self._fixed_poly("lag", d_l, 3)
         api.sync()
+        return self._alloc_working_set()
+
+    def _alloc_working_set(self):
+        lib, rows = self.lib, self.rows
         # the working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
         # [pa | ps | zp | zl] in Lagrange / coefficient form, their extended cosets, a block of fixed cosets, h.  The
         # Lagrange image of the advice columns is dead before the derived cosets exist and shares their memory.  The
@@ -172,6 +176,48 @@ class ProverRounds:
         self.d_h = api.DeviceBuffer(self.ne * B)
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         return self
+
+    # ------------------------------------------------------------------ the proving key on disk
+    def save_proving_key(self, path):
+        """What the reference's Keygen arm leaves for the Prove arm (src/scaffold/mod.rs:272-281: pinning + pk), in this
+        build's own container: an .npz (numpy.load with allow_pickle=False reads it) holding the circuit's shape, the break
+        points, and per fixed polynomial — gate selectors, sigma columns, range table, Lagrange selectors — its coefficient
+        form and its commitments.  Upstream's pk file format (SerdeFormat::RawBytes) is not reproduced: parity unpinned."""
+        api.sync()
+        doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, CHUNK_LEN, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
+        for name, q in self.fixed.items():
+            doc[name + "_coeff"] = q.coeff.download((q.n_cols, self.rows, 4))
+            doc[name + "_commits"] = q.commits
+        np.savez(path, **doc)
+
+    def load_proving_key(self, path):
+        """The Prove arm's side: the fixed polynomials from a file written by save_proving_key instead of a keygen run (no
+        flag-recording witness pass, no permutation construction).  The Lagrange forms the rounds read (sigma, table) are
+        recovered with a forward transform; raises ValueError when the file describes another circuit."""
+        hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
+        with np.load(path, allow_pickle=False) as doc:
+            meta = [int(v) for v in doc["meta"]]
+            if meta != [k, self.n_adv, self.n_lk, hp.L, CHUNK_LEN, N_BLIND] or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
+                raise ValueError("proving key does not describe this circuit (shape or break points differ)")
+            self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
+            self.srs_few = api.Srs(k, hp.g_monomial, None)
+            omega = api.root_of_unity(k)
+            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("sigma", self.n_cols, True, False), ("table", 1, True, True),
+                                                     ("lag", 3, False, True)):
+                coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
+                if coeff_h.shape != (n_cols, rows, 4):
+                    raise ValueError("proving key: wrong shape for " + name)
+                coeff = api.DeviceBuffer(coeff_h.nbytes)
+                coeff.upload(coeff_h)
+                lag = None
+                if need_lag:
+                    lag = api.DeviceBuffer(coeff_h.nbytes)
+                    check(lib.vdb_memcpy_d2d(lag.ptr, coeff.ptr, _sz(coeff_h.nbytes)))
+                    check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
+                self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None,
+                                         commits=np.ascontiguousarray(doc[name + "_commits"]))
+        api.sync()
+        return self._alloc_working_set()
 
     # ------------------------------------------------------------------ the rounds
     def prove(self, challenges=None, seed=1, timings=None, multiopen="shplonk"):

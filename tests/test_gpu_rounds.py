@@ -311,3 +311,27 @@ def test_shplonk_multiopen_verifies_in_the_exponent(circuit, O):
     bad = (g_scalar + 1) % R
     lhs_bad = O.msm_naive(O.fr_from_ints(scalars[:-2] + [bad, scalars[-1]]), np.concatenate(bases))
     assert not np.array_equal(lhs_bad, rhs)
+
+
+def test_proving_key_round_trip_gives_the_same_proof(circuit, tmp_path):
+    """Keygen arm -> file -> Prove arm: a second ProverRounds that never ran keygen, loaded from the saved proving key,
+    produces byte-identical proofs; a key for another circuit is refused"""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    hp, pr = circuit
+    path = tmp_path / "kmeans.pk.npz"
+    pr.save_proving_key(path)
+    want = pr.prove(None, seed=77)["proof"]
+    pr2 = ProverRounds(hp).load_proving_key(path)
+    try:
+        assert all(np.array_equal(pr2.fixed[name].commits, pr.fixed[name].commits) for name in pr.fixed)
+        got = pr2.prove(None, seed=77)["proof"]
+        assert got == want and len(got) > 0
+    finally:
+        pr2.free()
+    other = KmeansHotPath(n=8, dim=4, K=2, I=1, k=11, L=9, tau=TAU).setup()      # another lookup width: another circuit
+    try:
+        with pytest.raises(ValueError):
+            ProverRounds(other).load_proving_key(path)
+    finally:
+        other.free()

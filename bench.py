@@ -198,6 +198,15 @@ def main():
         try:
             mul_rate = api.bench_fr_mul()
             roofline["valu"] = {"fr_mul_per_s_microbench": mul_rate}
+            if name == "k_ntt_pass":
+                # field products the two transforms of one column need: butterflies with a non-trivial
+                # twiddle plus the inter-pass / coset / 1/n products, over all launches of the step
+                k, e = hp.k, 2
+                per_col = (n // 2) * (k - 1) + n + (2 * n) // 3 + (4 * n // 2) * (k + e - 2) + 4 * n
+                rate = per_col * hp.my_cols / (rec["ms"] * 1e-3)
+                roofline["valu"].update({"kernel_fr_mul_per_s": rate, "frac_of_microbench": rate / mul_rate,
+                                         "note": "products the NTT makes per second against the library's own field-product microbenchmark "
+                                                 "(vdb_bench_fr_mul, measured in this run): the bound that applies to this kernel"})
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:

@@ -64,8 +64,9 @@ class _Poly:
 
     def free(self):
         for b in (self.lag, self.coeff, self.ext):
-            if b is not None and getattr(b, "_owned", True):
+            if b is not None:
                 b.free()
+        self.lag = self.coeff = self.ext = None
 
 
 class ProverRounds:

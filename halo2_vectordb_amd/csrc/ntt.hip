@@ -501,7 +501,6 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       uint32_t G = 1u << p.logG;
       uint32_t tiles = (uint32_t)(n / ((uint64_t)m * G));
       size_t lds = (size_t)(G * (m + 1) + (m / 2 ? m / 2 : 1)) * (2 * sizeof(uint4) + sizeof(uint32_t));
-      if (const char* padenv = getenv("VDB_NTT_LDS_PAD")) lds += (size_t)atoi(padenv);   // EXPERIMENT ONLY
       dim3 grid((unsigned)(nc * tiles));
       if (lds > 64 * 1024) {
         static bool raised = false;

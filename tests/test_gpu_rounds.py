@@ -307,6 +307,14 @@ def test_shplonk_multiopen_verifies_in_the_exponent(circuit, O):
     lhs = O.msm_naive(O.fr_from_ints(scalars), np.concatenate(bases))
     rhs = O.msm_naive(O.fr_from_ints([(TAU - u) % R]), op["W2"].reshape(1, 8))
     assert np.array_equal(lhs, rhs) and lhs.any()
+    # the same statement the way a verifier checks it, without the toxic scalar: e(C_L + [u] W2, H) e(-W2, [tau] H) == 1 with
+    # [tau] H from the G2 side of the SRS (oracle/pairing.py)
+    from oracle import pairing as PR
+    to_pt = lambda a: None if not np.asarray(a).any() else tuple(O.fq_to_ints(np.asarray(a).reshape(2, 4)))
+    left = O.msm_naive(O.fr_from_ints(scalars + [u]), np.concatenate(bases + [op["W2"].reshape(1, 8)]))
+    tau_h = PR.pt_mul(PR.G2, TAU)
+    assert PR.pairing_product_is_one([(to_pt(left), PR.G2), (PR.pt_neg(to_pt(op["W2"])), tau_h)])
+    assert not PR.pairing_product_is_one([(to_pt(left), PR.G2), (PR.pt_neg(to_pt(op["W1"])), tau_h)])
     # a wrong evaluation in the proof breaks the equation
     bad = (g_scalar + 1) % R
     lhs_bad = O.msm_naive(O.fr_from_ints(scalars[:-2] + [bad, scalars[-1]]), np.concatenate(bases))

@@ -142,3 +142,19 @@ def test_prover_round_primitives_against_python(O):
     x = int(rng.integers(1, 1 << 62)) ** 3 % R
     got = O.eval_polys(O.fr_from_ints(num_i).reshape(1, n, 4), O.fr_from_ints([x])[0])
     assert O.fr_to_ints(got) == [sum(c * pow(x, i, R) for i, c in enumerate(num_i)) % R]
+
+
+def test_pairing_self_checks():
+    """oracle/pairing.py (test infrastructure for the verifier-side checks): the G2 generator lies on the twist and has order r,
+    the pairing is bilinear and non-degenerate"""
+    from oracle import pairing as PR
+    assert PR.on_twist(PR.G2)
+    assert PR.pt_mul(PR.G2, PR.R) is None and PR.pt_mul(PR.G1, PR.R) is None
+    a, b = 0x1234567, 0xABCDEF0123
+    aP, bQ = PR.pt_mul(PR.G1, a), PR.pt_mul(PR.G2, b)
+    assert PR.on_twist(bQ)
+    # e(aP, Q) e(-P, aQ) = 1;  e(aP, bQ) e(-abP, Q) = 1;  e(P, Q) != 1
+    assert PR.pairing_product_is_one([(aP, PR.G2), (PR.pt_neg(PR.G1), PR.pt_mul(PR.G2, a))])
+    assert PR.pairing_product_is_one([(aP, bQ), (PR.pt_neg(PR.pt_mul(PR.G1, a * b % PR.R)), PR.G2)])
+    assert not PR.pairing_product_is_one([(PR.G1, PR.G2)])
+    assert not PR.pairing_product_is_one([(aP, bQ), (PR.pt_neg(PR.pt_mul(PR.G1, a * b + 1)), PR.G2)])

@@ -343,3 +343,128 @@ def test_proving_key_round_trip_gives_the_same_proof(circuit, tmp_path):
             ProverRounds(other).load_proving_key(path)
     finally:
         other.free()
+
+
+def _verify(O, api, proof, vk):
+    """A verifier for the proofs ProverRounds.prove(None) writes (SHPLONK): knows the proof bytes and a verifying key — the
+    circuit's shape, the fixed commitments, [tau] H — and nothing else.  Replays the transcript, checks the quotient identity
+    and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
+    from oracle import pairing as PR
+    R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+              "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
+    pos = 0
+    tr = api.Transcript()
+    try:
+        def points(m):
+            nonlocal pos
+            pts = []
+            for _ in range(m):
+                if pos + 32 > len(proof):
+                    raise ValueError
+                try:
+                    pts.append(_decompress(O, proof[pos: pos + 32]))
+                except AssertionError:
+                    raise ValueError
+                pos += 32
+                tr.common_point(pts[-1])
+            return np.stack(pts) if pts else np.zeros((0, 8), dtype=np.uint64)
+        for name in ("sel", "sigma", "table", "lag"):
+            for pt in vk["fixed"][name]:
+                tr.common_point(pt)
+        C = dict(vk["fixed"])
+        C["adv"] = points(counts["adv"])
+        ch = {"theta": tr.squeeze()}
+        pairs = points(2 * meta["n_lk"])
+        C["pa"], C["ps"] = pairs[0::2], pairs[1::2]
+        ch["beta"], ch["gamma"] = tr.squeeze(), tr.squeeze()
+        C["zp"], C["zl"] = points(counts["zp"]), points(counts["zl"])
+        ch["y"] = tr.squeeze()
+        C["h"] = points(4)
+        ch["x"] = tr.squeeze()
+        evals = {}
+        for rot, names in opened.items():
+            for name in names:
+                vals = []
+                for _ in range(counts[name]):
+                    e = int.from_bytes(proof[pos: pos + 32], "little")
+                    if pos + 32 > len(proof) or e >= R:
+                        raise ValueError
+                    pos += 32
+                    tr.common_scalar(O.fr_from_ints([e])[0])
+                    vals.append(e)
+                evals[(name, rot)] = vals
+        ch["yo"], ch["v"] = tr.squeeze(), tr.squeeze()
+        W1 = points(1)[0]
+        ch["u"] = tr.squeeze()
+        W2 = points(1)[0]
+        if pos != len(proof):
+            raise ValueError
+    except ValueError:
+        return False
+    finally:
+        tr.free()
+    if not check_quotient_identity(O, meta, ch, evals):
+        return False
+    to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
+    x, yo, v, u = (to_int(ch[n]) for n in ("x", "yo", "v", "u"))
+    w = to_int(O.root_of_unity(meta["k"]))
+    pts = {rot: x * pow(w, rot % meta["rows"], R) % R for rot in opened}
+    by_poly = {}
+    for rot, names in opened.items():
+        for name in names:
+            by_poly.setdefault(name, []).append(rot)
+    sets = []
+    for name, rots in by_poly.items():
+        key = tuple(sorted(rots))
+        for sset in sets:
+            if sset[0] == key:
+                sset[1].append(name)
+                break
+        else:
+            sets.append((key, [name]))
+    all_rots = sorted({rot for rots, _ in sets for rot in rots})
+    def vanish(rots, at):
+        acc = 1
+        for rot in rots:
+            acc = acc * (at - pts[rot]) % R
+        return acc
+    m, scalars, bases, g_scalar = len(sets), [], [], 0
+    for s_i, (rots, names) in enumerate(sets):
+        commits = np.concatenate([C[name] for name in names])
+        vals = []
+        for rot in rots:
+            acc = 0
+            for name in names:
+                for e in evals[(name, rot)]:
+                    acc = (acc * yo + e) % R
+            vals.append(acc)
+        r_u = 0
+        for c in reversed(_interpolate([pts[rot] for rot in rots], vals, R)):
+            r_u = (r_u * u + c) % R
+        coef = pow(v, m - 1 - s_i, R) * vanish([rot for rot in all_rots if rot not in rots], u) % R
+        scalars += [coef * pow(yo, commits.shape[0] - 1 - i, R) % R for i in range(commits.shape[0])]
+        bases.append(commits)
+        g_scalar = (g_scalar - coef * r_u) % R
+    scalars += [g_scalar, (-vanish(all_rots, u)) % R, u]
+    bases += [O.g1_generator().reshape(1, 8), W1.reshape(1, 8), W2.reshape(1, 8)]
+    left = O.msm_naive(O.fr_from_ints(scalars), np.concatenate(bases))
+    to_pt = lambda a: None if not np.asarray(a).any() else tuple(O.fq_to_ints(np.asarray(a).reshape(2, 4)))
+    return PR.pairing_product_is_one([(to_pt(left), PR.G2), (PR.pt_neg(to_pt(W2)), vk["tau_h"])])
+
+
+def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O):
+    from halo2_vectordb_amd import api
+    from oracle import pairing as PR
+    hp, pr = circuit
+    out = pr.prove(None, seed=31)
+    vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+              tau_h=PR.pt_mul(PR.G2, TAU))
+    proof = out["proof"]
+    assert _verify(O, api, proof, vk)
+    n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 4
+    for where in (5, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 64 + 7, len(proof) - 20):    # a commitment, h, an evaluation, W1, W2
+        bad = bytearray(proof)
+        bad[where] ^= 4
+        assert not _verify(O, api, bytes(bad), vk)
+    assert not _verify(O, api, proof[:-32], vk) and not _verify(O, api, proof + bytes(32), vk)

@@ -242,6 +242,13 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
         assert check_quotient_identity(O, meta, out["challenges"], out["evals"])
         v = O.fr_to_ints(out["challenges"]["v"].reshape(1, 4))[0]
         assert check_openings(O, v, out["commitments"], out["evals"], out["openings"])
+        # and the SHPLONK proof bytes through the stand-alone verifier (defined below)
+        from halo2_vectordb_amd import api
+        from oracle import pairing as PR
+        out2 = pr.prove(None, seed=4)
+        vk = dict(meta=_meta(pr), opened=out2["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+                  tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out2["proof"], vk)
     finally:
         pr.free()
         hp.free()

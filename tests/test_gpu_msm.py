@@ -182,3 +182,21 @@ def test_point_sharded_msm_combines_to_the_whole_commitment(O, world):
     assert np.array_equal(got, want) and not got[1].any()
     # the sum is order independent
     assert np.array_equal(combine_partials(parts[::-1]), want)
+
+
+def test_g1_sum_exceptional_cases(O, PY):
+    """vdb_g1_sum on the cases a generic addition formula gets wrong: equal summands (doubling), opposite summands (identity),
+    identities among the summands, one summand only"""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.pipeline import combine_partials
+    api.init(0)
+    P5, P7 = O.g1_mul_generator([5, 7])
+    neg = lambda p: O.fq_from_ints([O.fq_to_ints(p.reshape(2, 4))[0], (-O.fq_to_ints(p.reshape(2, 4))[1]) % PY.Q]).reshape(8)
+    zero = np.zeros(8, dtype=np.uint64)
+    parts = np.stack([np.stack([P5, P5, zero, P5, zero]),
+                      np.stack([P5, neg(P5), zero, zero, P7]),
+                      np.stack([P5, zero, zero, P7, neg(P7)])])            # (3 ranks, 5 columns)
+    got = combine_partials(parts)
+    want = O.g1_mul_generator([15, 0, 0, 12, 0])
+    assert np.array_equal(got, want)
+    assert np.array_equal(combine_partials(parts[:1]), parts[0])

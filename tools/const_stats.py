@@ -1,13 +1,15 @@
+#!/usr/bin/env python3
+"""Keygen statistic: share of constant cells and of their MSM digits in a distance witness."""
 import sys, numpy as np
 sys.path.insert(0,'.')
 from halo2_vectordb_amd import api
-from oracle import oracle as O
 api.init()
 rng=np.random.default_rng(20260004)
 a=api.quantize(rng.integers(0,219,(4,128)).astype(float)); b=api.quantize(rng.integers(0,219,(4,128)).astype(float))
 g=api.wit_distance('euclidean',a,b,L=15,selectors=True)
-R=O.R_MOD
-vals=O.limbs_to_ints(O.fr_to_canonical(g['stream']))
+R=0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+canon=api.fr_to_canonical(g['stream'])
+vals=[sum(int(r[i])<<(64*i) for i in range(4)) for r in canon]
 m=g['const_mask'].astype(bool)
 fold=np.array([min(v,R-v) for v in vals],dtype=object)
 def digits(v,c=11):

@@ -1,0 +1,219 @@
+"""The Merkle circuit's own copy constraints (what keygen feeds the permutation argument beyond the cells
+the column layout duplicates): for every cell of the Poseidon trace that `merkle_commitment` emits
+(/root/reference/src/gadget/vectordb.rs:165-223 through PoseidonChip<F, 3, 2>), the earlier cell it is a copy of.
+
+The trace is data independent, so the map is built symbolically on the host from the cell templates of the halo2-base
+primitives the permutation is made of — GateChip::sum, inner_product with constants, mul, mul_add — in exactly the order
+halo2_vectordb_amd/csrc/witness.hip (trace_permutation) emits them, and instantiated per permutation with numpy.  The
+builder consumes the gate / constant flag bytes of one real permutation (a keygen-style run) both to resolve the one
+structural choice that depends on the spec's constants (inner_product starts with the first operand itself when its
+constant is one) and as a check: every gate-start bit and every constant bit of the template must equal the kernel's.
+tests/test_gpu_rounds.py additionally checks the map against witness values: every cell equals the cell it copies.
+
+Not covered: ties of constant cells to a fixed column (constants stay flagged, untied), and the leaves' message words,
+which the reference assigns before the gadget runs (they are free cells here).  [UPSTREAM-RECALL] for the primitives'
+cell templates, as for the kernels themselves."""
+import numpy as np
+
+T, RATE, R_F, R_P = 3, 2, 8, 57
+HALF = R_F // 2
+SELF, CONST = -1, -2          # template codes; >= 0: offset inside the block; state input i: -10 - i; message input i: -20 - i
+
+
+class _Tracer:
+    """symbolic WCtx: records per cell (source code, gate bit, constant bit)"""
+
+    def __init__(self, flags):
+        self.src, self.gate, self.cst, self.flags = [], [], [], flags
+
+    def push(self, src, gate, cst=False):
+        pos = len(self.src)
+        self.src.append(CONST if cst else (SELF if src is None else src))
+        self.gate.append(bool(gate))
+        self.cst.append(bool(cst))
+        return pos
+
+    def next_is_const(self):
+        return bool(self.flags[len(self.src)] & 2)
+
+    # GateChip::sum: v0, then (v_i, 1, s_i); `cmask` bit i: v_i is a constant
+    def sum(self, v, cmask):
+        self.push(v[0], len(v) > 1, bool(cmask & 1))
+        out = None
+        for i in range(1, len(v)):
+            self.push(v[i], False, bool((cmask >> i) & 1))
+            self.push(None, False, True)
+            out = self.push(None, i + 1 < len(v))
+        return out
+
+    # inner_product(a, constants): starts with a_0 itself when the first constant is one, with a constant zero otherwise
+    def ip_const(self, a):
+        n = len(a)
+        if self.next_is_const():
+            self.push(None, True, True)
+            i0, ng = 0, n
+        else:
+            self.push(a[0], n - 1 > 0)
+            i0, ng = 1, n - 1
+        out, gi = None, 1
+        for i in range(i0, n):
+            self.push(a[i], False)
+            self.push(None, False, True)
+            out = self.push(None, gi < ng)
+            gi += 1
+        return out
+
+    def mul(self, a, b):                       # [0, a, b, out]
+        self.push(None, True, True)
+        self.push(a, False)
+        self.push(b, False)
+        return self.push(None, False)
+
+    def sbox(self, x):                         # x^5 + c: mul(x, x), mul(x2, x2), mul_add(x, x4, c) = [c, x, x4, out]
+        x2 = self.mul(x, x)
+        x4 = self.mul(x2, x2)
+        self.push(None, True, True)
+        self.push(x, False)
+        self.push(x4, False)
+        return self.push(None, False)
+
+    def dense(self, st):
+        return [self.ip_const(st) for _ in range(T)]
+
+
+def permutation_template(flags, n_in):
+    """(src codes, final state offsets) of one PoseidonChip::permutation absorbing n_in message words; `flags`: the kernel's
+    flag bytes of one such permutation (bit 0 gate start, bit 1 constant)."""
+    t = _Tracer(flags)
+    st = [-10 - i for i in range(T)]
+    st[0] = t.sum([st[0], None], 0b10)
+    for i in range(n_in):
+        st[1 + i] = t.sum([st[1 + i], -20 - i, None], 0b100)
+    for i in range(n_in + 1, T):
+        st[i] = t.sum([st[i], None], 0b10)
+    for _ in range(1, HALF):
+        st = t.dense([t.sbox(x) for x in st])
+    st = t.dense([t.sbox(x) for x in st])                       # last of the first full rounds, then the pre-sparse matrix
+    for _ in range(R_P):
+        s0 = t.sbox(st[0])
+        cur = [s0, st[1], st[2]]
+        nxt = [t.ip_const(cur)]
+        for i in range(1, T):                                   # mul_add(s0, e, s_i) = [s_i, s0, e, out]
+            t.push(cur[i], True)
+            t.push(s0, False)
+            t.push(None, False, True)
+            nxt.append(t.push(None, False))
+        st = nxt
+    for _ in range(HALF - 1):
+        st = t.dense([t.sbox(x) for x in st])
+    st = t.dense([t.sbox(x) for x in st])
+    n = len(t.src)
+    if n != len(flags):
+        raise ValueError(f"permutation template has {n} cells, the kernel emitted {len(flags)}")
+    gate = np.array(t.gate, dtype=bool)
+    cst = np.array(t.cst, dtype=bool)
+    f = np.asarray(flags)
+    if not (np.array_equal(gate, (f & 1).astype(bool)) and np.array_equal(cst, (f & 2).astype(bool))):
+        raise ValueError("permutation template disagrees with the kernel's gate / constant flags")
+    return np.array(t.src, dtype=np.int64), st
+
+
+def perm_cells(n_in):
+    return {2: 18, 1: 15, 0: 12}[n_in] + 2238
+
+
+def merkle_copy_map(n, dim, flags):
+    """copy_of[i] = stream offset of the cell that cell i copies (i itself for new cells, message words and constants) for
+    merkle_commitment over n vectors of `dim` words; `flags`: the flag bytes of a keygen-style run of the same circuit
+    (vdb_wit_merkle_dev with a selector buffer).  Also returns the stream offset of the root cell."""
+    flags = np.asarray(flags, dtype=np.uint8)
+    nperm = (dim + 1) // 2 + (1 if dim % 2 == 0 else 0)
+    n_ins = [max(0, min(2, dim - 2 * p)) for p in range(nperm)]
+    sizes = [perm_cells(k) for k in n_ins]
+    leaf_cells = sum(sizes)
+    lp = 1
+    while lp < n:
+        lp <<= 1
+    zero_cell = 1 if lp > n else 0
+    node_cells = perm_cells(2) + perm_cells(0)
+    total = n * leaf_cells + zero_cell + (lp - 1) * node_cells
+    if total != flags.size:
+        raise ValueError("flags do not belong to this circuit")
+    copy_of = np.arange(total, dtype=np.int64)
+    templates = {}
+
+    def template(n_in, at):
+        if n_in not in templates:
+            templates[n_in] = permutation_template(flags[at: at + perm_cells(n_in)], n_in)
+        return templates[n_in]
+
+    def place(bases, n_in, state_src, msg_src):
+        """instantiate the template at every offset in `bases`; state_src / msg_src: per input, array of source offsets (or
+        None: a free / constant-initialised cell)"""
+        src, fin = template(n_in, int(bases[0]))
+        idx = bases[:, None] + np.arange(src.size)[None, :]
+        val = np.where(src[None, :] >= 0, bases[:, None] + np.maximum(src, 0)[None, :], idx)
+        for i in range(T):
+            cols = np.flatnonzero(src == -10 - i)
+            if state_src[i] is not None and cols.size:
+                val[:, cols] = state_src[i][:, None]
+        for i in range(n_in):
+            cols = np.flatnonzero(src == -20 - i)
+            if msg_src[i] is not None and cols.size:
+                val[:, cols] = msg_src[i][:, None]
+        copy_of[idx.reshape(-1)] = val.reshape(-1)
+        return [bases + f for f in fin]
+
+    # leaves: the sponge state runs through the leaf's permutations; the first starts from the chip's initial state
+    leaf_base = np.arange(n, dtype=np.int64) * leaf_cells
+    state, off = [None] * T, 0
+    for p in range(nperm):
+        state = place(leaf_base + off, n_ins[p], state, [None] * n_ins[p])
+        off += sizes[p]
+    digest = np.full(lp, n * leaf_cells, dtype=np.int64)        # padding leaves: the load_zero cell after the leaves
+    digest[:n] = state[1]
+    # tree levels: absorb [left, right], then the padding-only permutation
+    pos, width = n * leaf_cells + zero_cell, lp
+    while width > 1:
+        half = width // 2
+        bases = pos + np.arange(half, dtype=np.int64) * node_cells
+        st1 = place(bases, 2, [None] * T, [digest[0:width:2], digest[1:width:2]])
+        st2 = place(bases + perm_cells(2), 0, st1, [])
+        digest = st2[1]
+        pos += half * node_cells
+        width = half
+    return copy_of, int(digest[0])
+
+
+def mapping_from_copy_of(copy_of, break_points, n_cols, rows):
+    """Permutation over an n_cols x rows grid (words col << 32 | row, the identity where nothing is tied) from a copy map
+    over the stream cells that fill the first len(break_points) + 1 columns: every set of cells that copy one another
+    (directly or through other copies) becomes one cycle, and the overlap cell that ends column c is the cell that starts
+    column c + 1."""
+    copy_of = np.asarray(copy_of, dtype=np.int64)
+    bp = np.asarray(break_points, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(bp)])
+    root = copy_of.copy()
+    while True:                                                 # pointer jumping: sources are always earlier cells
+        nxt = root[root]
+        if np.array_equal(nxt, root):
+            break
+        root = nxt
+    s = np.arange(copy_of.size, dtype=np.int64)
+    col = np.searchsorted(starts, s, side="right") - 1
+    row = s - starts[col]
+    # the overlap cell: stream offset starts[c + 1] also sits in column c at row bp[c]
+    dup_s = starts[1:][starts[1:] < copy_of.size]
+    dup_col = np.arange(dup_s.size, dtype=np.int64)
+    pos_col = np.concatenate([col, dup_col])
+    pos_row = np.concatenate([row, bp[: dup_s.size]])
+    pos_root = np.concatenate([root, root[dup_s]])
+    order = np.lexsort((pos_row, pos_col, pos_root))
+    pc, prw, pr = pos_col[order], pos_row[order], pos_root[order]
+    first = np.concatenate([[True], pr[1:] != pr[:-1]])
+    group_start = np.maximum.accumulate(np.where(first, np.arange(pr.size), 0))
+    last = np.concatenate([pr[1:] != pr[:-1], [True]])
+    nxt_idx = np.where(last, group_start, np.arange(pr.size) + 1)
+    mapping = (np.arange(n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
+    mapping[pc, prw] = (pc[nxt_idx].astype(np.uint64) << np.uint64(32)) | prw[nxt_idx].astype(np.uint64)
+    return mapping

@@ -124,7 +124,10 @@ class ProverRounds:
         return p
 
     # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
-    def keygen(self):
+    def keygen(self, copy_of=None):
+        """`copy_of`: optional copy map over the stream cells (copy_of[i] = the earlier cell that cell i copies, i itself
+        otherwise) to tie in the permutation argument besides the cells the layout duplicates.  For the Merkle circuit it is
+        built here (copymap.merkle_copy_map) unless given; the k-means / nearest gadgets' own maps are not built."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
         # the derived columns (products, quotient, opening quotients) and the fixed sigma columns hold full-width scalars
         self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
@@ -135,13 +138,22 @@ class ProverRounds:
         hp._witness(sel=d_flags)
         d_q = api.DeviceBuffer(self.n_adv * rows * B)
         check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+        from .pipeline import MerkleHotPath
+        if copy_of is None and isinstance(hp, MerkleHotPath):
+            from .copymap import merkle_copy_map
+            copy_of, self.root_cell = merkle_copy_map(hp.n, hp.dim, d_flags.download((hp.n_cells,), dtype=np.uint8))
+        self.copy_of = copy_of
         d_flags.free()
         self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
-        mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
-        for c in range(self.n_adv - 1):
-            last = int(hp.bp[c])
-            mapping[c, last], mapping[c + 1, 0] = np.uint64((c + 1) << 32), np.uint64((c << 32) | last)
+        if copy_of is not None:
+            from .copymap import mapping_from_copy_of
+            mapping = mapping_from_copy_of(copy_of, hp.bp, self.n_cols, rows)
+        else:
+            mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
+            for c in range(self.n_adv - 1):
+                last = int(hp.bp[c])
+                mapping[c, last], mapping[c + 1, 0] = np.uint64((c + 1) << 32), np.uint64((c << 32) | last)
         d_map = api.DeviceBuffer(mapping.nbytes)
         d_map.upload(np.ascontiguousarray(mapping))
         d_sigma = api.DeviceBuffer(self.n_cols * rows * B)

@@ -475,3 +475,42 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
         bad[where] ^= 4
         assert not _verify(O, api, bytes(bad), vk)
     assert not _verify(O, api, proof[:-32], vk) and not _verify(O, api, proof + bytes(32), vk)
+
+
+def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
+    """The Merkle circuit's own copy constraints (halo2_vectordb_amd/copymap.py: symbolic trace of PoseidonChip::permutation,
+    checked cell by cell against the kernel's gate / constant flags): on a real witness every cell equals the cell it copies
+    — two different databases —, most cells are tied, the root cell holds the root; with the whole map in the permutation
+    argument the proof still verifies (the products close), and the stand-alone verifier accepts it."""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.copymap import mapping_from_copy_of
+    from halo2_vectordb_amd.pipeline import MerkleHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU).setup()      # 6 leaves padded to 8 (the zero cell), odd width: 3 permutations per leaf
+    pr = ProverRounds(hp).keygen()
+    try:
+        copy_of = pr.copy_of
+        assert copy_of is not None and copy_of.size == hp.n_cells and (copy_of <= np.arange(copy_of.size)).all()
+        tied = int((copy_of != np.arange(copy_of.size)).sum())
+        assert tied > 0.4 * copy_of.size
+        for seed in (1, 2):
+            vec = np.random.default_rng(seed).integers(0, 219, size=(6, 5)).astype(np.float64)
+            hp.set_vectors(vec)
+            hp._witness()
+            api.sync()
+            stream = hp.d_stream.download((hp.n_cells, 4))
+            assert np.array_equal(stream, stream[copy_of])
+            assert np.array_equal(stream[pr.root_cell], api.poseidon_merkle_root(hp.qvec))
+        # the permutation built from it is a permutation
+        mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows)
+        flat = (mapping >> np.uint64(32)).astype(np.int64) * pr.rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        assert np.array_equal(np.sort(flat.reshape(-1)), np.arange(pr.n_cols * pr.rows))
+        out = pr.prove(None, seed=8)
+        assert quotient_identity_holds(pr, out["challenges"], out["evals"])
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+                  tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], vk)
+    finally:
+        pr.free()
+        hp.free()

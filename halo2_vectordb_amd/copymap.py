@@ -10,9 +10,9 @@ structural choice that depends on the spec's constants (inner_product starts wit
 constant is one) and as a check: every gate-start bit and every constant bit of the template must equal the kernel's.
 tests/test_gpu_rounds.py additionally checks the map against witness values: every cell equals the cell it copies.
 
-Not covered: ties of constant cells to a fixed column (constants stay flagged, untied), and the leaves' message words,
-which the reference assigns before the gadget runs (they are free cells here).  [UPSTREAM-RECALL] for the primitives'
-cell templates, as for the kernels themselves."""
+The leaves' message words are copies of the vector cells assigned at the head of the stream (ctx.assign_witnesses before
+the gadget runs, as the reference's chip_merkle does).  Not covered: ties of constant cells to a fixed column (constants
+stay flagged, untied).  [UPSTREAM-RECALL] for the primitives' cell templates, as for the kernels themselves."""
 import numpy as np
 
 T, RATE, R_F, R_P = 3, 2, 8, 57
@@ -122,11 +122,19 @@ def perm_cells(n_in):
     return {2: 18, 1: 15, 0: 12}[n_in] + 2238
 
 
-def merkle_copy_map(n, dim, flags):
-    """copy_of[i] = stream offset of the cell that cell i copies (i itself for new cells, message words and constants) for
-    merkle_commitment over n vectors of `dim` words; `flags`: the flag bytes of a keygen-style run of the same circuit
-    (vdb_wit_merkle_dev with a selector buffer).  Also returns the stream offset of the root cell."""
+def merkle_copy_map(n, dim, flags, vectors_assigned=True):
+    """copy_of[i] = stream offset of the cell that cell i copies (i itself for new cells and constants) for merkle_commitment
+    over n vectors of `dim` words; `flags`: the flag bytes of a keygen-style run of the same circuit (vdb_wit_merkle_dev with a
+    selector buffer).  With `vectors_assigned` the stream starts with the n * dim assigned vector words
+    (ctx.assign_witnesses, as the reference's chip_merkle does) and every message word a leaf absorbs is a copy of its
+    cell; without, the message words are free cells.  Also returns the stream offset of the root cell."""
     flags = np.asarray(flags, dtype=np.uint8)
+    n_in = n * dim if vectors_assigned else 0
+    if n_in:
+        if flags[:n_in].any():
+            raise ValueError("the assigned vector words carry no gate or constant flag")
+        gadget, root = merkle_copy_map(n, dim, flags[n_in:], vectors_assigned=None)
+        return np.concatenate([np.arange(n_in, dtype=np.int64), gadget + n_in]), root + n_in
     nperm = (dim + 1) // 2 + (1 if dim % 2 == 0 else 0)
     n_ins = [max(0, min(2, dim - 2 * p)) for p in range(nperm)]
     sizes = [perm_cells(k) for k in n_ins]
@@ -168,7 +176,9 @@ def merkle_copy_map(n, dim, flags):
     leaf_base = np.arange(n, dtype=np.int64) * leaf_cells
     state, off = [None] * T, 0
     for p in range(nperm):
-        state = place(leaf_base + off, n_ins[p], state, [None] * n_ins[p])
+        # (vectors_assigned is None in the inner call of the assigned-vectors case: the words sit n * dim cells before the gadget)
+        msg = [np.arange(n, dtype=np.int64) * dim + 2 * p + i - n * dim for i in range(n_ins[p])] if vectors_assigned is None else [None] * n_ins[p]
+        state = place(leaf_base + off, n_ins[p], state, msg)
         off += sizes[p]
     digest = np.full(lp, n * leaf_cells, dtype=np.int64)        # padding leaves: the load_zero cell after the leaves
     digest[:n] = state[1]

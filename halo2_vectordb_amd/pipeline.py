@@ -443,18 +443,21 @@ class MerkleHotPath(KmeansHotPath):
     def _circuit_size(self):
         cells = ctypes.c_uint64()
         check(self.lib.vdb_wit_merkle_size(self.n, self.dim, 0, ctypes.byref(cells)))
-        return 0, cells.value, 0
+        return self.n * self.dim, cells.value, 0      # the vectors are assigned first (tests/vectordb/mod.rs:253-262 chip_merkle)
 
     def _alloc_outputs(self):
         self.d_root = api.DeviceBuffer(32)
 
     def _witness(self, sel=None):
         lib = self.lib
+        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
         windowed = sel is None and self.shard_witness and self.world > 1
         if windowed:   # only the permutations whose cells fall into this rank's columns are traced; the digests are computed everywhere
-            check(lib.vdb_wit_set_window(ctypes.c_uint64(self.win_adv[0]), ctypes.c_uint64(self.win_adv[1]), ctypes.c_uint64(0), ctypes.c_uint64(0)))
+            lo, hi = (max(0, x - self.n_in) for x in self.win_adv)       # in the coordinates of the pointer handed to the call
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(0), ctypes.c_uint64(0)))
         try:
-            check(lib.vdb_wit_merkle_dev(self.d_vec.ptr, self.n, self.dim, 0, self.d_stream.ptr, sel.ptr if sel is not None else None, self.d_root.ptr))
+            check(lib.vdb_wit_merkle_dev(self.d_vec.ptr, self.n, self.dim, 0, self.d_stream.at(self.n_in * 32),
+                                         ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_root.ptr))
         finally:
             if windowed:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))

@@ -215,7 +215,7 @@ def test_merkle_hot_path_c3_and_column_shards(api, O):
     the unsharded commitments (the way C5's 2^18-row circuits are cut to fit: tools/c5_subcircuits.py)."""
     from halo2_vectordb_amd.pipeline import MerkleHotPath
     hp = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED).setup()
-    assert hp.n_lk_cols == 0 and hp.n_cells == 1024 * (64 * 2256 + 2250) + 1023 * (2256 + 2250)
+    assert hp.n_lk_cols == 0 and hp.n_cells == 1024 * 128 + 1024 * (64 * 2256 + 2250) + 1023 * (2256 + 2250)    # assigned vectors + trace
     full = hp.step().copy()
     assert np.array_equal(hp.results(), api.poseidon_merkle_root(hp.qvec))
     hp.relayout()

@@ -501,6 +501,8 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
             api.sync()
             stream = hp.d_stream.download((hp.n_cells, 4))
             assert np.array_equal(stream, stream[copy_of])
+            assert np.array_equal(stream[: 6 * 5], hp.qvec.reshape(-1, 4))                  # the assigned vector words ...
+            assert (copy_of[30:] < 30).sum() == 6 * 5                                       # ... each absorbed exactly once
             assert np.array_equal(stream[pr.root_cell], api.poseidon_merkle_root(hp.qvec))
         # the permutation built from it is a permutation
         mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows)

@@ -11,8 +11,8 @@ constant is one) and as a check: every gate-start bit and every constant bit of 
 tests/test_gpu_rounds.py additionally checks the map against witness values: every cell equals the cell it copies.
 
 The leaves' message words are copies of the vector cells assigned at the head of the stream (ctx.assign_witnesses before
-the gadget runs, as the reference's chip_merkle does).  Not covered: ties of constant cells to a fixed column (constants
-stay flagged, untied).  [UPSTREAM-RECALL] for the primitives' cell templates, as for the kernels themselves."""
+the gadget runs, as the reference's chip_merkle does).  Constant cells are not part of the map: they are pinned by
+the constants gate of the rounds (rounds.py) instead of being tied to a fixed column.  [UPSTREAM-RECALL] for the primitives' cell templates, as for the kernels themselves."""
 import numpy as np
 
 T, RATE, R_F, R_P = 3, 2, 8, 57

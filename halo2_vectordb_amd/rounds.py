@@ -19,6 +19,7 @@ from ._lib import check
 from .pipeline import N_BLIND
 
 B = 32
+FIXED = ("sel", "qc", "fc", "sigma", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
@@ -143,8 +144,26 @@ class ProverRounds:
             from .copymap import merkle_copy_map
             copy_of, self.root_cell = merkle_copy_map(hp.n, hp.dim, d_flags.download((hp.n_cells,), dtype=np.uint8))
         self.copy_of = copy_of
-        d_flags.free()
         self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
+        # constant cells as a gate: qc = one where a column holds a QuantumCell::Constant, fc = the constant there (from this
+        # keygen-style run's stream), zero elsewhere.  The overlap cell that ends a column is flagged in the next column only,
+        # exactly like the gate selectors.
+        n_el = self.n_adv * rows
+        d_mask = api.DeviceBuffer(n_el)
+        check(lib.vdb_layout_const_mask_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_mask.ptr))
+        for c in range(self.n_adv - 1):
+            check(lib.vdb_memset_dev(d_mask.at(c * rows + int(hp.bp[c])), 0, _sz(1)))
+        d_fc = api.DeviceBuffer(n_el * B)
+        check(lib.vdb_layout_columns_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_fc.ptr, None, 0))
+        check(lib.vdb_mask_select_dev(d_fc.ptr, d_mask.ptr, ctypes.c_uint64(n_el), 1, d_fc.ptr))
+        d_mask.free()
+        cflags = (d_flags.download((hp.n_cells,), dtype=np.uint8) >> 1) & 1
+        d_flags.upload(np.ascontiguousarray(cflags))
+        d_qc = api.DeviceBuffer(n_el * B)
+        check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_qc.ptr))
+        d_flags.free()
+        self._fixed_poly("qc", d_qc, self.n_adv, keep_lag=False, keep_ext=False)
+        self._fixed_poly("fc", d_fc, self.n_adv, keep_lag=False, keep_ext=False)
         # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
         if copy_of is not None:
             from .copymap import mapping_from_copy_of
@@ -159,7 +178,7 @@ class ProverRounds:
         d_sigma = api.DeviceBuffer(self.n_cols * rows * B)
         check(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_cols), k, api._p(self.delta), d_sigma.ptr))
         d_map.free()
-        self._fixed_poly("sigma", d_sigma, self.n_cols, keep_ext=False)
+        self._fixed_poly("sigma", d_sigma, self.n_cols, keep_lag=False, keep_ext=False)
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
         tab[tab >= (1 << hp.L)] = 0
@@ -179,12 +198,13 @@ class ProverRounds:
         lib, rows = self.lib, self.rows
         # the working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
         # [pa | ps | zp | zl] in Lagrange / coefficient form, their extended cosets, a block of fixed cosets, h.  The
-        # Lagrange image of the advice columns is dead before the derived cosets exist and shares their memory.  The
+        # Lagrange images of the advice and sigma columns (the latter recovered from its coefficients by a forward transform
+        # each time) are dead before the derived cosets exist and share their memory.  The
         # library's MSM scratch is released first so that it is re-sized to what is left.
         check(lib.vdb_scratch_release())
         n_der = 3 * self.n_lk + self.n_sets
         self.pool_der = api.DeviceBuffer(max(n_der, 1) * rows * B)
-        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, self.n_cols * rows) * B)
+        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, 2 * self.n_cols * rows) * B)
         self.d_blk = api.DeviceBuffer(min(self.n_cols, max(self.block_cols, 510)) * self.ne * B)
         self.d_h = api.DeviceBuffer(self.ne * B)
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
@@ -215,8 +235,8 @@ class ProverRounds:
             self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
             self.srs_few = api.Srs(k, hp.g_monomial, None)
             omega = api.root_of_unity(k)
-            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("sigma", self.n_cols, True, False), ("table", 1, True, True),
-                                                     ("lag", 3, False, True)):
+            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("qc", self.n_adv, False, False), ("fc", self.n_adv, False, False),
+                                                     ("sigma", self.n_cols, False, False), ("table", 1, True, True), ("lag", 3, False, True)):
                 coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
                 if coeff_h.shape != (n_cols, rows, 4):
                     raise ValueError("proving key: wrong shape for " + name)
@@ -261,7 +281,7 @@ class ProverRounds:
                     tr.write_point(pt)
 
         if tr is not None:
-            for name in ("sel", "sigma", "table", "lag"):
+            for name in FIXED:
                 for pt in self.fixed[name].commits:
                     tr.common_point(pt)
         usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
@@ -304,8 +324,12 @@ class ProverRounds:
         squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
+        d_sigma_lag = _View(self.pool_ext, n_cols * rows * B, n_cols * rows * B)
+
         def products():
-            check(lib.vdb_permutation_product_dev(d_lag.ptr, fx["sigma"].lag.ptr, _sz(n_cols), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
+            check(lib.vdb_memcpy_d2d(d_sigma_lag.ptr, fx["sigma"].coeff.ptr, _sz(n_cols * rows * B)))
+            check(lib.vdb_ntt_batch_dev(d_sigma_lag.ptr, _sz(n_cols), k, api._p(api.root_of_unity(k)), 0))
+            check(lib.vdb_permutation_product_dev(d_lag.ptr, d_sigma_lag.ptr, _sz(n_cols), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
                                                   api._p(self.delta), d_zp.ptr))
             check(lib.vdb_lookup_product_dev(lk_lag, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
                                              d_zl.ptr))
@@ -340,6 +364,16 @@ class ProverRounds:
                 nb = min(blk, n_adv - c0)
                 check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
                 check(lib.vdb_gate_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
+            # constants gate: qc a per column (qc cosets in blocks), then minus sum_c y^(n-1-c) fc_c — combined in coefficient form,
+            # extended once
+            for c0 in range(0, n_adv, blk):
+                nb = min(blk, n_adv - c0)
+                check(lib.vdb_coeff_to_extended_dev(fx["qc"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
+                check(lib.vdb_const_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
+            check(lib.vdb_memset_dev(self.d_comb.ptr, 0, _sz(rows * B)))
+            check(lib.vdb_poly_lincomb_dev(fx["fc"].coeff.ptr, _sz(n_adv), _sz(rows), p["y"], self.d_comb.ptr))
+            check(lib.vdb_coeff_to_extended_dev(self.d_comb.ptr, d_blk.ptr, _sz(1), k, EXT_K))
+            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-1)), d_blk.ptr, _sz(ne)))
             for c0 in range(0, n_cols, blk):
                 nb = min(blk, n_cols - c0)
                 check(lib.vdb_coeff_to_extended_dev(fx["sigma"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
@@ -359,7 +393,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "sigma", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "qc", "fc", "sigma", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
@@ -561,6 +595,9 @@ def quotient_identity_holds(pr, challenges, evals):
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
+    qc, fc = ev("qc"), ev("fc")
+    for c in range(n_adv):
+        acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
     n_cols, n_sets = len(a0), len(z0)

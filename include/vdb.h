@@ -317,6 +317,14 @@ int vdb_extended_to_coeff_dev(vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32
  * the extended coset of 2^(k+ext_k) points.  adv_ext_dev, sel_ext_dev: n_cols x 2^(k+ext_k) (vdb_coeff_to_extended_dev of
  * the advice and selector polynomials); acc_dev: 2^(k+ext_k), read and written (zero it before the first call). */
 int vdb_gate_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *y, vdb_fr *acc_dev);
+/* Constant cells as a gate: per advice column the fixed polynomials qc (one on the rows that hold a QuantumCell::Constant) and
+ * fc (the constant on those rows, zero elsewhere) with qc(X) a(X) - fc(X) = 0 on the domain.  This call folds the qc part into
+ * the accumulator: acc[j] <- Horner over the columns of (acc * y + qc_c[j] * a_c[j]) on the extended coset.  The fc part is linear
+ * in the fixed polynomials: the caller combines the fc coefficients with the same powers of y (vdb_poly_lincomb_dev), extends
+ * that one polynomial (vdb_coeff_to_extended_dev) and subtracts it (vdb_poly_axpy_dev with -1) right after the last block.
+ * (halo2-base ties constants to a fixed column through the permutation argument instead; this build states the same fact —
+ * the cell holds that constant — as a degree-2 gate.) */
+int vdb_const_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *qc_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *y, vdb_fr *acc_dev);
 /* EvaluationDomain::divide_by_vanishing_poly: h[j] /= (X^n - 1) at the j-th point of the extended coset, in place. */
 int vdb_divide_by_vanishing_dev(vdb_fr *h_ext_dev, uint32_t k, uint32_t ext_k);
 /* column-layout image of the gate selectors as field elements (keygen side; flags as for vdb_layout_const_mask_dev, bit 0):

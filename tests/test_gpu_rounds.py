@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
+FIXED = ("sel", "qc", "fc", "sigma", "table", "lag")
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
@@ -47,6 +48,9 @@ def check_quotient_identity(O, meta, ch, evals):
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
+    qc, fc = ev("qc"), ev("fc")
+    for c in range(n_adv):
+        acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
     n_cols, n_sets = len(a0), len(z0)
@@ -121,6 +125,11 @@ def test_quotient_identity_from_the_returned_evaluations(circuit, proved, O):
     wrong = dict(out["evals"])
     wrong[("zl", 1)] = [(e + 1) % O.R_MOD for e in wrong[("zl", 1)]]
     assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
+    # the constants gate is part of the identity: a different constant polynomial breaks it
+    assert any(out["evals"][("qc", 0)]) and any(out["evals"][("fc", 0)])
+    wrong = dict(out["evals"])
+    wrong[("fc", 0)] = [(e + 1) % O.R_MOD for e in wrong[("fc", 0)]]
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
 
 
 def test_every_opening_verifies_in_the_exponent(circuit, proved, O):
@@ -169,8 +178,8 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     out = pr.prove(None, seed=11, multiopen="gwc")
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
-    fixed = {name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")}
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    fixed = {name: pr.fixed[name].commits for name in FIXED}
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
@@ -184,7 +193,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
         pos += 32 * m
         return pts
     tr = api.Transcript()
-    for name in ("sel", "sigma", "table", "lag"):
+    for name in FIXED:
         for pt in fixed[name]:
             tr.common_point(pt)
     commitments = dict(fixed)
@@ -246,7 +255,7 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
         from halo2_vectordb_amd import api
         from oracle import pairing as PR
         out2 = pr.prove(None, seed=4)
-        vk = dict(meta=_meta(pr), opened=out2["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+        vk = dict(meta=_meta(pr), opened=out2["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
                   tau_h=PR.pt_mul(PR.G2, TAU))
         assert _verify(O, api, out2["proof"], vk)
     finally:
@@ -358,7 +367,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     pos = 0
     tr = api.Transcript()
@@ -376,7 +385,7 @@ def _verify(O, api, proof, vk):
                 pos += 32
                 tr.common_point(pts[-1])
             return np.stack(pts) if pts else np.zeros((0, 8), dtype=np.uint64)
-        for name in ("sel", "sigma", "table", "lag"):
+        for name in FIXED:
             for pt in vk["fixed"][name]:
                 tr.common_point(pt)
         C = dict(vk["fixed"])
@@ -465,7 +474,7 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
     from oracle import pairing as PR
     hp, pr = circuit
     out = pr.prove(None, seed=31)
-    vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+    vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
               tau_h=PR.pt_mul(PR.G2, TAU))
     proof = out["proof"]
     assert _verify(O, api, proof, vk)
@@ -510,7 +519,7 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
         assert np.array_equal(np.sort(flat.reshape(-1)), np.arange(pr.n_cols * pr.rows))
         out = pr.prove(None, seed=8)
         assert quotient_identity_holds(pr, out["challenges"], out["evals"])
-        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in ("sel", "sigma", "table", "lag")},
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
                   tau_h=PR.pt_mul(PR.G2, TAU))
         assert _verify(O, api, out["proof"], vk)
     finally:

@@ -127,14 +127,16 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
     over n vectors of `dim` words; `flags`: the flag bytes of a keygen-style run of the same circuit (vdb_wit_merkle_dev with a
     selector buffer).  With `vectors_assigned` the stream starts with the n * dim assigned vector words
     (ctx.assign_witnesses, as the reference's chip_merkle does) and every message word a leaf absorbs is a copy of its
-    cell; without, the message words are free cells.  Also returns the stream offset of the root cell."""
+    cell; without, the message words are free cells.  Also returns the stream offset of the root cell and the offsets of the
+    cells that hold the sponge's initial state (every leaf and every tree node starts from [2^64, 0, 0]; the kernels emit them
+    as ordinary cells, the circuit must pin them like constants)."""
     flags = np.asarray(flags, dtype=np.uint8)
     n_in = n * dim if vectors_assigned else 0
     if n_in:
         if flags[:n_in].any():
             raise ValueError("the assigned vector words carry no gate or constant flag")
-        gadget, root = merkle_copy_map(n, dim, flags[n_in:], vectors_assigned=None)
-        return np.concatenate([np.arange(n_in, dtype=np.int64), gadget + n_in]), root + n_in
+        gadget, root, init = merkle_copy_map(n, dim, flags[n_in:], vectors_assigned=None)
+        return np.concatenate([np.arange(n_in, dtype=np.int64), gadget + n_in]), root + n_in, init + n_in
     nperm = (dim + 1) // 2 + (1 if dim % 2 == 0 else 0)
     n_ins = [max(0, min(2, dim - 2 * p)) for p in range(nperm)]
     sizes = [perm_cells(k) for k in n_ins]
@@ -149,6 +151,7 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
         raise ValueError("flags do not belong to this circuit")
     copy_of = np.arange(total, dtype=np.int64)
     templates = {}
+    init_cells = []          # cells that hold the sponge's initial state [2^64, 0, 0]: constants of the circuit, though not flagged
 
     def template(n_in, at):
         if n_in not in templates:
@@ -165,6 +168,8 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
             cols = np.flatnonzero(src == -10 - i)
             if state_src[i] is not None and cols.size:
                 val[:, cols] = state_src[i][:, None]
+            elif cols.size:
+                init_cells.append(idx[:, cols].reshape(-1))
         for i in range(n_in):
             cols = np.flatnonzero(src == -20 - i)
             if msg_src[i] is not None and cols.size:
@@ -192,7 +197,7 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
         digest = st2[1]
         pos += half * node_cells
         width = half
-    return copy_of, int(digest[0])
+    return copy_of, int(digest[0]), np.sort(np.concatenate(init_cells))
 
 
 def mapping_from_copy_of(copy_of, break_points, n_cols, rows):

@@ -142,7 +142,11 @@ class ProverRounds:
         from .pipeline import MerkleHotPath
         if copy_of is None and isinstance(hp, MerkleHotPath):
             from .copymap import merkle_copy_map
-            copy_of, self.root_cell = merkle_copy_map(hp.n, hp.dim, d_flags.download((hp.n_cells,), dtype=np.uint8))
+            flags_h = d_flags.download((hp.n_cells,), dtype=np.uint8)
+            copy_of, self.root_cell, init_cells = merkle_copy_map(hp.n, hp.dim, flags_h)
+            flags_h[init_cells] |= 2              # the sponge's initial state: pinned by the constants gate below like any constant
+            d_flags.upload(flags_h)
+            self.n_pinned_init = int(init_cells.size)
         self.copy_of = copy_of
         self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # constant cells as a gate: qc = one where a column holds a QuantumCell::Constant, fc = the constant there (from this

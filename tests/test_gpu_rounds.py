@@ -501,6 +501,7 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
     try:
         copy_of = pr.copy_of
         assert copy_of is not None and copy_of.size == hp.n_cells and (copy_of <= np.arange(copy_of.size)).all()
+        assert pr.n_pinned_init == 3 * (6 + 7)           # the initial sponge state of 6 leaves and 7 tree nodes, pinned as constants
         tied = int((copy_of != np.arange(copy_of.size)).sum())
         assert tied > 0.4 * copy_of.size
         for seed in (1, 2):

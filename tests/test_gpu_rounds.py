@@ -526,3 +526,42 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_copy_constraints_are_enforced(O):
+    """A vector word at the head of the stream is in no gate: changing it after witness generation leaves every gate and every
+    constant intact and breaks exactly one copy constraint (the word a leaf absorbs is no longer the assigned one).  With the
+    Merkle circuit's copy map in the permutation argument the verifier rejects the proof; with only the layout's own ties
+    (the identity map) the same tampered witness still proves — which is what the map is for."""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.pipeline import MerkleHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    hp = MerkleHotPath(n=4, dim=4, k=11, tau=TAU).setup()
+    honest = hp._witness
+    other = O.fr_from_ints([123456789])
+
+    def tampered(sel=None):
+        honest(sel)
+        if sel is None:
+            hp.d_stream.upload(other, offset=7 * 32)
+
+    tau_h = PR.pt_mul(PR.G2, TAU)
+    results = {}
+    for label, copy_of in (("full map", None), ("layout ties only", np.arange(hp.n_cells, dtype=np.int64))):
+        pr = ProverRounds(hp).keygen(copy_of=copy_of)
+        try:
+            vk = lambda out: dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=tau_h)
+            out = pr.prove(None, seed=1)
+            assert _verify(O, api, out["proof"], vk(out))                          # the honest witness proves under both
+            hp._witness = tampered
+            try:
+                bad = pr.prove(None, seed=1)
+            finally:
+                hp._witness = honest
+            results[label] = (quotient_identity_holds(pr, bad["challenges"], bad["evals"]), _verify(O, api, bad["proof"], vk(bad)))
+        finally:
+            pr.free()
+    hp.free()
+    assert results["full map"] == (False, False)
+    assert results["layout ties only"] == (True, True)

@@ -522,6 +522,18 @@ class Transcript:
     def write_point(self, pt):
         check(self.L.vdb_transcript_write_point(self.h, _p(np.ascontiguousarray(pt, dtype=np.uint64))))
 
+    def write_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 8)
+        check(self.L.vdb_transcript_write_points(self.h, _p(pts), _sz(pts.shape[0])))
+
+    def write_scalars(self, ss):
+        ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
+        check(self.L.vdb_transcript_write_scalars(self.h, _p(ss), _sz(ss.shape[0])))
+
+    def common_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 8)
+        check(self.L.vdb_transcript_common_points(self.h, _p(pts), _sz(pts.shape[0])))
+
     def squeeze(self):
         out = np.zeros(4, dtype=np.uint64)
         check(self.L.vdb_transcript_squeeze(self.h, _p(out)))

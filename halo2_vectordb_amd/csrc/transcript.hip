@@ -27,24 +27,98 @@ struct vdb_transcript {
 
 namespace {
 
+// Host arithmetic for the sponge: the same Montgomery representatives (R = 2^256) on four 64-bit limbs with 128-bit
+// products — a proof of a few thousand columns absorbs tens of thousands of values, i.e. ~10^4 permutations of 68 rounds,
+// and the device-oriented 29-bit-limb product is several times slower on a CPU core.
+struct F4 {
+  uint64_t l[4];
+};
+constexpr uint64_t FR_P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+constexpr uint64_t FR_INV = 0xc2e1f593efffffffull;  // -r^-1 mod 2^64
+inline F4 to_f4(const u256& a) {
+  F4 r;
+  memcpy(r.l, a.w, 32);
+  return r;
+}
+inline u256 from_f4(const F4& a) {
+  u256 r;
+  memcpy(r.w, a.l, 32);
+  return r;
+}
+inline bool geq_p(const uint64_t t[4]) {
+  for (int i = 3; i >= 0; i--)
+    if (t[i] != FR_P[i]) return t[i] > FR_P[i];
+  return true;
+}
+inline void sub_p(uint64_t t[4]) {
+  unsigned __int128 b = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 d = (unsigned __int128)t[i] - FR_P[i] - (uint64_t)b;
+    t[i] = (uint64_t)d;
+    b = (d >> 64) & 1;
+  }
+}
+inline F4 f4_add(const F4& a, const F4& b) {
+  F4 r;
+  unsigned __int128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (unsigned __int128)a.l[i] + b.l[i];
+    r.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if (c || geq_p(r.l)) sub_p(r.l);  // a + b < 2 r < 2^255: no carry out in fact
+  return r;
+}
+inline F4 f4_mul(const F4& a, const F4& b) {  // CIOS
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (unsigned __int128)a.l[j] * b.l[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * FR_INV;
+    c = (unsigned __int128)m * FR_P[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (unsigned __int128)m * FR_P[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  F4 r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq_p(r.l)) sub_p(r.l);
+  return r;
+}
+
 void permute(vdb_transcript* tr) {
   const int t = tr->t, half = tr->r_f / 2;
-  std::vector<u256>& st = tr->state;
-  std::vector<u256> nx(t);
+  F4 st[16], nx[16];
+  for (int i = 0; i < t; i++) st[i] = to_f4(tr->state[i]);
+  const F4* rc = reinterpret_cast<const F4*>(tr->rc.data());
+  const F4* mds = reinterpret_cast<const F4*>(tr->mds.data());
   for (int r = 0; r < tr->r_f + tr->r_p; r++) {
-    for (int i = 0; i < t; i++) st[i] = fr_add(st[i], tr->rc[(size_t)r * t + i]);
+    for (int i = 0; i < t; i++) st[i] = f4_add(st[i], rc[(size_t)r * t + i]);
     const bool full = r < half || r >= half + tr->r_p;
     for (int i = 0; i < (full ? t : 1); i++) {
-      const u256 x2 = fr_mul(st[i], st[i]);
-      st[i] = fr_mul(fr_mul(x2, x2), st[i]);
+      const F4 x2 = f4_mul(st[i], st[i]);
+      st[i] = f4_mul(f4_mul(x2, x2), st[i]);
     }
     for (int i = 0; i < t; i++) {
-      u256 acc = fr_mul(tr->mds[(size_t)i * t], st[0]);
-      for (int j = 1; j < t; j++) acc = fr_add(acc, fr_mul(tr->mds[(size_t)i * t + j], st[j]));
+      F4 acc = f4_mul(mds[(size_t)i * t], st[0]);
+      for (int j = 1; j < t; j++) acc = f4_add(acc, f4_mul(mds[(size_t)i * t + j], st[j]));
       nx[i] = acc;
     }
-    st = nx;
+    for (int i = 0; i < t; i++) st[i] = nx[i];
   }
+  for (int i = 0; i < t; i++) tr->state[i] = from_f4(st[i]);
 }
 
 void absorb_chunk(vdb_transcript* tr, const u256* in, int n_in) {
@@ -128,6 +202,33 @@ int vdb_transcript_write_point(vdb_transcript* tr, const vdb_g1* p) {
   const u256 x = from_mont<Fq>(xy[0]), y = from_mont<Fq>(xy[1]);
   const bool identity = u256_is_zero(x) && u256_is_zero(y);
   put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? 0x40 : 0);
+  return VDB_OK;
+}
+
+int vdb_transcript_write_points(vdb_transcript* tr, const vdb_g1* p, size_t n) {
+  VDB_ARG(tr && (p || n == 0), "null pointer");
+  for (size_t i = 0; i < n; i++) {
+    int rc = vdb_transcript_write_point(tr, p + i);
+    if (rc) return rc;
+  }
+  return VDB_OK;
+}
+
+int vdb_transcript_write_scalars(vdb_transcript* tr, const vdb_fr* s, size_t n) {
+  VDB_ARG(tr && (s || n == 0), "null pointer");
+  for (size_t i = 0; i < n; i++) {
+    int rc = vdb_transcript_write_scalar(tr, s + i);
+    if (rc) return rc;
+  }
+  return VDB_OK;
+}
+
+int vdb_transcript_common_points(vdb_transcript* tr, const vdb_g1* p, size_t n) {
+  VDB_ARG(tr && (p || n == 0), "null pointer");
+  for (size_t i = 0; i < n; i++) {
+    int rc = vdb_transcript_common_point(tr, p + i);
+    if (rc) return rc;
+  }
   return VDB_OK;
 }
 

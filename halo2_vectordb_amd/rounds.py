@@ -280,14 +280,12 @@ class ProverRounds:
                     p[name] = api._p(ch[name])
 
         def write_points(points):
-            if tr is not None:
-                for pt in points:
-                    tr.write_point(pt)
+            if tr is not None and len(points):
+                tr.write_points(np.stack([np.asarray(pt) for pt in points]) if isinstance(points, list) else points)
 
         if tr is not None:
             for name in FIXED:
-                for pt in self.fixed[name].commits:
-                    tr.common_point(pt)
+                tr.common_points(self.fixed[name].commits)
         usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
         fx = self.fixed
         T = {} if timings is None else timings
@@ -323,8 +321,8 @@ class ProverRounds:
         self._blind(d_ps, n_lk, usable, rng)
         polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1, dense=False)))
         polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1, dense=False)))
-        for a, b in zip(polys["pa"].commits, polys["ps"].commits):
-            write_points([a, b])
+        if n_lk:
+            write_points(np.stack([polys["pa"].commits, polys["ps"].commits], axis=1).reshape(-1, 8))     # (pa_c, ps_c) per lookup column
         squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
@@ -419,8 +417,7 @@ class ProverRounds:
         if tr is not None:
             for rot, names in opened.items():
                 for name in names:
-                    for e in evals[(name, rot)]:
-                        tr.write_scalar(e)
+                    tr.write_scalars(evals[(name, rot)])
         d_comb, d_quot = self.d_comb, self.d_quot
         if multiopen == "shplonk":
             openings = self._shplonk(allp, opened, points, evals, p, ch, squeeze, write_points, stage)

@@ -344,6 +344,10 @@ int vdb_transcript_common_scalar(vdb_transcript *tr, const vdb_fr *s);
 int vdb_transcript_common_point(vdb_transcript *tr, const vdb_g1 *p);
 int vdb_transcript_write_scalar(vdb_transcript *tr, const vdb_fr *s);
 int vdb_transcript_write_point(vdb_transcript *tr, const vdb_g1 *p);
+/* the same over arrays (one call per round instead of one per column) */
+int vdb_transcript_write_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
+int vdb_transcript_write_scalars(vdb_transcript *tr, const vdb_fr *s, size_t n);
+int vdb_transcript_common_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
 int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
 int vdb_transcript_proof_len(const vdb_transcript *tr, size_t *len);
 int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t cap);

@@ -19,7 +19,7 @@ from ._lib import check
 from .pipeline import N_BLIND
 
 B = 32
-FIXED = ("sel", "qc", "fc", "sigma", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
+FIXED = ("sel", "qc", "fc", "sigma", "table", "lag", "inst")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
@@ -125,10 +125,13 @@ class ProverRounds:
         return p
 
     # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
-    def keygen(self, copy_of=None):
+    def keygen(self, copy_of=None, instance_cells=None):
         """`copy_of`: optional copy map over the stream cells (copy_of[i] = the earlier cell that cell i copies, i itself
         otherwise) to tie in the permutation argument besides the cells the layout duplicates.  For the Merkle circuit it is
-        built here (copymap.merkle_copy_map) unless given; the k-means / nearest gadgets' own maps are not built."""
+        built here (copymap.merkle_copy_map) unless given; the k-means / nearest gadgets' own maps are not built.
+        `instance_cells`: stream cells whose values are public inputs of the statement (for the Merkle circuit: the root
+        cell).  Each gets a fixed Lagrange polynomial L of its (column, row) and the term L (a - value) in the quotient — the
+        value enters the transcript and the verifier's identity; halo2 would tie the cell to an instance column instead."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
         # the derived columns (products, quotient, opening quotients) and the fixed sigma columns hold full-width scalars
         self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
@@ -195,6 +198,19 @@ class ProverRounds:
         d_l = api.DeviceBuffer(lag.nbytes)
         d_l.upload(lag)
         self._fixed_poly("lag", d_l, 3)
+        if instance_cells is None:
+            instance_cells = [self.root_cell] if getattr(self, "root_cell", None) is not None else []
+        starts = np.concatenate([[0], np.cumsum(np.asarray(hp.bp, dtype=np.int64))])
+        self.instance_cells = [int(c) for c in instance_cells]
+        self.instance_pos = []
+        inst = np.zeros((max(len(self.instance_cells), 1), rows, 4), dtype=np.uint64)
+        for i, cell in enumerate(self.instance_cells):
+            col = int(np.searchsorted(starts, cell, side="right") - 1)
+            self.instance_pos.append((col, cell - int(starts[col])))
+            inst[i, cell - int(starts[col])] = one
+        d_i = api.DeviceBuffer(inst.nbytes)
+        d_i.upload(inst)
+        self._fixed_poly("inst", d_i, len(self.instance_cells))
         api.sync()
         return self._alloc_working_set()
 
@@ -222,8 +238,10 @@ class ProverRounds:
         form and its commitments.  Upstream's pk file format (SerdeFormat::RawBytes) is not reproduced: parity unpinned."""
         api.sync()
         doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, CHUNK_LEN, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
+        doc["instance_cells"] = np.asarray(self.instance_cells, dtype=np.int64)
+        doc["instance_pos"] = np.asarray(self.instance_pos, dtype=np.int64).reshape(-1, 2)
         for name, q in self.fixed.items():
-            doc[name + "_coeff"] = q.coeff.download((q.n_cols, self.rows, 4))
+            doc[name + "_coeff"] = q.coeff.download((max(q.n_cols, 1), self.rows, 4))
             doc[name + "_commits"] = q.commits
         np.savez(path, **doc)
 
@@ -240,12 +258,19 @@ class ProverRounds:
             self.srs_few = api.Srs(k, hp.g_monomial, None)
             omega = api.root_of_unity(k)
             for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("qc", self.n_adv, False, False), ("fc", self.n_adv, False, False),
-                                                     ("sigma", self.n_cols, False, False), ("table", 1, True, True), ("lag", 3, False, True)):
+                                                     ("sigma", self.n_cols, False, False), ("table", 1, True, True), ("lag", 3, False, True),
+                                                     ("inst", None, False, True)):
                 coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
+                if n_cols is None:                      # instance cells: their number and positions come with the key
+                    self.instance_cells = [int(c) for c in doc["instance_cells"]]
+                    self.instance_pos = [(int(c), int(r)) for c, r in doc["instance_pos"]]
+                    n_cols = len(self.instance_cells)
+                    coeff_h = coeff_h[:n_cols]
                 if coeff_h.shape != (n_cols, rows, 4):
                     raise ValueError("proving key: wrong shape for " + name)
-                coeff = api.DeviceBuffer(coeff_h.nbytes)
-                coeff.upload(coeff_h)
+                coeff = api.DeviceBuffer(max(coeff_h.nbytes, 32))
+                if coeff_h.nbytes:
+                    coeff.upload(coeff_h)
                 lag = None
                 if need_lag:
                     lag = api.DeviceBuffer(coeff_h.nbytes)
@@ -257,7 +282,7 @@ class ProverRounds:
         return self._alloc_working_set()
 
     # ------------------------------------------------------------------ the rounds
-    def prove(self, challenges=None, seed=1, timings=None, multiopen="shplonk"):
+    def prove(self, challenges=None, seed=1, timings=None, multiopen="shplonk", instances=None):
         """challenges: dict of Montgomery field elements beta, gamma, y, x, v, or None to derive them with the Fiat–Shamir
         transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the fixed commitments
         (in place of the verifying key's digest); advice commitments -> theta (squeezed as halo2 does, unused: the lookups
@@ -265,7 +290,9 @@ class ProverRounds:
         pieces -> x; all evaluations, rotation by rotation -> then the multi-open: "gwc": v, one quotient per rotation
         point; "shplonk" (what the reference's gen_snark_shplonk runs, [UPSTREAM-RECALL] for the order of its challenges):
         yo, v; the quotient f of all rotation sets; u; the quotient of the linearisation polynomial.
-        Returns dict(commitments, evals, openings, points, proof): commitments[name] (n, 8); evals[(name, rotation)] list
+        `instances`: the public values of keygen's instance cells (Montgomery field elements); None = read from the witness
+        this proof commits to (the honest prover's statement).
+        Returns dict(commitments, evals, openings, points, proof, instances): commitments[name] (n, 8); evals[(name, rotation)] list
         of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W)."""
         hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
         rng = np.random.default_rng(seed)
@@ -298,6 +325,13 @@ class ProverRounds:
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
         adv_commits = hp.step(T).copy()
+        if instances is None:
+            instances = [hp.d_stream.download((4,), offset=cell * 32) for cell in self.instance_cells]
+        instances = [np.ascontiguousarray(v, dtype=np.uint64) for v in instances]
+        assert len(instances) == len(self.instance_cells)
+        if tr is not None:
+            for v in instances:
+                tr.common_scalar(v)
         write_points(adv_commits)
         squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
@@ -376,6 +410,11 @@ class ProverRounds:
             check(lib.vdb_poly_lincomb_dev(fx["fc"].coeff.ptr, _sz(n_adv), _sz(rows), p["y"], self.d_comb.ptr))
             check(lib.vdb_coeff_to_extended_dev(self.d_comb.ptr, d_blk.ptr, _sz(1), k, EXT_K))
             check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-1)), d_blk.ptr, _sz(ne)))
+            # public inputs: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
+            for i, (col, _row) in enumerate(self.instance_pos):
+                l_ext = fx["inst"].ext.at(i * ne * B)
+                check(lib.vdb_const_eval_dev(adv.ext.at(col * ne * B), l_ext, _sz(1), k, EXT_K, p["y"], d_h.ptr))
+                check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
             for c0 in range(0, n_cols, blk):
                 nb = min(blk, n_cols - c0)
                 check(lib.vdb_coeff_to_extended_dev(fx["sigma"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
@@ -395,7 +434,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "qc", "fc", "sigma", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "qc", "fc", "sigma", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
@@ -427,7 +466,8 @@ class ProverRounds:
                 tr.free()
             api.sync()
             return dict(commitments={name: q.commits for name, q in allp.items()}, evals=openings.pop("evals_int"), openings=openings, points=points,
-                        proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened)
+                        proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened,
+                        instances=[_fr_to_int(v) for v in instances], instance_pos=list(self.instance_pos))
         squeeze("v")
 
         # round 6 (v): one opening per rotation point: combine with powers of v, divide by (X - point), commit
@@ -453,7 +493,8 @@ class ProverRounds:
         api.sync()
         commitments = {name: q.commits for name, q in allp.items()}
         return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points,
-                    proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened)
+                    proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened,
+                        instances=[_fr_to_int(v) for v in instances], instance_pos=list(self.instance_pos))
 
     # ------------------------------------------------------------------ SHPLONK multi-open (halo2 poly/kzg/multiopen/shplonk)
     def _shplonk(self, allp, opened, points, evals, p, ch, squeeze, write_points, stage):
@@ -584,7 +625,7 @@ class ProverRounds:
                 setattr(self, name, None)
 
 
-def quotient_identity_holds(pr, challenges, evals):
+def quotient_identity_holds(pr, challenges, evals, instances=None):
     """What a verifier checks first: the gate, permutation and lookup expressions recombined from the evaluations at x (and the
     rotated points) equal h(x) (x^n - 1).  `pr`: the ProverRounds that produced them (for the circuit's shape); `challenges`,
     `evals`: as returned by ProverRounds.prove.  Plain integer arithmetic on the host."""
@@ -599,6 +640,8 @@ def quotient_identity_holds(pr, challenges, evals):
     qc, fc = ev("qc"), ev("fc")
     for c in range(n_adv):
         acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
+    for l_i, (col, _row), value in zip(ev("inst"), pr.instance_pos, instances if instances is not None else []):
+        acc = (acc * yv + l_i * (a0[col] - value)) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
     n_cols, n_sets = len(a0), len(z0)

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
-FIXED = ("sel", "qc", "fc", "sigma", "table", "lag")
+FIXED = ("sel", "qc", "fc", "sigma", "table", "lag", "inst")
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
@@ -37,7 +37,7 @@ def proved(circuit, O):
     return ch, out, timings
 
 
-def check_quotient_identity(O, meta, ch, evals):
+def check_quotient_identity(O, meta, ch, evals, instances=()):
     """gates + permutation + lookup expressions from the evaluations == h(x) (x^n - 1)"""
     R = O.R_MOD
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
@@ -51,6 +51,9 @@ def check_quotient_identity(O, meta, ch, evals):
     qc, fc = ev("qc"), ev("fc")
     for c in range(n_adv):
         acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
+    assert len(instances) == len(meta["instance_pos"])
+    for l_i, (col, _row), value in zip(ev("inst"), meta["instance_pos"], instances):        # public inputs: L (a - value)
+        acc = (acc * yv + l_i * (a0[col] - value)) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
     n_cols, n_sets = len(a0), len(z0)
@@ -103,7 +106,7 @@ def _meta(pr):
     from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND
     import halo2_vectordb_amd.rounds as rounds
     return dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=CHUNK_LEN, n_blind=N_BLIND,
-                delta=rounds._fr_to_int(pr.delta))
+                delta=rounds._fr_to_int(pr.delta), instance_pos=list(pr.instance_pos))
 
 
 def test_round_outputs_have_the_expected_shape(circuit, proved):
@@ -179,7 +182,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
@@ -248,7 +251,7 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
         out = pr.prove(None, seed=3, multiopen="gwc")
         meta = _meta(pr)
         assert out["commitments"]["pa"].shape == (0, 8) and len(out["proof"]) > 0
-        assert check_quotient_identity(O, meta, out["challenges"], out["evals"])
+        assert check_quotient_identity(O, meta, out["challenges"], out["evals"], out["instances"])
         v = O.fr_to_ints(out["challenges"]["v"].reshape(1, 4))[0]
         assert check_openings(O, v, out["commitments"], out["evals"], out["openings"])
         # and the SHPLONK proof bytes through the stand-alone verifier (defined below)
@@ -256,8 +259,9 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
         from oracle import pairing as PR
         out2 = pr.prove(None, seed=4)
         vk = dict(meta=_meta(pr), opened=out2["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
-                  tau_h=PR.pt_mul(PR.G2, TAU))
+                  tau_h=PR.pt_mul(PR.G2, TAU), instances=out2["instances"])
         assert _verify(O, api, out2["proof"], vk)
+        assert not _verify(O, api, out2["proof"], {**vk, "instances": [(out2["instances"][0] + 1) % O.R_MOD]})    # another root: rejected
     finally:
         pr.free()
         hp.free()
@@ -367,7 +371,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     pos = 0
     tr = api.Transcript()
@@ -388,6 +392,8 @@ def _verify(O, api, proof, vk):
         for name in FIXED:
             for pt in vk["fixed"][name]:
                 tr.common_point(pt)
+        for value in vk.get("instances", []):
+            tr.common_scalar(O.fr_from_ints([value])[0])
         C = dict(vk["fixed"])
         C["adv"] = points(counts["adv"])
         ch = {"theta": tr.squeeze()}
@@ -420,7 +426,7 @@ def _verify(O, api, proof, vk):
         return False
     finally:
         tr.free()
-    if not check_quotient_identity(O, meta, ch, evals):
+    if not check_quotient_identity(O, meta, ch, evals, vk.get("instances", [])):
         return False
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     x, yo, v, u = (to_int(ch[n]) for n in ("x", "yo", "v", "u"))
@@ -519,9 +525,10 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
         flat = (mapping >> np.uint64(32)).astype(np.int64) * pr.rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)
         assert np.array_equal(np.sort(flat.reshape(-1)), np.arange(pr.n_cols * pr.rows))
         out = pr.prove(None, seed=8)
-        assert quotient_identity_holds(pr, out["challenges"], out["evals"])
+        assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
+        assert out["instances"] == [O.fr_to_ints(api.poseidon_merkle_root(hp.qvec).reshape(1, 4))[0]]                # the public input is the root
         vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
-                  tau_h=PR.pt_mul(PR.G2, TAU))
+                  tau_h=PR.pt_mul(PR.G2, TAU), instances=out["instances"])
         assert _verify(O, api, out["proof"], vk)
     finally:
         pr.free()
@@ -551,7 +558,8 @@ def test_copy_constraints_are_enforced(O):
     for label, copy_of in (("full map", None), ("layout ties only", np.arange(hp.n_cells, dtype=np.int64))):
         pr = ProverRounds(hp).keygen(copy_of=copy_of)
         try:
-            vk = lambda out: dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=tau_h)
+            vk = lambda out: dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=tau_h,
+                                  instances=out["instances"])
             out = pr.prove(None, seed=1)
             assert _verify(O, api, out["proof"], vk(out))                          # the honest witness proves under both
             hp._witness = tampered
@@ -559,7 +567,7 @@ def test_copy_constraints_are_enforced(O):
                 bad = pr.prove(None, seed=1)
             finally:
                 hp._witness = honest
-            results[label] = (quotient_identity_holds(pr, bad["challenges"], bad["evals"]), _verify(O, api, bad["proof"], vk(bad)))
+            results[label] = (quotient_identity_holds(pr, bad["challenges"], bad["evals"], bad["instances"]), _verify(O, api, bad["proof"], vk(bad)))
         finally:
             pr.free()
     hp.free()

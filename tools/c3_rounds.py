@@ -16,7 +16,7 @@ T = {}
 t3 = time.time()
 out = pr.prove(None, seed=1, timings=T)
 wall = (time.time() - t3) * 1e3
-ok = quotient_identity_holds(pr, out["challenges"], out["evals"])
+ok = quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
 print(json.dumps({"workload": "merkle_commitment 1024x128 k=15 (BASELINE C3) with its full copy map and the constants gate", "cells": hp.n_cells, "columns": hp.n_cols,
                   "tied_cells": tied, "setup_s": round(t1 - t0, 1), "keygen_s": round(t2 - t1, 1), "quotient_identity_at_x_holds": bool(ok), "proof_bytes": len(out["proof"]),
                   "wall_ms": round(wall, 1), "device_ms": {k: round(v, 2) for k, v in T.items()}, "device_ms_total": round(sum(T.values()), 1)}))

@@ -34,7 +34,7 @@ for it in range(2):
         best = (wall, T)
 wall, T = best
 from halo2_vectordb_amd.rounds import quotient_identity_holds
-identity = quotient_identity_holds(pr, out["challenges"], out["evals"])
+identity = quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
 cells = hp.n_cells + hp.n_lookup
 print(json.dumps({"workload": f"kmeans K=4 I={I} 256x128 k=16", "advice_columns": pr.n_adv, "lookup_columns": pr.n_lk, "product_columns": pr.n_sets + pr.n_lk,
                   "cells": cells, "quotient_identity_at_x_holds": bool(identity), "setup_s": round(t_setup, 1), "wall_ms": round(wall, 1), "device_ms": {k: round(v, 2) for k, v in T.items()},

@@ -200,11 +200,23 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
     return copy_of, int(digest[0]), np.sort(np.concatenate(init_cells))
 
 
-def mapping_from_copy_of(copy_of, break_points, n_cols, rows):
+def lookup_sources(flags, n_lookup):
+    """For every cell of the lookup stream (cells_to_lookup: copies of advice cells, laid out in the lookup columns) the
+    stream offset of the advice cell it copies, from a keygen-style run's flag bytes: the kernels mark those cells with bit 2
+    in the order they queue them (gadgets.hpp r_range_check).  Raises when the counts differ — a circuit that looks a cell
+    up that was assigned somewhere else (a range check of at most lookup_bits bits) is not covered."""
+    src = np.flatnonzero(np.asarray(flags, dtype=np.uint8) & 4).astype(np.int64)
+    if src.size != n_lookup:
+        raise ValueError(f"{src.size} advice cells are marked as lookup sources for {n_lookup} lookup cells")
+    return src
+
+
+def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, lookup_rows=None):
     """Permutation over an n_cols x rows grid (words col << 32 | row, the identity where nothing is tied) from a copy map
     over the stream cells that fill the first len(break_points) + 1 columns: every set of cells that copy one another
     (directly or through other copies) becomes one cycle, and the overlap cell that ends column c is the cell that starts
-    column c + 1."""
+    column c + 1.  `lookup_src` (with `lookup_rows` cells per lookup column): lookup cell j, at row j % lookup_rows of column
+    n_adv + j // lookup_rows, joins the cycle of the advice cell lookup_src[j]."""
     copy_of = np.asarray(copy_of, dtype=np.int64)
     bp = np.asarray(break_points, dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(bp)])
@@ -223,6 +235,11 @@ def mapping_from_copy_of(copy_of, break_points, n_cols, rows):
     pos_col = np.concatenate([col, dup_col])
     pos_row = np.concatenate([row, bp[: dup_s.size]])
     pos_root = np.concatenate([root, root[dup_s]])
+    if lookup_src is not None and len(lookup_src):
+        j = np.arange(len(lookup_src), dtype=np.int64)
+        pos_col = np.concatenate([pos_col, bp.size + 1 + j // lookup_rows])
+        pos_row = np.concatenate([pos_row, j % lookup_rows])
+        pos_root = np.concatenate([pos_root, root[np.asarray(lookup_src, dtype=np.int64)]])
     order = np.lexsort((pos_row, pos_col, pos_root))
     pc, prw, pr = pos_col[order], pos_row[order], pos_root[order]
     first = np.concatenate([[True], pr[1:] != pr[:-1]])

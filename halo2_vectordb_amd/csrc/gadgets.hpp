@@ -81,6 +81,11 @@ struct WCtx {
     if (!count_only && pos > 0 && in_window(pos - 1) && lpos >= rllo && lpos < rlhi) lk[lpos] = v;
     lpos++;
   }
+  // keygen-style runs only (sel != null): bit 2 of the flag byte marks the advice cell at `p` as the cell a lookup cell copies
+  // (cells_to_lookup holds copies of advice cells; the j-th marked cell in stream order is the source of lookup cell j)
+  HD void mark_lookup_source(uint64_t p) {
+    if (sel && !count_only && in_window(p) && in_rank(p)) sel[p] |= 4;
+  }
   // true when a sub-gadget of `cells` advice cells (and `lks` lookup cells) starting here cannot touch the windows
   HD bool skip(uint32_t cells, uint32_t lks = 0) const {
     if (count_only) return false;
@@ -259,7 +264,7 @@ struct Gadgets {
     const uint32_t L = T.L, k = (bits + L - 1) / L, rem = bits % L;
     u256 last;
     if (k == 1) {
-      c.lookup(a);
+      c.lookup(a);  // (the source is the cell that holds `a`, somewhere earlier: not marked — copymap refuses such circuits)
       last = a;
     } else {
       // inner_product(limbs, [1, 2^L, 2^2L, ...]) starting with the constant 1:
@@ -268,6 +273,7 @@ struct Gadgets {
       const uint32_t lmask = (1u << L) - 1u;
       u256 rem = ac;
       u256 s = limb_mont(rem.w[0] & lmask);
+      const uint64_t p0 = c.pos;  // limb 0 sits here, limb i at p0 + 1 + 3 (i - 1)
       c.push(s, true);
       for (uint32_t i = 1; i < k; i++) {
         rem = u256_shr_small(rem, L);
@@ -280,6 +286,7 @@ struct Gadgets {
       }
       rem = ac;
       for (uint32_t i = 0; i < k; i++) {
+        c.mark_lookup_source(i ? p0 + 1 + 3 * (uint64_t)(i - 1) : p0);
         c.lookup(limb_mont(rem.w[0] & lmask));
         rem = u256_shr_small(rem, L);
       }
@@ -288,6 +295,7 @@ struct Gadgets {
       g_assert_bit(last);
     } else if (rem > 1) {
       u256 chk = g_mul(last, T.pow2[L - rem]);
+      c.mark_lookup_source(c.pos - 1);
       c.lookup(chk);
       last = chk;
     }

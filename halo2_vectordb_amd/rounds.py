@@ -125,7 +125,7 @@ class ProverRounds:
         return p
 
     # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
-    def keygen(self, copy_of=None, instance_cells=None):
+    def keygen(self, copy_of=None, instance_cells=None, tie_lookups=True):
         """`copy_of`: optional copy map over the stream cells (copy_of[i] = the earlier cell that cell i copies, i itself
         otherwise) to tie in the permutation argument besides the cells the layout duplicates.  For the Merkle circuit it is
         built here (copymap.merkle_copy_map) unless given; the k-means / nearest gadgets' own maps are not built.
@@ -150,6 +150,14 @@ class ProverRounds:
             flags_h[init_cells] |= 2              # the sponge's initial state: pinned by the constants gate below like any constant
             d_flags.upload(flags_h)
             self.n_pinned_init = int(init_cells.size)
+        # the lookup columns hold copies of advice cells (cells_to_lookup): tie every lookup cell to the cell it copies, so that
+        # the range checks the lookup argument proves are range checks of the advice cells
+        self.lookup_src = None
+        if hp.n_lookup and tie_lookups:
+            from .copymap import lookup_sources
+            self.lookup_src = lookup_sources(d_flags.download((hp.n_cells,), dtype=np.uint8), hp.n_lookup)
+            if copy_of is None:
+                copy_of = np.arange(hp.n_cells, dtype=np.int64)
         self.copy_of = copy_of
         self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # constant cells as a gate: qc = one where a column holds a QuantumCell::Constant, fc = the constant there (from this
@@ -174,7 +182,8 @@ class ProverRounds:
         # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
         if copy_of is not None:
             from .copymap import mapping_from_copy_of
-            mapping = mapping_from_copy_of(copy_of, hp.bp, self.n_cols, rows)
+            from .pipeline import MINIMUM_ROWS
+            mapping = mapping_from_copy_of(copy_of, hp.bp, self.n_cols, rows, self.lookup_src, rows - MINIMUM_ROWS)
         else:
             mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
             for c in range(self.n_adv - 1):

@@ -573,3 +573,39 @@ def test_copy_constraints_are_enforced(O):
     hp.free()
     assert results["full map"] == (False, False)
     assert results["layout ties only"] == (True, True)
+
+
+def test_lookup_cells_are_tied_to_the_advice_cells_they_copy(circuit, O):
+    """cells_to_lookup holds copies of advice cells: keygen marks the sources (flag bit 2) and ties every lookup cell to its
+    source through the permutation argument.  On a real k-means witness every lookup cell equals its source; and a witness
+    whose lookup column is given a different (still in-table) value no longer proves, whereas it does when the ties are left out
+    — a range check that is not tied to the cell it checks proves nothing about it."""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    hp, pr = circuit
+    assert pr.lookup_src is not None and len(pr.lookup_src) == hp.n_lookup and (np.diff(pr.lookup_src) > 0).all()
+    hp._witness()
+    api.sync()
+    stream, lookup = hp.d_stream.download((hp.n_cells, 4)), hp.d_lookup.download((hp.n_lookup, 4))
+    assert np.array_equal(lookup, stream[pr.lookup_src])
+    honest = hp._witness
+    swapped = O.fr_from_ints([(O.fr_to_ints(lookup[5].reshape(1, 4))[0] + 1) % (1 << hp.L)])       # another value of the table
+
+    def tampered(sel=None):
+        honest(sel)
+        if sel is None:
+            hp.d_lookup.upload(swapped, offset=5 * 32)
+
+    loose = ProverRounds(hp).keygen(tie_lookups=False)
+    results = {}
+    try:
+        for label, p in (("tied", pr), ("untied", loose)):
+            hp._witness = tampered
+            try:
+                bad = p.prove(None, seed=2)
+            finally:
+                hp._witness = honest
+            results[label] = quotient_identity_holds(p, bad["challenges"], bad["evals"], bad["instances"])
+    finally:
+        loose.free()
+    assert results == {"tied": False, "untied": True}

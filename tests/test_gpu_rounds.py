@@ -609,3 +609,22 @@ def test_lookup_cells_are_tied_to_the_advice_cells_they_copy(circuit, O):
     finally:
         loose.free()
     assert results == {"tied": False, "untied": True}
+
+
+def test_rounds_on_a_nearest_vector_circuit(O):
+    """the same rounds, copy ties (layout + lookup sources) and verifier on nearest_vector (query + 12 vectors of 6 words)"""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    hp = NearestHotPath(n=12, dim=6, k=12, L=11, tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.n_lk >= 1 and len(pr.lookup_src) == hp.n_lookup
+        out = pr.prove(None, seed=6)
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
+                  instances=out["instances"])
+        assert _verify(O, api, out["proof"], vk)
+    finally:
+        pr.free()
+        hp.free()

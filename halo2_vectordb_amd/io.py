@@ -88,3 +88,42 @@ def read_pinning(path):
     if len(bp) and int(bp.max()) >= rows:
         raise ValueError("break point beyond the column height")
     return params, bp
+
+
+# ---------------------------------------------------------------- proof file (the reference writes data/{name}.snark, src/scaffold/mod.rs:292-297)
+SNARK_MAGIC = b"VDBSNARK1\n"
+
+
+def write_snark(path, proof, instances):
+    """The Prove arm's output file in this build's own container (upstream's is a bincode dump of snark-verifier's Snark struct —
+    protocol, instances, proof —, not reproduced: parity unpinned): magic, the number of public inputs, each as 32 little-endian
+    bytes of the canonical value, then the proof bytes as the transcript wrote them."""
+    with open(path, "wb") as f:
+        f.write(SNARK_MAGIC)
+        f.write(len(instances).to_bytes(4, "little"))
+        for v in instances:
+            f.write(int(v).to_bytes(32, "little"))
+        f.write(len(proof).to_bytes(8, "little"))
+        f.write(proof)
+
+
+def read_snark(path):
+    """-> (proof bytes, instances as integers); raises ValueError on a malformed file"""
+    with open(path, "rb") as f:
+        data = f.read()
+    if not data.startswith(SNARK_MAGIC):
+        raise ValueError("not a proof file of this build")
+    pos = len(SNARK_MAGIC)
+    if len(data) < pos + 4:
+        raise ValueError("truncated proof file")
+    n = int.from_bytes(data[pos: pos + 4], "little")
+    pos += 4
+    if len(data) < pos + 32 * n + 8:
+        raise ValueError("truncated proof file")
+    instances = [int.from_bytes(data[pos + 32 * i: pos + 32 * i + 32], "little") for i in range(n)]
+    pos += 32 * n
+    m = int.from_bytes(data[pos: pos + 8], "little")
+    pos += 8
+    if len(data) != pos + m:
+        raise ValueError("proof length does not match the file")
+    return data[pos:], instances

@@ -484,6 +484,13 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
               tau_h=PR.pt_mul(PR.G2, TAU))
     proof = out["proof"]
     assert _verify(O, api, proof, vk)
+    # through the proof file the Prove arm leaves behind (io.write_snark / read_snark)
+    from halo2_vectordb_amd.io import read_snark, write_snark
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        write_snark(os.path.join(d, "kmeans.snark"), proof, out["instances"])
+        proof_f, inst_f = read_snark(os.path.join(d, "kmeans.snark"))
+    assert proof_f == proof and _verify(O, api, proof_f, {**vk, "instances": inst_f})
     n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 4
     for where in (5, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 64 + 7, len(proof) - 20):    # a commitment, h, an evaluation, W1, W2
         bad = bytearray(proof)

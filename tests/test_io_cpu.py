@@ -83,3 +83,17 @@ def test_chacha20_rng_and_srs_scalar():
     nonce_as_stream = int.from_bytes(bytes.fromhex("0000004a00000000"), "little")
     blk = chacha20_block(key, 1 | (0x09000000 << 32), nonce_as_stream)
     assert blk[:16].hex() == "10f1e7e4d13b5915500fdd1fa32071c4"
+
+
+def test_snark_file_round_trip(tmp_path):
+    from halo2_vectordb_amd.io import read_snark, write_snark
+    proof, inst = bytes(range(256)) * 3, [5, (1 << 253) + 17]
+    write_snark(tmp_path / "p.snark", proof, inst)
+    assert read_snark(tmp_path / "p.snark") == (proof, inst)
+    write_snark(tmp_path / "e.snark", b"", [])
+    assert read_snark(tmp_path / "e.snark") == (b"", [])
+    raw = (tmp_path / "p.snark").read_bytes()
+    for bad in (raw[:-1], raw + b"x", b"junk" + raw, raw[:12]):
+        (tmp_path / "bad.snark").write_bytes(bad)
+        with pytest.raises(ValueError):
+            read_snark(tmp_path / "bad.snark")

@@ -76,10 +76,13 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     t0 = time.perf_counter()
     c.assign_witnesses(qv)
     c.kmeans(hp.metric_name, qv, hp.K, 1, P=hp.P, L=hp.L)
-    c.advice()
+    adv = c.advice()
     t_wit = time.perf_counter() - t0
     cells_one_iter = len(c) + c.n_lookup
-    del c
+    # the cells of the first iteration are a prefix of the I-iteration streams: compare them with what the GPU emitted
+    lk = c.lookup()
+    wit_parity = bool(np.array_equal(hp.d_stream.download((len(adv), 4)), adv) and np.array_equal(hp.d_lookup.download((len(lk), 4)), lk))
+    del c, adv, lk
     # commit + NTT on a sample of the real columns, all cores
     t0 = time.perf_counter()
     want = O.msm_batch(cols_sample, hp.g_lagrange, threads=cores)
@@ -96,7 +99,8 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
         "sample": (f"oracle C restatement: 1 of {hp.I} k-means iterations of witness gen single-threaded ({t_wit:.2f} s, "
                    f"{cells_one_iter} cells), Pippenger MSM + iNTT/coset-NTT of {ns} of {hp.n_cols} real columns on {cores} threads "
                    f"({t_msm:.2f} s + {t_ntt:.2f} s), extrapolated linearly to the full job"),
-        "est_full_job_s": t_full, "commitment_parity_on_sample": parity,
+        "est_full_job_s": t_full, "commitment_parity_on_sample": parity, "witness_parity_on_sample": wit_parity,
+        "witness_cells_compared": cells_one_iter,
     }
 
 
@@ -142,57 +146,72 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
+    from halo2_vectordb_amd.pipeline import gather_commitments
+    dev = None
+    if dist is not None:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def one_step(timings=None):
+        """one pass of the hot path; with N > 1 it ends with the path's one exchange step, the all_gather of the 64-byte
+        commitments of every rank's column shard (every rank then holds what the transcript absorbs next)"""
+        com = hp.step(timings)
+        if dist is not None:
+            com = gather_commitments(dist, com, hp.shards, dev)
+        return com
+
     for _ in range(args.warmup):
-        hp.step()
+        one_step()
     barrier()
     timings = {}
+    # HIP events around every kernel launch of the timed steps, on the stream each launch goes to, read after the
+    # region has drained (vdb_profile_begin_deferred): the kernels run and overlap exactly as they do unprofiled
+    api.profile_begin(deferred=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        hp.step(timings)
+        commitments = one_step(timings)
     barrier()
     elapsed = time.perf_counter() - t0
-    commitments = hp.commitments
+    prof = api.profile_end()
     if dist is not None:
         import torch
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the one real exchange step: gather the 64-byte commitments of every rank's column shard
-        from halo2_vectordb_amd.pipeline import gather_commitments
-        commitments = gather_commitments(dist, commitments, hp.shards, dev)
 
     total_cells = hp.n_cells + hp.n_lookup
     ms_per_step = elapsed / args.steps * 1e3
     value = total_cells * args.steps / elapsed
     stage_ms = {k: v / args.steps for k, v in timings.items()}
 
-    # ---- dominant kernel: HIP-event timing per launch (separate, untimed pass) ------------------
+    # ---- dominant kernel: HIP-event durations of its launches inside the timed region ------------
     roofline = None
     cpu = None
     if rank == 0:
-        api.profile_begin()
-        hp.step()
-        prof = api.profile_end()
+        for rec in prof.values():                       # totals over the timed steps -> per step
+            rec["ms"] /= args.steps
+            rec["launches"] //= args.steps
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         name, rec = dom
         avg_ms = rec["ms"] / rec["launches"]
         n = hp.rows
-        # algorithmic bytes per launch (DESIGN.md "Kernels and rooflines")
+        # algorithmic bytes per step of the dominant kernel's launches (SURVEY 8(d) per-unit figures; DESIGN.md section 4)
         if name == "k_ntt_pass":
-            # one transform moves 64 B per element; a launch is one of the passes of one transform
-            # over a chunk of columns: iNTT 2^16 has 2 passes, coset NTT 2^18 has 3 (5 launches / chunk set)
-            elems = hp.my_cols * (n + 4 * n)
-            algo_bytes = 64.0 * elems / rec["launches"]
+            # per column: lagrange_to_coeff = one NTT of size n, 64 n B (read + write once); coeff_to_extended = coset
+            # extension n -> 4n, 32 n B read + 128 n B written: 224 n B per column, whatever the number of passes
+            algo_step = 224.0 * n * hp.my_cols
         elif name in ("k_msm_accum", "k_msm_sort", "k_msm_reduce"):
-            algo_bytes = (32.0 * n * hp.my_cols + 64.0 * n) / rec["launches"]
+            algo_step = 32.0 * n * hp.my_cols + 64.0 * n
         else:
-            algo_bytes = 32.0 * total_cells / rec["launches"]
+            algo_step = 32.0 * total_cells
+        algo_bytes = algo_step / rec["launches"]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic_per_launch(name)
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                    "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_step": algo_step,
                     "avg_launch_ms": avg_ms, "launches_per_step": rec["launches"],
+                    "timing": "HIP events around every launch of the timed steps, on the launch's own stream (deferred read-out)",
                     "note": "integer-ALU bound (254-bit Montgomery products on v_mad_u64_u32); see valu",
                     "kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
         try:

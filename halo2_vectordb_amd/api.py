@@ -608,8 +608,9 @@ def timer_stop():
     return ms.value
 
 
-def profile_begin():
-    check(_lib.init().vdb_profile_begin())
+def profile_begin(deferred=False):
+    """deferred: do not wait for each launch; the events are read in profile_end (kernels run as in the untimed path)"""
+    check(_lib.init().vdb_profile_begin_deferred() if deferred else _lib.init().vdb_profile_begin())
 
 
 def profile_end():

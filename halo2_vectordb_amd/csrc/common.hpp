@@ -1,5 +1,5 @@
-// Shared host-side plumbing of libvdb_hip: process-wide context (one GPU per process), error
-// reporting across the C ABI, scratch allocation.
+// Shared host-side plumbing of libvdb_hip: one context per bound GPU (vdb_init binds one, vdb_init_devices several; a host
+// thread works on the device it selected with vdb_set_device), error reporting across the C ABI, scratch allocation.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -27,6 +27,8 @@ struct Context {
   bool msm_pending = false;       // a deferred MSM has not been collected yet
   const void* msm_counters = nullptr;
   const void* msm_out = nullptr;  // device buffer the deferred MSM writes its points to
+  void* msm_out_buf = nullptr;    // its allocation (grow-only; not one of the shared scratch slots)
+  size_t msm_out_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int cu_count = 256;
   // twiddle tables keyed by (log_n, first limb words of omega): tw[e] = omega^e, e < n
@@ -42,9 +44,21 @@ struct Context {
   // grow-only scratch buffers
   void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // device-resident caches owned by other translation units; released through their hooks in vdb_shutdown
+  std::map<uint64_t, void*> fp_tables;   // witness.hip: FixedPointChip tables keyed by (P, L)
+  void* poseidon_spec = nullptr;          // poseidon.hip: device copy of the Poseidon spec
+  bool ntt_lds_raised = false;            // ntt.hip: hipFuncAttributeMaxDynamicSharedMemorySize raised on this device
+  uint64_t win[4] = {0, ~0ull, 0, ~0ull}; // witness.hip: rank window of the *_dev witness entry points (vdb_wit_set_window)
 };
 
+#define VDB_MAX_DEVICES 16
+// the context of the device the calling thread works on: the one it chose with vdb_set_device, else the process default
+// (the device of the last vdb_init, device 0 after vdb_init_devices)
 Context& ctx();
+// makes that device the calling thread's current HIP device (HIP's current device is per thread)
+int bind_thread();
+void witness_release(Context& c);   // witness.hip
+void poseidon_release(Context& c);  // poseidon.hip
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // returns nullptr (and sets error) on failure
@@ -62,6 +76,7 @@ void* scratch_get(int slot, size_t bytes);
       vdb::set_error("vdb_init() has not been called (or failed)"); \
       return VDB_ERR_NOT_INIT;                                        \
     }                                                                 \
+    if (int _rc = vdb::bind_thread()) return _rc;                     \
   } while (0)
 
 #define VDB_ARG(cond, msg)       \
@@ -89,26 +104,39 @@ __device__ __forceinline__ u256 colsrc_fetch(const ColSrc& cs, uint64_t i, uint6
 static inline const u256* as_u256(const vdb_fr* p) { return reinterpret_cast<const u256*>(p); }
 static inline u256* as_u256(vdb_fr* p) { return reinterpret_cast<u256*>(p); }
 
-// Optional per-kernel timing with HIP events on the library stream (vdb_profile_begin/_end).  Off in
-// the timed path; bench.py turns it on for one extra pass to measure the dominant kernel's duration.
+// Optional per-kernel timing with HIP events (vdb_profile_begin / _begin_deferred / _end).  Two modes:
+//   1 "synchronous": every launch is waited for (kernels run one at a time; the deferred MSM tail runs on the main stream);
+//   2 "deferred":    events are recorded around every launch on the stream it goes to and only read in vdb_profile_end,
+//                    after the work has drained — the kernels run exactly as in the untimed path (overlap included), which is
+//                    what bench.py uses inside its timed region.
 struct ProfEntry {
   double ms = 0;
   uint64_t launches = 0;
 };
-extern bool g_prof_on;
+struct ProfPending {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+extern int g_prof_mode;
 extern std::map<std::string, ProfEntry> g_prof;
+extern std::vector<ProfPending> g_prof_pending;
 struct ProfScope {
   const char* name;
+  hipStream_t st;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  explicit ProfScope(const char* n) : name(n) {
-    if (!g_prof_on) return;
+  explicit ProfScope(const char* n, hipStream_t s = nullptr) : name(n), st(s ? s : ctx().stream) {
+    if (!g_prof_mode) return;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, ctx().stream);
+    (void)hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx().stream);
+    (void)hipEventRecord(e1, st);
+    if (g_prof_mode == 2) {
+      g_prof_pending.push_back({name, e0, e1});
+      return;
+    }
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -120,6 +148,7 @@ struct ProfScope {
   }
 };
 #define VDB_PROF(name) vdb::ProfScope _prof_scope_(name)
+#define VDB_PROF_ON(name, stream) vdb::ProfScope _prof_scope_(name, stream)
 
 // Fr domain constants computed on the host with the same field code
 u256 host_root_of_unity(uint32_t k);  // ROOT_OF_UNITY^(2^(28-k)), Montgomery

@@ -4,12 +4,24 @@
 
 namespace vdb {
 
-static Context g_ctx;
+static Context g_ctxs[VDB_MAX_DEVICES];
+static int g_default = 0;               // device of the last vdb_init (0 after vdb_init_devices)
+static thread_local int t_cur = -1;     // device this thread chose with vdb_set_device (-1: the process default)
+static thread_local int t_hip_dev = -1; // HIP's current device on this thread, as far as this library set it
 static thread_local char g_err[512] = "";
 
-Context& ctx() { return g_ctx; }
-bool g_prof_on = false;
+Context& ctx() { return g_ctxs[t_cur >= 0 ? t_cur : g_default]; }
+int bind_thread() {
+  const int d = ctx().device;
+  if (t_hip_dev != d) {
+    VDB_HIP(hipSetDevice(d));
+    t_hip_dev = d;
+  }
+  return VDB_OK;
+}
+int g_prof_mode = 0;
 std::map<std::string, ProfEntry> g_prof;
+std::vector<ProfPending> g_prof_pending;
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -22,6 +34,11 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 void* scratch_get(int slot, size_t bytes) {
   Context& c = ctx();
+  if (slot == 2 && c.msm_pending) {
+    // the bucket folding of an open deferred MSM is still working in this slot on the second stream
+    set_error("scratch slot 2 belongs to the open deferred MSM: call vdb_msm_batch_end first");
+    return nullptr;
+  }
   if (c.scratch_bytes[slot] >= bytes) return c.scratch[slot];
   if (c.scratch[slot]) (void)hipFree(c.scratch[slot]);
   c.scratch[slot] = nullptr;
@@ -163,18 +180,11 @@ int vdb_device_count(void) {
 const char* vdb_version(void) { return "halo2-vectordb_amd 0.1 (gfx950)"; }
 const char* vdb_last_error(void) { return g_err; }
 
-int vdb_init(int device) {
-  Context& c = ctx();
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n == 0) {
-    set_error("no HIP device visible (hipGetDeviceCount: %s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
-    return VDB_ERR_NO_DEVICE;
-  }
-  VDB_ARG(device >= 0 && device < n, "device index out of range");
-  if (c.ready && c.device == device) return VDB_OK;
-  if (c.ready) vdb_shutdown();
+static int init_context(int device) {
+  Context& c = g_ctxs[device];
+  if (c.ready) return VDB_OK;
   VDB_HIP(hipSetDevice(device));
+  t_hip_dev = device;
   VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   VDB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
   VDB_HIP(hipEventCreateWithFlags(&c.ev_tail, hipEventDisableTiming));
@@ -187,12 +197,15 @@ int vdb_init(int device) {
   c.ready = true;
   return VDB_OK;
 }
-void vdb_shutdown(void) {
-  Context& c = ctx();
+static void shutdown_context(int device) {
+  Context& c = g_ctxs[device];
   if (!c.ready) return;
+  if (hipSetDevice(device) == hipSuccess) t_hip_dev = device;
   (void)hipStreamSynchronize(c.stream);
   (void)hipStreamSynchronize(c.aux);
   c.msm_pending = false;
+  c.msm_counters = nullptr;
+  c.msm_out = nullptr;
   for (auto& kv : c.twiddles) (void)hipFree(kv.second);
   c.twiddles.clear();
   for (int i = 0; i < 6; i++) {
@@ -200,12 +213,73 @@ void vdb_shutdown(void) {
     c.scratch[i] = nullptr;
     c.scratch_bytes[i] = 0;
   }
+  if (c.msm_out_buf) (void)hipFree(c.msm_out_buf);
+  c.msm_out_buf = nullptr;
+  c.msm_out_bytes = 0;
+  witness_release(c);
+  poseidon_release(c);
+  c.ntt_lds_raised = false;
+  c.win[0] = 0, c.win[1] = ~0ull, c.win[2] = 0, c.win[3] = ~0ull;
   (void)hipEventDestroy(c.ev0);
   (void)hipEventDestroy(c.ev1);
   (void)hipEventDestroy(c.ev_tail);
   (void)hipStreamDestroy(c.aux);
   (void)hipStreamDestroy(c.stream);
   c.ready = false;
+  c.device = -1;
+}
+static int visible_devices(int* n) {
+  *n = 0;
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess || *n == 0) {
+    set_error("no HIP device visible (hipGetDeviceCount: %s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return VDB_ERR_NO_DEVICE;
+  }
+  if (*n > VDB_MAX_DEVICES) *n = VDB_MAX_DEVICES;
+  return VDB_OK;
+}
+
+int vdb_init(int device) {
+  int n = 0;
+  if (int rc = visible_devices(&n)) return rc;
+  VDB_ARG(device >= 0 && device < n, "device index out of range");
+  // one process, one GPU: whatever else was bound is released
+  for (int d = 0; d < VDB_MAX_DEVICES; d++)
+    if (d != device) shutdown_context(d);
+  if (int rc = init_context(device)) return rc;
+  g_default = device;
+  t_cur = device;
+  return bind_thread();
+}
+int vdb_init_devices(int n_devices) {
+  int n = 0;
+  if (int rc = visible_devices(&n)) return rc;
+  VDB_ARG(n_devices >= 1 && n_devices <= n, "n_devices must be between 1 and the number of visible devices");
+  for (int d = n_devices; d < VDB_MAX_DEVICES; d++) shutdown_context(d);
+  for (int d = 0; d < n_devices; d++)
+    if (int rc = init_context(d)) return rc;
+  g_default = 0;
+  t_cur = 0;
+  return bind_thread();
+}
+int vdb_devices_bound(void) {
+  int n = 0;
+  for (int d = 0; d < VDB_MAX_DEVICES; d++) n += g_ctxs[d].ready ? 1 : 0;
+  return n;
+}
+int vdb_set_device(int device) {
+  if (device < 0 || device >= VDB_MAX_DEVICES || !g_ctxs[device].ready) {
+    set_error("vdb_set_device: device %d has not been bound (vdb_init / vdb_init_devices)", device);
+    return VDB_ERR_ARG;
+  }
+  t_cur = device;
+  return bind_thread();
+}
+int vdb_current_device(void) { return ctx().ready ? ctx().device : -1; }
+void vdb_shutdown(void) {
+  for (int d = 0; d < VDB_MAX_DEVICES; d++) shutdown_context(d);
+  t_cur = -1;
+  g_default = 0;
 }
 int vdb_malloc(void** dptr, size_t bytes) {
   VDB_REQUIRE_INIT();
@@ -320,14 +394,44 @@ int vdb_bench_fr_mul(size_t threads, size_t iters, double* mul_per_sec) {
   return VDB_OK;
 }
 
+static void prof_drop_pending() {
+  for (auto& pp : g_prof_pending) {
+    (void)hipEventDestroy(pp.e0);
+    (void)hipEventDestroy(pp.e1);
+  }
+  g_prof_pending.clear();
+}
 int vdb_profile_begin(void) {
   VDB_REQUIRE_INIT();
   g_prof.clear();
-  g_prof_on = true;
+  prof_drop_pending();
+  g_prof_mode = 1;
+  return VDB_OK;
+}
+int vdb_profile_begin_deferred(void) {
+  VDB_REQUIRE_INIT();
+  g_prof.clear();
+  prof_drop_pending();
+  g_prof_mode = 2;
   return VDB_OK;
 }
 int vdb_profile_end(char* json_out, size_t cap) {
-  g_prof_on = false;
+  const int mode = g_prof_mode;
+  g_prof_mode = 0;
+  if (mode == 2) {
+    // every recorded launch has to have finished before its events can be read
+    (void)hipStreamSynchronize(ctx().stream);
+    (void)hipStreamSynchronize(ctx().aux);
+    for (auto& pp : g_prof_pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pp.e0, pp.e1) == hipSuccess) {
+        ProfEntry& pe = g_prof[pp.name];
+        pe.ms += ms;
+        pe.launches += 1;
+      }
+    }
+  }
+  prof_drop_pending();
   VDB_ARG(json_out && cap > 2, "null buffer");
   std::string js = "{";
   bool first = true;

@@ -29,7 +29,10 @@ struct vdb_srs {
   size_t n;
   uint32_t c, W, B;
   vdb::Affine* table[2];  // [0] monomial, [1] lagrange; each W * n points
+  int device;             // the GPU whose HBM holds the tables
 };
+// a handle only works on the device it was loaded on (the calling thread's current one: vdb_set_device)
+#define VDB_SRS_HERE(srs) VDB_ARG((srs)->device == vdb::ctx().device, "this srs handle was loaded on another device (vdb_set_device)")
 
 namespace vdb {
 
@@ -702,7 +705,7 @@ static uint32_t pick_window(uint32_t k) {
 int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t n_cols, size_t n, Affine* out_dev, const uint8_t* skip_mask = nullptr,
                   const Affine* add_points = nullptr, bool defer_tail = false, const ColSrc* srcs = nullptr, uint32_t n_blind = 0) {
   Context& cx = ctx();
-  if (g_prof_on) defer_tail = false;  // per-kernel timing serialises on the main stream
+  if (g_prof_mode == 1) defer_tail = false;  // per-kernel timing serialises on the main stream
   if (cx.msm_pending) {
     set_error("msm: a deferred batch has not been collected (vdb_msm_batch_end)");
     return VDB_ERR_ARG;
@@ -784,13 +787,13 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       uint32_t max_nt = (uint32_t)range_cap_col + 1, passes = 0;
       while ((1u << passes) < max_nt) passes++;
       for (uint32_t ps = 0; ps < passes; ps++) {
-        VDB_PROF("k_msm_combine");
+        VDB_PROF_ON("k_msm_combine", ts);
         hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(cx.cu_count * 8)), dim3(256), 0, ts, partials, seginfo, counters, ps, seg_cap);
       }
       VDB_LAUNCH_CHECK();
     }
     {
-      VDB_PROF("k_msm_reduce");
+      VDB_PROF_ON("k_msm_reduce", ts);
       hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)nc), dim3(64), 0, ts, partials, seg_off, c, counters, add_points ? add_points + c0 : nullptr, out_dev + c0);
     }
     VDB_LAUNCH_CHECK();
@@ -868,6 +871,7 @@ int vdb_srs_load_window(uint32_t k, const vdb_g1* g, const vdb_g1* g_lagrange, u
   VDB_ARG(window_bits == 0 || (window_bits >= 2 && window_bits <= 14), "window_bits must be 0 (default) or 2..14");
   Context& cx = ctx();
   vdb_srs* s = new vdb_srs();
+  s->device = cx.device;
   s->k = k;
   s->n = (size_t)1 << k;
   s->c = window_bits ? window_bits : pick_window(k);
@@ -922,8 +926,11 @@ int vdb_g1_sum(const vdb_g1* parts, size_t m, size_t n, vdb_g1* out) {
 }
 void vdb_srs_free(vdb_srs* s) {
   if (!s) return;
+  int cur = -1;
+  const bool hop = hipGetDevice(&cur) == hipSuccess && cur != s->device && hipSetDevice(s->device) == hipSuccess;
   for (int b = 0; b < 2; b++)
     if (s->table[b]) (void)hipFree(s->table[b]);
+  if (hop) (void)hipSetDevice(cur);
   delete s;
 }
 int vdb_srs_info(const vdb_srs* s, uint32_t* k, uint32_t* window_bits, uint32_t* windows) {
@@ -934,9 +941,27 @@ int vdb_srs_info(const vdb_srs* s, uint32_t* k, uint32_t* window_bits, uint32_t*
   return VDB_OK;
 }
 
+// The results of a deferred batch stay in a buffer of their own until vdb_msm_batch_end: the shared scratch slots remain
+// free for whatever the caller queues in between (slot 2, where the batch's bucket folding is still at work on the second
+// stream, is refused to everybody else while the batch is open: scratch_get).
+static void* deferred_out(size_t bytes) {
+  Context& c = ctx();
+  if (c.msm_out_bytes >= bytes && c.msm_out_buf) return c.msm_out_buf;
+  if (c.msm_out_buf) (void)hipFree(c.msm_out_buf);
+  c.msm_out_buf = nullptr;
+  c.msm_out_bytes = 0;
+  hipError_t e = hipMalloc(&c.msm_out_buf, bytes + bytes / 8 + 64);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipMalloc(deferred MSM output)", __FILE__, __LINE__);
+    return nullptr;
+  }
+  c.msm_out_bytes = bytes + bytes / 8 + 64;
+  return c.msm_out_buf;
+}
 int vdb_msm_batch_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, vdb_g1* out_host) {
   VDB_REQUIRE_INIT();
   VDB_ARG(srs && scalars_dev && out_host && (basis == 0 || basis == 1), "bad argument");
+  VDB_SRS_HERE(srs);
   VDB_ARG(srs->table[basis], "srs was loaded without this basis");
   VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size (shorter columns are allowed)");
   if (n_cols == 0) return VDB_OK;
@@ -951,6 +976,7 @@ int vdb_msm_batch_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, 
 int vdb_msm_count_entries_dev(const vdb_srs* srs, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev, uint64_t* counts_out) {
   VDB_REQUIRE_INIT();
   VDB_ARG(srs && scalars_dev && counts_out && n <= srs->n, "bad argument");
+  VDB_SRS_HERE(srs);
   if (n_cols == 0) return VDB_OK;
   Context& cx = ctx();
   unsigned long long* d = (unsigned long long*)scratch_get(2, n_cols * sizeof(unsigned long long));
@@ -969,11 +995,12 @@ int vdb_msm_batch_masked_dev_begin(const vdb_srs* srs, int basis, const vdb_fr* 
                                    const vdb_g1* const_points_dev) {
   VDB_REQUIRE_INIT();
   VDB_ARG(srs && scalars_dev && (basis == 0 || basis == 1), "bad argument");
+  VDB_SRS_HERE(srs);
   VDB_ARG(srs->table[basis], "srs was loaded without this basis");
   VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size");
   VDB_ARG((skip_mask_dev == nullptr) == (const_points_dev == nullptr), "mask and constant points go together");
   if (n_cols == 0) return VDB_OK;
-  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  Affine* dout = (Affine*)deferred_out(n_cols * sizeof(Affine));
   if (!dout) return VDB_ERR_OOM;
   ctx().msm_out = dout;
   int rc = msm_batch_dev(srs, basis, as_u256(scalars_dev), n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev), true);
@@ -984,11 +1011,12 @@ int vdb_msm_batch_src_dev_begin(const vdb_srs* srs, int basis, const vdb_colsrc*
                                 const uint8_t* skip_mask_dev, const vdb_g1* const_points_dev) {
   VDB_REQUIRE_INIT();
   VDB_ARG(srs && src_dev && (basis == 0 || basis == 1), "bad argument");
+  VDB_SRS_HERE(srs);
   VDB_ARG(srs->table[basis], "srs was loaded without this basis");
   VDB_ARG(n <= srs->n && n > 0 && n_blind <= n, "n exceeds the loaded SRS size");
   VDB_ARG((skip_mask_dev == nullptr) == (const_points_dev == nullptr), "mask and constant points go together");
   if (n_cols == 0) return VDB_OK;
-  Affine* dout = (Affine*)scratch_get(1, n_cols * sizeof(Affine));
+  Affine* dout = (Affine*)deferred_out(n_cols * sizeof(Affine));
   if (!dout) return VDB_ERR_OOM;
   ctx().msm_out = dout;
   int rc = msm_batch_dev(srs, basis, nullptr, n_cols, n, dout, skip_mask_dev, reinterpret_cast<const Affine*>(const_points_dev), true,
@@ -1012,6 +1040,7 @@ int vdb_msm_batch_masked_dev(const vdb_srs* srs, int basis, const vdb_fr* scalar
                              const vdb_g1* const_points_dev, vdb_g1* out_host) {
   VDB_REQUIRE_INIT();
   VDB_ARG(srs && scalars_dev && out_host && (basis == 0 || basis == 1) && skip_mask_dev && const_points_dev, "bad argument");
+  VDB_SRS_HERE(srs);
   VDB_ARG(srs->table[basis], "srs was loaded without this basis");
   VDB_ARG(n <= srs->n && n > 0, "n exceeds the loaded SRS size");
   if (n_cols == 0) return VDB_OK;

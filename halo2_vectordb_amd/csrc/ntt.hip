@@ -23,6 +23,7 @@ namespace vdb {
 #define NTT_THREADS 256
 #define NTT_TILE 1024
 #define NTT_MAX_PASSES 4
+#define NTT_DEFAULT_COLGROUP 0x7fffffffu  // tile-major over all columns of a launch (measured equal to column-major within noise; 4x less twiddle refetch)
 
 struct NttPass {
   uint32_t log_n, S, log_inner, logG;
@@ -38,6 +39,10 @@ struct NttPass {
   uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
   const ColSrc* srcs;             // pass 0 only: columns still lying in a witness stream (null: read `in`)
   uint32_t n_blind;
+  uint32_t n_cols;                // columns of this launch
+  uint32_t col_group;             // 0: workgroups run column after column; g > 0: inside groups of g columns they run tile
+                                  // after tile (the same tile of all g columns back to back), so a tile's 32-B inter-pass
+                                  // twiddles and stage twiddles are L2 hits for every column after the first on an XCD
   u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery (zeta^-1 = zeta^2: the same two serve coset_out)
   uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
 };
@@ -109,7 +114,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   D.c = reinterpret_cast<uint32_t*>(W.b + NW);
   W.c = D.c + NE;
   const uint32_t tid = threadIdx.x;
-  const uint32_t col = blockIdx.x / tiles_per_col, tile = blockIdx.x % tiles_per_col;
+  uint32_t col, tile;
+  if (p.col_group == 0) {
+    col = blockIdx.x / tiles_per_col;
+    tile = blockIdx.x % tiles_per_col;
+  } else {
+    const uint32_t per_group = p.col_group * tiles_per_col;
+    const uint32_t grp = blockIdx.x / per_group, r = blockIdx.x % per_group;
+    const uint32_t left = p.n_cols - grp * p.col_group, ncg = left < p.col_group ? left : p.col_group;
+    col = grp * p.col_group + r % ncg;
+    tile = r / ncg;
+  }
   const u256* cin = in + (size_t)col * p.in_stride;
   ColSrc csrc;
   const bool from_src = p.first && p.srcs != nullptr;
@@ -415,6 +430,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     scratch = (u256*)scratch_get(3, chunk_cols * n * sizeof(u256));
     if (!scratch) return VDB_ERR_OOM;
   }
+  // launch order of the non-last passes (VDB_NTT_COLGROUP: 0 = column after column)
+  static const uint32_t col_group = getenv("VDB_NTT_COLGROUP") ? (uint32_t)strtoul(getenv("VDB_NTT_COLGROUP"), nullptr, 10) : NTT_DEFAULT_COLGROUP;
   for (size_t c0 = 0; c0 < n_cols; c0 += chunk_cols) {
     size_t nc = n_cols - c0 < chunk_cols ? n_cols - c0 : chunk_cols;
     uint32_t done_bits = 0;
@@ -425,15 +442,17 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.S = S[l];
       p.log_inner = log_n - done_bits - S[l];
       p.first = (l == 0);
+      const bool last = (l == L - 1);
       p.coset = (l == 0 && coset_in);
       p.in_len = in_len;
       p.srcs = (l == 0 && srcs) ? srcs + c0 : nullptr;
       p.n_blind = n_blind;
+      p.n_cols = (uint32_t)nc;
+      p.col_group = last ? 0u : (col_group < nc ? col_group : (uint32_t)nc);  // the last pass reads no inter-pass twiddles
       p.zeta1 = z1;
       p.zeta2 = z2;
       p.fin = fin;
       memcpy(p.ckp, ckp, sizeof(ckp));
-      bool last = (l == L - 1);
       p.scale = last && scale_ninv && L == 1;
       p.coset_out = last && coset_out;
       // zero-padded input (coeff_to_extended): when rows of pass 0 run along the top digit and only their first
@@ -503,7 +522,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       size_t lds = (size_t)(G * (m + 1) + (m / 2 ? m / 2 : 1)) * (2 * sizeof(uint4) + sizeof(uint32_t));
       dim3 grid((unsigned)(nc * tiles));
       if (lds > 64 * 1024) {
-        static bool raised = false;
+        bool& raised = c.ntt_lds_raised;  // per device: the attribute belongs to the device's code object
         if (!raised) {
           VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
           VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

@@ -201,18 +201,20 @@ void poseidon_build_spec(PoseidonSpec* out) {
 }
 
 static PoseidonSpec g_spec_host;
-static PoseidonSpec* g_spec_dev = nullptr;
-static bool g_spec_built = false;
+static std::once_flag g_spec_once;
+void poseidon_release(Context& c) {
+  if (c.poseidon_spec) (void)hipFree(c.poseidon_spec);
+  c.poseidon_spec = nullptr;
+}
+// the host copy is built once per process, the device copy once per bound device (Context::poseidon_spec)
 int poseidon_spec_dev(const PoseidonSpec** dev_out, const PoseidonSpec** host_out) {
-  if (!g_spec_built) {
-    poseidon_build_spec(&g_spec_host);
-    g_spec_built = true;
+  std::call_once(g_spec_once, [] { poseidon_build_spec(&g_spec_host); });
+  Context& c = ctx();
+  if (dev_out && !c.poseidon_spec) {
+    VDB_HIP(hipMalloc(&c.poseidon_spec, sizeof(PoseidonSpec)));
+    VDB_HIP(hipMemcpy(c.poseidon_spec, &g_spec_host, sizeof(PoseidonSpec), hipMemcpyHostToDevice));
   }
-  if (!g_spec_dev) {
-    VDB_HIP(hipMalloc(&g_spec_dev, sizeof(PoseidonSpec)));
-    VDB_HIP(hipMemcpy(g_spec_dev, &g_spec_host, sizeof(PoseidonSpec), hipMemcpyHostToDevice));
-  }
-  if (dev_out) *dev_out = g_spec_dev;
+  if (dev_out) *dev_out = static_cast<const PoseidonSpec*>(c.poseidon_spec);
   if (host_out) *host_out = &g_spec_host;
   return VDB_OK;
 }

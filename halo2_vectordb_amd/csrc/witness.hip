@@ -57,7 +57,16 @@ struct FpEntry {
   FpTables* dev;
   u256* limb_tab;
 };
-static std::map<uint64_t, FpEntry*> g_fp;
+// cached per device in Context::fp_tables (released by witness_release on vdb_shutdown)
+void witness_release(Context& c) {
+  for (auto& kv : c.fp_tables) {
+    FpEntry* e = static_cast<FpEntry*>(kv.second);
+    if (e->limb_tab) (void)hipFree(e->limb_tab);
+    if (e->dev) (void)hipFree(e->dev);
+    delete e;
+  }
+  c.fp_tables.clear();
+}
 
 __global__ void k_limb_table(u256* tab, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,12 +83,30 @@ static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
     return VDB_ERR_ARG;
   }
   uint64_t key = ((uint64_t)P << 32) | L;
-  auto it = g_fp.find(key);
-  if (it != g_fp.end()) {
-    *out = it->second;
+  auto& cache = ctx().fp_tables;
+  auto it = cache.find(key);
+  if (it != cache.end()) {
+    *out = static_cast<FpEntry*>(it->second);
     return VDB_OK;
   }
+  // owned by the cache from here on, so that an error path below leaks nothing (vdb_shutdown frees what was allocated)
   FpEntry* e = new FpEntry();
+  e->dev = nullptr;
+  e->limb_tab = nullptr;
+  cache[key] = e;
+  struct Guard {
+    std::map<uint64_t, void*>& cache;
+    uint64_t key;
+    FpEntry* e;
+    bool keep = false;
+    ~Guard() {
+      if (keep) return;
+      if (e->limb_tab) (void)hipFree(e->limb_tab);
+      if (e->dev) (void)hipFree(e->dev);
+      cache.erase(key);
+      delete e;
+    }
+  } guard{cache, key, e};
   FpTables& T = e->host;
   memset(&T, 0, sizeof(T));
   T.P = P;
@@ -120,7 +147,7 @@ static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
   VDB_HIP(hipMalloc(&e->dev, sizeof(FpTables)));
   VDB_HIP(hipMemcpyAsync(e->dev, &T, sizeof(FpTables), hipMemcpyHostToDevice, ctx().stream));
   VDB_HIP(hipStreamSynchronize(ctx().stream));
-  g_fp[key] = e;
+  guard.keep = true;
   *out = e;
   return VDB_OK;
 }
@@ -1142,12 +1169,12 @@ int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, S
 
 using namespace vdb;
 
-// rank window applied by the *_dev witness entry points (vdb_wit_set_window); full range by default
-static uint64_t g_win[4] = {0, ~0ull, 0, ~0ull};
+// rank window applied by the *_dev witness entry points (vdb_wit_set_window); full range by default; per device context
+#define g_win (vdb::ctx().win)
 
 // break points and their prefix sums (column c starts at stream cell starts[c]) -> device scratch slot 1
 static int upload_break_points(const uint64_t* break_points, uint64_t n_bp, uint64_t** dbp, uint64_t** dstarts) {
-  static std::vector<uint64_t> h;  // pageable source: hipMemcpyAsync stages it before returning
+  static thread_local std::vector<uint64_t> h;  // pageable source: hipMemcpyAsync stages it before returning
   h.resize(2 * n_bp + 2);
   uint64_t acc = 0;
   h[n_bp] = 0;

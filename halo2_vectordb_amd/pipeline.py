@@ -148,9 +148,12 @@ class KmeansHotPath:
     """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
 
     def __init__(self, n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="euclidean", seed=20260004, tau=None,
-                 col_shard=(0, 1)):
+                 col_shard=(0, 1), vectors=None):
         """`tau`: toxic-waste scalar of the "unsafe" SRS as a canonical integer; None = the scalar the reference's
-        `gen_srs(k)` derives from its fixed ChaCha20 seed (srs.gen_srs_tau, src/scaffold/mod.rs:260)."""
+        `gen_srs(k)` derives from its fixed ChaCha20 seed (srs.gen_srs_tau, src/scaffold/mod.rs:260).
+        `vectors`: the f64 rows the circuit assigns first (the `--input` file of the reference's examples,
+        src/scaffold/mod.rs:64-77); None = the seeded SIFT-shaped synthetic rows of SURVEY 8(d)."""
+        self.given_vectors = None if vectors is None else np.ascontiguousarray(vectors, dtype=np.float64)
         self.n, self.dim, self.K, self.I, self.k, self.P, self.L = n, dim, K, I, k, P, L
         self.metric = api.METRICS[metric]
         self.metric_name = metric
@@ -171,7 +174,8 @@ class KmeansHotPath:
         points are used as they are — the Prove arm of the reference (src/scaffold/mod.rs:285-287) — after checking that
         they describe this circuit; otherwise they are derived from the keygen-style run, like the Keygen arm."""
         lib, n, dim, K, I = self.lib, self.n, self.dim, self.K, self.I
-        vec, self.seed = self._input_vectors()
+        vec, self.seed = self._input_vectors() if self.given_vectors is None else (self.given_vectors, self.seed)
+        assert vec.shape == (self.n_input_rows(), self.dim), "input rows do not match the circuit's shape"
         self.vectors_f64 = vec
         self.qvec = api.quantize(vec, self.P)
         self.n_in, n_gadget_cells, self.n_lookup = self._circuit_size()
@@ -295,6 +299,9 @@ class KmeansHotPath:
     def _input_vectors(self):
         """(f64 rows that ctx.assign_witnesses puts at the head of the stream, seed actually used)"""
         return sift_like_vectors(self.seed, self.n, self.dim, self.K)
+
+    def n_input_rows(self):
+        return self.n
 
     def _circuit_size(self):
         """(cells of ctx.assign_witnesses(quantize_vector(v)) for every vector, cells the gadget emits, lookup cells)"""
@@ -435,8 +442,8 @@ class MerkleHotPath(KmeansHotPath):
     column counts per rank are balanced already; a rank that holds a block of columns traces only the permutations whose
     cells fall into it (the sponge states and the tree's digests are computed by every rank, value only)."""
 
-    def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1)):
-        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard)
+    def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1), vectors=None):
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors)
         self.balance_shards = False
         self.msm_window_bits = 14   # every scalar is a full-width Poseidon state: 19 windows instead of 24
 
@@ -477,9 +484,13 @@ class NearestHotPath(KmeansHotPath):
     vectors) through the same hot path.  The running minimum is one chain over all vectors, so every rank emits the whole
     witness and takes its block of columns."""
 
-    def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1)):
-        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard)
+    def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1), vectors=None):
+        """`vectors`: (n + 1, dim) f64 rows, the query first"""
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors)
         self.shard_witness = False
+
+    def n_input_rows(self):
+        return self.n + 1
 
     def _input_vectors(self):
         vec, seed = sift_like_vectors(self.seed, self.n, self.dim)

@@ -71,6 +71,9 @@ int vdb_timer_stop(float *ms_out);
 /* per-kernel HIP-event timing: between begin and end every kernel launch of the library is bracketed by
  * events on its stream (serialising them); end returns {"kernel": {"ms": total, "launches": n}, ...} */
 int vdb_profile_begin(void);
+/* the same without serialising: events are recorded on the stream each launch goes to and read in vdb_profile_end, so
+ * the kernels run (and overlap) exactly as they do untimed — what bench.py uses inside its timed region */
+int vdb_profile_begin_deferred(void);
 int vdb_profile_end(char *json_out, size_t cap);
 
 /* ---- field helpers (tests / staging) -------------------------------------------------------- */

@@ -10,8 +10,8 @@ advice / lookup-advice column (MSM, Lagrange basis) -> lagrange_to_coeff (iNTT 2
 
 metric = constraints/sec where a constraint is one advice cell or one lookup cell of the halo2-base
 flat stream.  Multi-GPU: columns are sharded over ranks (strong scaling; every rank walks the
-cheap value-only path of the whole circuit but emits only the cells of its own columns), commitments
-all-gathered over RCCL.
+cheap value-only path of the whole circuit but emits only the cells of its own columns); every timed step ends
+with the path's one exchange step, the all_gather of the 64-byte commitments over RCCL.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced problem for quick functional checks (not a valid bench line)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the timed steps rank 0 re-runs the job unsharded and checks the gathered commitments against it (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +138,8 @@ def main():
     cfg = dict(n=256, dim=128, K=4, I=8, k=16, P=48, L=15)
     if args.small:
         cfg = dict(n=32, dim=16, K=2, I=2, k=12, P=48, L=11)
+    if args.verify_gather:
+        cfg["blind_seed"] = 20260004     # the sharded and the unsharded run must blind alike to be compared (test hook)
     hp = KmeansHotPath(col_shard=(rank, world), **cfg).setup()
 
     def barrier():
@@ -177,6 +181,13 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    gather_ok = None
+    if args.verify_gather and rank == 0:
+        whole = KmeansHotPath(col_shard=(0, 1), **cfg).setup()
+        gather_ok = bool(np.array_equal(whole.step(), commitments))
+        whole.free()
+        assert gather_ok, "the gathered commitments of the sharded job differ from the unsharded job's"
 
     total_cells = hp.n_cells + hp.n_lookup
     ms_per_step = elapsed / args.steps * 1e3
@@ -249,6 +260,8 @@ def main():
             "proof_stage_ms": stage_ms,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if gather_ok is not None:
+            out["gathered_commitments_match_unsharded_job"] = gather_ok
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

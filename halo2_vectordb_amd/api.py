@@ -39,6 +39,23 @@ def device_count():
     return _lib.load().vdb_device_count()
 
 
+def init_devices(n):
+    """Bind GPUs 0 .. n-1 in this process (vdb_init_devices); this thread works on device 0 until set_device."""
+    return _lib.init_devices(n)
+
+
+def set_device(device):
+    check(_lib.load().vdb_set_device(int(device)))
+
+
+def current_device():
+    return _lib.load().vdb_current_device()
+
+
+def devices_bound():
+    return _lib.load().vdb_devices_bound()
+
+
 # ---------------------------------------------------------------- field helpers
 def _binop(name, a, b):
     L = _lib.init()
@@ -159,6 +176,53 @@ class Srs:
             self.free()
         except Exception:
             pass
+
+
+class SrsAll:
+    """One Srs handle per bound device, the bases replicated (vdb_srs_load_all); commits batches of columns over all of them."""
+
+    def __init__(self, k, g=None, g_lagrange=None, window_bits=0):
+        self.L = _lib.init()
+        self.k = k
+        n = devices_bound()
+        self.handles = (ctypes.c_void_p * n)()
+        ga = np.ascontiguousarray(g, dtype=np.uint64) if g is not None else None
+        gl = np.ascontiguousarray(g_lagrange, dtype=np.uint64) if g_lagrange is not None else None
+        check(self.L.vdb_srs_load_all(ctypes.c_uint32(k), _p(ga) if ga is not None else None, _p(gl) if gl is not None else None,
+                                      ctypes.c_uint32(window_bits), self.handles, n))
+
+    def devices(self):
+        out = []
+        for h in self.handles:
+            d = ctypes.c_int(-1)
+            check(self.L.vdb_srs_device(h, ctypes.byref(d)))
+            out.append(d.value)
+        return out
+
+    def msm_batch(self, cols, basis=1):
+        """cols: (n_cols, n, 4) host scalars -> (n_cols, 8): device i commits the i-th contiguous block of the columns"""
+        cols = _fr(cols)
+        n_cols, n = cols.shape[0], cols.shape[1]
+        out = np.zeros((n_cols, 8), dtype=np.uint64)
+        check(self.L.vdb_msm_batch_multi(self.handles, len(self.handles), ctypes.c_int(basis), _col_ptrs([cols[i] for i in range(n_cols)]),
+                                         _sz(n_cols), _sz(n), _p(out)))
+        return out
+
+    def free(self):
+        for i, h in enumerate(self.handles):
+            if h:
+                self.L.vdb_srs_free(h)
+                self.handles[i] = None
+
+
+def ntt_batch_multi(cols, omega, flags=0):
+    """ntt_batch with the columns cut into one block per bound device"""
+    L = _lib.init()
+    cols = np.array(cols, dtype=np.uint64, copy=True)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    omega = _fr(omega)
+    check(L.vdb_ntt_batch_multi(_col_ptrs([cols[i] for i in range(n_cols)]), _sz(n_cols), ctypes.c_uint32(n.bit_length() - 1), _p(omega), ctypes.c_int(flags)))
+    return cols
 
 
 def srs_setup_unsafe(k, tau_mont):
@@ -337,6 +401,22 @@ def poseidon_permute(states):
     s = np.array(states, dtype=np.uint64, copy=True)
     check(L.vdb_poseidon_permute(_p(s), _sz(s.size // 12)))
     return s
+
+
+def random_scalars_dev(dst_ptr, n, seed=None):
+    """n uniformly random field elements written to device memory at dst_ptr: 64 bytes of entropy each, reduced mod r on
+    the device (vdb_fr_from_wide_dev = halo2curves Fr::random).  seed=None draws from the operating system (os.urandom), as
+    halo2's prover does for its blinding scalars; an integer seed gives a reproducible stream (tests only)."""
+    import os
+    lib = _lib.init()
+    raw = os.urandom(64 * n) if seed is None else np.random.default_rng(seed).bytes(64 * n)
+    wide = DeviceBuffer(max(64 * n, 64))
+    try:
+        wide.upload(np.frombuffer(raw, dtype=np.uint8))
+        check(lib.vdb_fr_from_wide_dev(wide.ptr, _sz(n), dst_ptr))
+        sync()        # `wide` is freed on return
+    finally:
+        wide.free()
 
 
 # ---------------------------------------------------------------- device buffers

@@ -57,6 +57,7 @@ struct Context {
 Context& ctx();
 // makes that device the calling thread's current HIP device (HIP's current device is per thread)
 int bind_thread();
+bool context_ready(int device);
 void witness_release(Context& c);   // witness.hip
 void poseidon_release(Context& c);  // poseidon.hip
 void set_error(const char* fmt, ...);

@@ -11,6 +11,7 @@ static thread_local int t_hip_dev = -1; // HIP's current device on this thread, 
 static thread_local char g_err[512] = "";
 
 Context& ctx() { return g_ctxs[t_cur >= 0 ? t_cur : g_default]; }
+bool context_ready(int device) { return device >= 0 && device < VDB_MAX_DEVICES && g_ctxs[device].ready; }
 int bind_thread() {
   const int d = ctx().device;
   if (t_hip_dev != d) {
@@ -112,6 +113,15 @@ __global__ __launch_bounds__(256) void k_batch_invert(const u256* __restrict__ i
       acc = fr_mul(acc, x);
     }
   }
+}
+
+// out[i] = (the 512-bit little-endian integer wide[i]) mod r in Montgomery form: how halo2curves' Fr::random / from_u512 turns
+// 64 bytes of entropy into a statistically uniform scalar (lo R2 + hi R3 in its terms)
+__global__ __launch_bounds__(256) void k_from_wide(const u256* __restrict__ wide, u256* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u256 lo = ld256(wide + 2 * i), hi = ld256(wide + 2 * i + 1);
+  st256(out + i, fr_add(to_mont<Fr>(lo), to_mont<Fr>(to_mont<Fr>(hi))));
 }
 
 // 4 independent dependency chains per thread so the measurement is throughput-, not latency-bound
@@ -370,6 +380,15 @@ int vdb_fr_batch_invert(const vdb_fr* in, vdb_fr* out, size_t n) {
   VDB_LAUNCH_CHECK();
   VDB_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c.stream));
   VDB_HIP(hipStreamSynchronize(c.stream));
+  return VDB_OK;
+}
+
+int vdb_fr_from_wide_dev(const uint8_t* wide_dev, size_t n, vdb_fr* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(wide_dev && out_dev, "null pointer");
+  if (n == 0) return VDB_OK;
+  hipLaunchKernelGGL(k_from_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, reinterpret_cast<const u256*>(wide_dev), as_u256(out_dev), n);
+  VDB_LAUNCH_CHECK();
   return VDB_OK;
 }
 

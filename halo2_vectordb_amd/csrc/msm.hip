@@ -933,6 +933,11 @@ void vdb_srs_free(vdb_srs* s) {
   if (hop) (void)hipSetDevice(cur);
   delete s;
 }
+int vdb_srs_device(const vdb_srs* s, int* device) {
+  VDB_ARG(s && device, "null pointer");
+  *device = s->device;
+  return VDB_OK;
+}
 int vdb_srs_info(const vdb_srs* s, uint32_t* k, uint32_t* window_bits, uint32_t* windows) {
   VDB_ARG(s, "null srs");
   if (k) *k = s->k;

@@ -148,11 +148,17 @@ class KmeansHotPath:
     """kmeans::<K, I> over N x D vectors at 2^k rows: witness -> layout -> commit -> NTT, one GPU."""
 
     def __init__(self, n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="euclidean", seed=20260004, tau=None,
-                 col_shard=(0, 1), vectors=None):
+                 col_shard=(0, 1), vectors=None, blind_seed=None):
         """`tau`: toxic-waste scalar of the "unsafe" SRS as a canonical integer; None = the scalar the reference's
         `gen_srs(k)` derives from its fixed ChaCha20 seed (srs.gen_srs_tau, src/scaffold/mod.rs:260).
         `vectors`: the f64 rows the circuit assigns first (the `--input` file of the reference's examples,
-        src/scaffold/mod.rs:64-77); None = the seeded SIFT-shaped synthetic rows of SURVEY 8(d)."""
+        src/scaffold/mod.rs:64-77); None = the seeded SIFT-shaped synthetic rows of SURVEY 8(d).
+        `blind_seed`: None = the blinding rows of every column are drawn afresh from the operating system's entropy for every
+        proof (step), as halo2's create_proof does with its OsRng (reached from src/scaffold/mod.rs:296); an integer fixes
+        them — a test hook for comparing commitments across runs, never for real proofs (two proofs that share blinds leak
+        the difference of their witnesses)."""
+        self.blind_seed = blind_seed
+        self._entropy = None
         self.given_vectors = None if vectors is None else np.ascontiguousarray(vectors, dtype=np.float64)
         self.n, self.dim, self.K, self.I, self.k, self.P, self.L = n, dim, K, I, k, P, L
         self.metric = api.METRICS[metric]
@@ -250,12 +256,10 @@ class KmeansHotPath:
         else:
             self.win_adv = (0, 0)
         self.win_lk = (self.l_lo * max_rows, min(self.l_hi * max_rows, self.n_lookup)) if self.my_lk else (0, 0)
-        rng = np.random.default_rng(self.seed + 7)
-        raw = rng.integers(0, 1 << 62, size=(self.n_cols * N_BLIND, 4), dtype=np.int64).astype(object)
-        blind = from_ints([(int(r[0]) | int(r[1]) << 62 | int(r[2]) << 124 | int(r[3]) << 186) % R for r in raw])
-        self.blind = blind  # treated as Montgomery representatives: any value < r is a valid field element
-        self.d_blind = api.DeviceBuffer(blind.nbytes)
-        self.d_blind.upload(blind)
+        # N_BLIND blinding scalars per column, uniform in Fr: 64 bytes of entropy each, reduced on the device
+        self.d_blind = api.DeviceBuffer(self.n_cols * N_BLIND * B)
+        self.d_wide = api.DeviceBuffer(self.n_cols * N_BLIND * 64)
+        self.refresh_blinds()
         self.d_cols = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * B)
         # column descriptors of my [advice block | lookup block]: where each column lies in the streams (data independent)
         self.d_src = api.DeviceBuffer(max(self.my_cols, 1) * 24)
@@ -294,6 +298,21 @@ class KmeansHotPath:
         d_fmask.free()
         api.sync()
         return self
+
+    # ------------------------------------------------------------------ blinding
+    def _draw_entropy(self, seed):
+        import os
+        nbytes = self.n_cols * N_BLIND * 64
+        return os.urandom(nbytes) if seed is None else np.random.default_rng(seed).bytes(nbytes)
+
+    def refresh_blinds(self, seed=None):
+        """New blinding rows for every column (halo2: Blind(Scalar::random(OsRng)) per committed polynomial).  The bytes for
+        the next proof are drawn while the GPU is busy with this one (step()), so a refresh costs one small upload."""
+        seed = self.blind_seed if seed is None else seed
+        raw = self._entropy if (seed is None and self._entropy is not None) else self._draw_entropy(seed)
+        self._entropy = None
+        self.d_wide.upload(np.frombuffer(raw, dtype=np.uint8))
+        check(self.lib.vdb_fr_from_wide_dev(self.d_wide.ptr, ctypes.c_size_t(self.n_cols * N_BLIND), self.d_blind.ptr))
 
     # ------------------------------------------------------------------ what is specific to the k-means circuit
     def _input_vectors(self):
@@ -355,8 +374,9 @@ class KmeansHotPath:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
     # ------------------------------------------------------------------ one pass of the hot path
-    def step(self, timings=None):
+    def step(self, timings=None, blind_seed=None):
         lib, B = self.lib, 32
+        self.refresh_blinds(blind_seed)
 
         def stage(name, fn):
             if timings is not None:
@@ -382,17 +402,23 @@ class KmeansHotPath:
             else:
                 check(lib.vdb_msm_batch_masked_dev_begin(self.srs.h, 1, my, ctypes.c_size_t(self.my_cols), ctypes.c_size_t(self.rows), mask, cpts))
 
-        stage("commit_msm", commit)
-
         def ntt():
             if virt:
                 check(lib.vdb_lagrange_to_coeff_src_dev(self.d_src.ptr, my, ctypes.c_size_t(self.my_cols), self.k, N_BLIND))
             else:
                 check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
             check(lib.vdb_coeff_to_extended_dev(my, self.d_ext.ptr, ctypes.c_size_t(self.my_cols), self.k, 2))
+            if self.blind_seed is None and blind_seed is None:
+                self._entropy = self._draw_entropy(None)      # the next proof's blinds, drawn while the GPU works on this one
             check(lib.vdb_msm_batch_end(api._p(self.commitments), ctypes.c_size_t(self.my_cols)))
 
-        stage("ntt", ntt)
+        stage("commit_msm", commit)
+        try:
+            stage("ntt", ntt)
+        except Exception:
+            # a deferred MSM must always be collected, or every later MSM is refused ("deferred batch has not been collected")
+            lib.vdb_msm_batch_end(None, ctypes.c_size_t(0))
+            raise
         api.sync()
         return self.commitments
 
@@ -428,7 +454,7 @@ class KmeansHotPath:
         return cent, ind
 
     def free(self):
-        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_cols", "d_ext", "d_mask", "d_cpts", "d_src"):
+        for name in ("d_vec", "d_stream", "d_lookup", "d_cent", "d_ind", "d_blind", "d_wide", "d_cols", "d_ext", "d_mask", "d_cpts", "d_src"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()
@@ -442,8 +468,8 @@ class MerkleHotPath(KmeansHotPath):
     column counts per rank are balanced already; a rank that holds a block of columns traces only the permutations whose
     cells fall into it (the sponge states and the tree's digests are computed by every rank, value only)."""
 
-    def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1), vectors=None):
-        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors)
+    def __init__(self, n=1024, dim=128, k=15, P=32, seed=20260003, tau=None, col_shard=(0, 1), vectors=None, blind_seed=None):
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=8, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors, blind_seed=blind_seed)
         self.balance_shards = False
         self.msm_window_bits = 14   # every scalar is a full-width Poseidon state: 19 windows instead of 24
 
@@ -484,9 +510,10 @@ class NearestHotPath(KmeansHotPath):
     vectors) through the same hot path.  The running minimum is one chain over all vectors, so every rank emits the whole
     witness and takes its block of columns."""
 
-    def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1), vectors=None):
+    def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1), vectors=None, blind_seed=None):
         """`vectors`: (n + 1, dim) f64 rows, the query first"""
-        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors)
+        super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors,
+                         blind_seed=blind_seed)
         self.shard_witness = False
 
     def n_input_rows(self):

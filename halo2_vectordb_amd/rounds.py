@@ -102,12 +102,14 @@ class ProverRounds:
         check(self.lib.vdb_msm_batch_dev(srs.h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
         return out
 
-    def _blind(self, buf, n_cols, from_row, rng):
+    def _blind(self, buf, n_cols, from_row, seed):
+        """uniform field elements into the rows from `from_row` on of every column (halo2 fills them with Scalar::random(rng)
+        from OsRng): 64 bytes of entropy each, reduced on the device; `seed` = None draws from the operating system"""
         cnt = self.rows - from_row
-        raw = rng.integers(0, 1 << 62, size=(n_cols * cnt, 4), dtype=np.uint64)
-        raw[:, 3] &= np.uint64((1 << 61) - 1)                                      # any value below r is a field element
-        d = api.DeviceBuffer(raw.nbytes)
-        d.upload(raw)
+        if n_cols * cnt == 0:
+            return
+        d = api.DeviceBuffer(n_cols * cnt * B)
+        api.random_scalars_dev(d.ptr, n_cols * cnt, seed=seed)
         check(self.lib.vdb_fill_rows_dev(buf.ptr, _sz(n_cols), _sz(self.rows), _sz(from_row), d.ptr))
         api.sync()
         d.free()
@@ -291,7 +293,7 @@ class ProverRounds:
         return self._alloc_working_set()
 
     # ------------------------------------------------------------------ the rounds
-    def prove(self, challenges=None, seed=1, timings=None, multiopen="shplonk", instances=None):
+    def prove(self, challenges=None, seed=None, timings=None, multiopen="shplonk", instances=None):
         """challenges: dict of Montgomery field elements beta, gamma, y, x, v, or None to derive them with the Fiat–Shamir
         transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the fixed commitments
         (in place of the verifying key's digest); advice commitments -> theta (squeezed as halo2 does, unused: the lookups
@@ -302,9 +304,11 @@ class ProverRounds:
         `instances`: the public values of keygen's instance cells (Montgomery field elements); None = read from the witness
         this proof commits to (the honest prover's statement).
         Returns dict(commitments, evals, openings, points, proof, instances): commitments[name] (n, 8); evals[(name, rotation)] list
-        of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W)."""
+        of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W).
+        `seed`: None = every blinding scalar of this proof (advice, lookup and product columns) comes fresh from the
+        operating system's entropy, as in halo2's create_proof; an integer makes the proof reproducible (tests)."""
         hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
-        rng = np.random.default_rng(seed)
+        seeds = iter([None] * 8 if seed is None else [[int(seed), i] for i in range(1, 9)])
         tr = api.Transcript() if challenges is None else None
         ch = {} if challenges is None else {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
         p = {name: api._p(v) for name, v in ch.items()}
@@ -333,7 +337,7 @@ class ProverRounds:
             return r
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
-        adv_commits = hp.step(T).copy()
+        adv_commits = hp.step(T, blind_seed=None if seed is None else [int(seed), 0]).copy()
         if instances is None:
             instances = [hp.d_stream.download((4,), offset=cell * 32) for cell in self.instance_cells]
         instances = [np.ascontiguousarray(v, dtype=np.uint64) for v in instances]
@@ -360,8 +364,8 @@ class ProverRounds:
         def permute():
             check(lib.vdb_lookup_permute_dev(lk_lag, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
         stage("lookup_permute", permute)
-        self._blind(d_pa, n_lk, usable, rng)
-        self._blind(d_ps, n_lk, usable, rng)
+        self._blind(d_pa, n_lk, usable, next(seeds))
+        self._blind(d_ps, n_lk, usable, next(seeds))
         polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1, dense=False)))
         polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1, dense=False)))
         if n_lk:
@@ -379,8 +383,8 @@ class ProverRounds:
             check(lib.vdb_lookup_product_dev(lk_lag, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
                                              d_zl.ptr))
         stage("products", products)
-        self._blind(d_zp, n_sets, usable + 1, rng)
-        self._blind(d_zl, n_lk, usable + 1, rng)
+        self._blind(d_zp, n_sets, usable + 1, next(seeds))
+        self._blind(d_zl, n_lk, usable + 1, next(seeds))
         polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
         polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit(d_zl, n_lk, 1)))
         write_points(polys["zp"].commits)

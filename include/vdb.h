@@ -46,10 +46,21 @@ enum {
 };
 
 /* ---- b0 lifecycle -------------------------------------------------------------------------- */
-/* Binds this process to HIP device `device` and creates streams/workspaces.  Fails loudly with
- * VDB_ERR_NO_DEVICE when no GPU is visible: there is NO CPU fallback in this library. */
+/* Binds this process to HIP device `device` and creates streams/workspaces (whatever was bound before is released).
+ * Fails loudly with VDB_ERR_NO_DEVICE when no GPU is visible: there is NO CPU fallback in this library. */
 int vdb_init(int device);
-void vdb_shutdown(void);
+/* binds devices 0 .. n_devices-1 in ONE process, each with its own context (streams, workspaces, twiddle and
+ * gadget tables).  A host thread works on the device it selected with vdb_set_device (thread-local; device 0 until then);
+ * device pointers, vdb_srs handles and deferred MSMs belong to the device they were created on.  The path shards by
+ * column with no exchange between devices: the *_multi entry points below cut a batch of columns into one
+ * block per device and return every device's results D2H; no RCCL communicator is needed for that.  The other supported
+ * arrangement is one process per GPU (vdb_init(local_rank), torch.distributed / RCCL all_gather of the commitments:
+ * bench.py). */
+int vdb_init_devices(int n_devices);
+int vdb_devices_bound(void);      /* number of bound devices */
+int vdb_set_device(int device);   /* the calling thread works on this (bound) device from now on */
+int vdb_current_device(void);     /* -1 when nothing is bound */
+void vdb_shutdown(void);          /* releases every bound device */
 const char *vdb_last_error(void);
 int vdb_device_count(void);
 const char *vdb_version(void);
@@ -77,6 +88,10 @@ int vdb_profile_begin_deferred(void);
 int vdb_profile_end(char *json_out, size_t cap);
 
 /* ---- field helpers (tests / staging) -------------------------------------------------------- */
+/* out[i] = (64 little-endian bytes wide[64 i ..]) mod r, Montgomery: Fr::random / Fr::from_u512 of halo2curves — how the
+ * prover's blinding scalars are drawn from OS entropy (halo2 create_proof: Blind(Scalar::random(rng)), reached from
+ * src/scaffold/mod.rs:296).  Device pointers; asynchronous on the library stream. */
+int vdb_fr_from_wide_dev(const uint8_t *wide_dev, size_t n, vdb_fr *out_dev);
 int vdb_fr_from_canonical(const vdb_fr *in, vdb_fr *out, size_t n);
 int vdb_fr_to_canonical(const vdb_fr *in, vdb_fr *out, size_t n);
 int vdb_fr_mul(const vdb_fr *a, const vdb_fr *b, vdb_fr *out, size_t n);
@@ -194,6 +209,7 @@ void vdb_srs_free(vdb_srs *srs);
  * combine step of a point-sharded MSM — each GPU commits its slice of the rows of every column against the matching slice of
  * the bases, the partial commitments are all-gathered and added.  RCCL has no curve reduction operator. */
 int vdb_g1_sum(const vdb_g1 *parts, size_t m, size_t n, vdb_g1 *out);
+int vdb_srs_device(const vdb_srs *srs, int *device); /* the device whose HBM holds the handle's tables */
 int vdb_srs_info(const vdb_srs *srs, uint32_t *k, uint32_t *window_bits, uint32_t *windows);
 
 /* ---- b2 MSM: replaces halo2 arithmetic::best_multiexp(&[Fr], &[G1Affine]) -> G1 and
@@ -202,6 +218,12 @@ int vdb_srs_info(const vdb_srs *srs, uint32_t *k, uint32_t *window_bits, uint32_
  *      affine, identity = (0,0).  n <= 2^k scalars use the first n bases. ------------------------- */
 int vdb_msm(const vdb_srs *srs, int basis, const vdb_fr *scalars, size_t n, vdb_g1 *out);
 int vdb_msm_batch(const vdb_srs *srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
+/* The same over every device bound by vdb_init_devices (columns are independent, the bases are replicated):
+ * vdb_srs_load_all builds one handle per bound device (out[i] belongs to the i-th bound device, n_out = vdb_devices_bound());
+ * vdb_msm_batch_multi gives device i the i-th contiguous block of the columns, one host thread per device, results D2H into
+ * out[] in column order.  With one bound device they reduce to the calls above. */
+int vdb_srs_load_all(uint32_t k, const vdb_g1 *g, const vdb_g1 *g_lagrange, uint32_t window_bits, vdb_srs **out, int n_out);
+int vdb_msm_batch_multi(vdb_srs *const *srs, int n_srs, int basis, const vdb_fr *const *cols, size_t n_cols, size_t n, vdb_g1 *out);
 /* scalars_dev: contiguous n_cols x n in HBM; out_host: n_cols points */
 int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, vdb_g1 *out_host);
 /* Deferred form of vdb_msm_batch[_masked]_dev (mask and constant points may both be NULL): _begin queues the whole MSM and
@@ -230,6 +252,8 @@ int vdb_msm_batch_masked_dev(const vdb_srs *srs, int basis, const vdb_fr *scalar
 #define VDB_NTT_INVERSE_SCALE 1 /* multiply the result by n^{-1} (EvaluationDomain::ifft) */
 /* In place on each column; natural order in, natural order out; X[i] = sum_j a[j] omega^(ij). */
 int vdb_ntt_batch(vdb_fr *const *cols, size_t n_cols, uint32_t log_n, const vdb_fr *omega, int flags);
+/* the same with the columns cut into one contiguous block per bound device (vdb_init_devices), one host thread each */
+int vdb_ntt_batch_multi(vdb_fr *const *cols, size_t n_cols, uint32_t log_n, const vdb_fr *omega, int flags);
 /* contiguous device buffer of n_cols columns of 2^log_n elements */
 int vdb_ntt_batch_dev(vdb_fr *cols_dev, size_t n_cols, uint32_t log_n, const vdb_fr *omega, int flags);
 /* lagrange_to_coeff for the 2^k domain (omega = ROOT_OF_UNITY^(2^(28-k))) */

@@ -42,6 +42,17 @@ def test_no_silent_cpu_fallback(lib):
         api.fr_mul([[0, 0, 0, 0]], [[0, 0, 0, 0]])
 
 
+def test_multi_device_lifecycle_without_a_gpu(lib):
+    """b0: vdb_init_devices / vdb_set_device fail loudly too; shutdown is always safe"""
+    if lib.vdb_device_count() > 0:
+        pytest.skip("GPU present")
+    assert lib.vdb_init_devices(1) == -6 and b"no CPU fallback" in lib.vdb_last_error()
+    assert lib.vdb_set_device(0) == -3 and lib.vdb_current_device() == -1 and lib.vdb_devices_bound() == 0
+    lib.vdb_shutdown()
+    lib.vdb_shutdown()
+    assert lib.vdb_init(0) == -6
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "halo2_vectordb_amd")
     for dp, _, files in os.walk(pkg):

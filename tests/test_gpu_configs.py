@@ -91,7 +91,7 @@ def test_constant_factoring_is_data_independent(api, O):
     """Keygen with database A, prove database B: the commitments computed with the constant cells factored out
     (vdb_msm_batch_masked_dev + keygen-time constant points) must equal the plain MSM of B's real columns."""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    hp = KmeansHotPath(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11).setup()
+    hp = KmeansHotPath(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11, blind_seed=3).setup()   # fixed blinds: commitments are compared across steps
     assert hp.const_cell_fraction is not None and 0.15 < hp.const_cell_fraction < 0.6
     rng = np.random.default_rng(999)
     hp.set_vectors(rng.integers(0, 219, size=(14, 6)).astype(np.float64) + rng.random((14, 6)))
@@ -138,7 +138,7 @@ def test_sharded_ranks_reproduce_the_unsharded_job(api, O, world, metric):
     reassembled in the order gather_commitments uses, are exactly those of the unsharded job, and the k-means results
     (computed on the value-only path everywhere) are the same on every rank."""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    cfg = dict(n=20, dim=9, K=3, I=3, k=10, P=48, L=9, seed=17, metric=metric)
+    cfg = dict(n=20, dim=9, K=3, I=3, k=10, P=48, L=9, seed=17, metric=metric, blind_seed=4)   # the ranks must blind alike to be compared
     full = KmeansHotPath(**cfg).setup()
     want_commit = full.step().copy()
     full.relayout()
@@ -168,7 +168,7 @@ def test_pinning_file_keygen_then_prove(api, O, tmp_path):
     """Keygen arm writes configs/{name}.json, Prove arm reads it back (src/scaffold/mod.rs:272, 285-287): same break
     points, same commitments; a pinning of another circuit is refused."""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    cfg = dict(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11)
+    cfg = dict(n=14, dim=6, K=3, I=2, k=10, P=48, L=9, seed=11, blind_seed=5)
     keygen = KmeansHotPath(**cfg).setup()
     pin = tmp_path / "kmeans.json"
     keygen.write_pinning(pin)
@@ -188,7 +188,7 @@ def test_virtual_layout_matches_the_copied_layout(api, O, k, metric):
     """committing and transforming straight from the witness stream (vdb_colsrc) gives the same commitments, coefficient
     columns and extended columns as the path that first copies the stream into columns"""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    cfg = dict(n=14, dim=6, K=3, I=2, k=k, P=48, L=9, seed=11, metric=metric)
+    cfg = dict(n=14, dim=6, K=3, I=2, k=k, P=48, L=9, seed=11, metric=metric, blind_seed=6)
     out = {}
     for virt in (False, True):
         hp = KmeansHotPath(**cfg)
@@ -214,7 +214,7 @@ def test_merkle_hot_path_c3_and_column_shards(api, O):
     hash-only root, sampled commitments equal the oracle's MSM of the laid-out columns, and two column shards reproduce
     the unsharded commitments (the way C5's 2^18-row circuits are cut to fit: tools/c5_subcircuits.py)."""
     from halo2_vectordb_amd.pipeline import MerkleHotPath
-    hp = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED).setup()
+    hp = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED, blind_seed=7).setup()
     assert hp.n_lk_cols == 0 and hp.n_cells == 1024 * 128 + 1024 * (64 * 2256 + 2250) + 1023 * (2256 + 2250)    # assigned vectors + trace
     full = hp.step().copy()
     assert np.array_equal(hp.results(), api.poseidon_merkle_root(hp.qvec))
@@ -225,7 +225,7 @@ def test_merkle_hot_path_c3_and_column_shards(api, O):
     hp.free()
     parts = []
     for rank in range(2):
-        h = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED, col_shard=(rank, 2)).setup()
+        h = MerkleHotPath(n=1024, dim=128, k=15, tau=0x5EED, col_shard=(rank, 2), blind_seed=7).setup()
         parts.append(h.step().copy())
         h.free()
     assert sum(len(p) for p in parts) == n_adv and np.array_equal(np.concatenate(parts), full)
@@ -249,3 +249,24 @@ def test_nearest_hot_path_c2(api, O):
     assert np.array_equal(cols[0][: 65 * 128], hp.qvec.reshape(-1, 4)[: 65 * 128])
     assert np.array_equal(got[pick], O.msm_batch(cols, hp.g_lagrange))
     hp.free()
+
+
+def test_two_rank_timed_path_with_the_collective(tmp_path):
+    """The N > 1 path of bench.py exactly as the driver launches it (torch.distributed.run, one process per rank), here
+    with two ranks sharing this box's one GPU over gloo (VDB_DIST_BACKEND=gloo; on a multi-GPU node the same code runs over
+    RCCL): every timed step ends with the all_gather of the commitments, and the gathered commitments equal the unsharded
+    job's (--verify-gather)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small", "--no-cpu-baseline", "--verify-gather"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["gathered_commitments_match_unsharded_job"] is True
+    assert out["value"] > 0 and out["roofline"]["launches_per_step"] > 0

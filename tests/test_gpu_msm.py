@@ -200,3 +200,53 @@ def test_g1_sum_exceptional_cases(O, PY):
     want = O.g1_mul_generator([15, 0, 0, 12, 0])
     assert np.array_equal(got, want)
     assert np.array_equal(combine_partials(parts[:1]), parts[0])
+
+
+def test_multi_device_lifecycle_and_batches(api, O):
+    """SURVEY 8(b) b0 behind the ABI: vdb_init_devices binds per-device contexts in one process, a host thread works on the
+    device it selected, the *_multi entry points cut a batch of columns into one block per bound device (one host thread
+    each) and return the commitments D2H.  This box has one GPU, so the blocks are one block — the same code path an 8-GPU
+    caller runs with eight —, driven once from the main thread and once from a second host thread; an srs handle is refused
+    on a device it does not belong to; shutdown / init cycles leave no stale per-device state (witness tables, twiddles)."""
+    import threading
+    rng = np.random.default_rng(77)
+    k, n = 9, 512
+    g, gl = O.srs_from_tau(k, 0x51DE)
+    cols = O.random_fr(rng, 5 * n).reshape(5, n, 4)
+    cols[1] = witness_like(O, rng, n)
+    want = O.msm_batch(cols, gl, threads=4)
+    qa = O.quantize(rng.uniform(-2, 2, (2, 5)))
+    want_dist = api.wit_distance("euclidean", qa[:1], qa[1:], L=10)["stream"]
+    try:
+        api.init_devices(1)
+        assert api.devices_bound() == 1 and api.current_device() == 0
+        with pytest.raises(api.VdbError):
+            api.set_device(1)                      # not bound
+        srs = api.SrsAll(k, g, gl)
+        assert srs.devices() == [0]
+        assert np.array_equal(srs.msm_batch(cols), want)
+        out = {}
+
+        def worker():
+            api.set_device(0)
+            out["msm"] = srs.msm_batch(cols)
+            out["ntt"] = api.ntt_batch_multi(cols, api.root_of_unity(k))
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert np.array_equal(out["msm"], want)
+        assert np.array_equal(out["ntt"], O.ntt_batch(cols, O.root_of_unity(k), threads=2))
+        srs.free()
+        # cycle: everything cached on the device (gadget tables, twiddles, Poseidon spec) is rebuilt after a shutdown
+        api.shutdown()
+        import ctypes
+        from halo2_vectordb_amd import _lib
+        buf = (ctypes.c_uint64 * 4)()
+        assert _lib.load().vdb_fr_mul(buf, buf, buf, ctypes.c_size_t(1)) == -1      # VDB_ERR_NOT_INIT: nothing is bound any more
+        api.init(0)
+        assert np.array_equal(api.wit_distance("euclidean", qa[:1], qa[1:], L=10)["stream"], want_dist)
+        assert np.array_equal(api.ntt_batch(cols, api.root_of_unity(k)), out["ntt"])
+        assert np.array_equal(api.poseidon_hash_many(cols[:1, :2])[0], O.poseidon_hash_many(cols[:1, :2])[0])
+    finally:
+        api.shutdown()
+        api.init(0)

@@ -499,6 +499,29 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
     assert not _verify(O, api, proof[:-32], vk) and not _verify(O, api, proof + bytes(32), vk)
 
 
+def test_every_proof_draws_fresh_blinding_scalars(circuit, O):
+    """halo2's create_proof blinds every committed polynomial with Scalar::random(OsRng): two proofs of the same witness
+    must not share a commitment (shared blinds would expose the difference of two witnesses), and both must verify"""
+    from halo2_vectordb_amd import api
+    from oracle import pairing as PR
+    hp, pr = circuit
+    a, b = pr.prove(None), pr.prove(None)               # seed=None: operating-system entropy
+    for name in ("adv", "pa", "ps", "zp", "zl"):
+        ca, cb = a["commitments"][name], b["commitments"][name]
+        assert ca.shape == cb.shape and not (ca == cb).all(axis=1).any(), name
+    assert a["proof"] != b["proof"]
+    for out in (a, b):
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], vk)
+    # the hot path alone: two steps, different advice commitments for the same witness; a seed (test hook) pins them
+    c1, c2 = hp.step().copy(), hp.step().copy()
+    assert not (c1 == c2).all(axis=1).any()
+    assert np.array_equal(hp.step(blind_seed=5), hp.step(blind_seed=5))
+    # the blinding rows are uniform field elements: canonical values below r that fill the whole range
+    blinds = O.fr_to_ints(hp.d_blind.download((hp.n_cols * 6, 4)))
+    assert len(set(blinds)) == len(blinds) and max(v.bit_length() for v in blinds) >= 252 and all(v < O.R_MOD for v in blinds)
+
+
 def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
     """The Merkle circuit's own copy constraints (halo2_vectordb_amd/copymap.py: symbolic trace of PoseidonChip::permutation,
     checked cell by cell against the kernel's gate / constant flags): on a real witness every cell equals the cell it copies

@@ -419,6 +419,45 @@ def random_scalars_dev(dst_ptr, n, seed=None):
         wide.free()
 
 
+class MockReport(ctypes.Structure):
+    """vdb_mock_report (include/vdb.h)"""
+    _fields_ = [(n, ctypes.c_uint64) for n in ("gate_rows_violated", "first_gate_row", "lookup_cells_out_of_table", "first_lookup_cell",
+                                               "copies_unequal", "first_copy", "lookup_copies_unequal", "first_lookup_copy",
+                                               "constants_changed", "first_constant")]
+
+    def violations(self):
+        return int(self.gate_rows_violated + self.lookup_cells_out_of_table + self.copies_unequal + self.lookup_copies_unequal + self.constants_changed)
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def mock_check_dev(stream_ptr, n_cells, flags_ptr, lookup_ptr, n_lookup, lookup_bits, copy_of_ptr=None, lookup_src_ptr=None, const_stream_ptr=None):
+    """MockProver-style check of a device-resident witness (vdb_mock_check_dev): every gate row, lookup cell, copy and constant"""
+    rep = MockReport()
+    check(_lib.init().vdb_mock_check_dev(stream_ptr, ctypes.c_uint64(n_cells), flags_ptr, lookup_ptr, ctypes.c_uint64(n_lookup), ctypes.c_uint32(lookup_bits),
+                                         copy_of_ptr, lookup_src_ptr, const_stream_ptr, ctypes.byref(rep)))
+    return rep
+
+
+def mock_check(stream, flags, lookup, lookup_bits, copy_of=None, lookup_src=None, const_stream=None):
+    """the same on host arrays (uploaded): stream (n, 4), flags (n,) uint8, lookup (m, 4); copy maps as int64 arrays"""
+    stream, lookup = _fr(stream), _fr(lookup) if lookup is not None and len(lookup) else np.zeros((0, 4), dtype=np.uint64)
+    arrays = [stream, np.ascontiguousarray(flags, dtype=np.uint8), lookup]
+    opt = [None if a is None else np.ascontiguousarray(a, dtype=np.int64) for a in (copy_of, lookup_src)] + [None if const_stream is None else _fr(const_stream)]
+    bufs = [DeviceBuffer(max(a.nbytes, 32)) for a in arrays] + [None if a is None else DeviceBuffer(max(a.nbytes, 32)) for a in opt]
+    try:
+        for b, a in zip(bufs, arrays + opt):
+            if b is not None and a.nbytes:
+                b.upload(a)
+        return mock_check_dev(bufs[0].ptr, stream.shape[0], bufs[1].ptr, bufs[2].ptr, lookup.shape[0], lookup_bits,
+                              *(None if b is None else b.ptr for b in bufs[3:]))
+    finally:
+        for b in bufs:
+            if b is not None:
+                b.free()
+
+
 # ---------------------------------------------------------------- device buffers
 def extended_to_coeff(ext_cols, k, ext_k=2):
     """inverse of coeff_to_extended; ext_cols: (n_cols, 2^(k+ext_k), 4) on the host"""

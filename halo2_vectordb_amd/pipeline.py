@@ -422,6 +422,40 @@ class KmeansHotPath:
         api.sync()
         return self.commitments
 
+    # ------------------------------------------------------------------ the Mock stage (src/scaffold/mod.rs:263-266)
+    def keygen_flags(self):
+        """flag byte per advice cell from a keygen-style run (bit 0 gate start, bit 1 constant cell, bit 2 lookup source), on the device"""
+        d_flags = api.DeviceBuffer(self.n_cells)
+        check(self.lib.vdb_memset_dev(d_flags.ptr, 0, ctypes.c_size_t(self.n_cells)))
+        self._witness(sel=d_flags)     # the flags are data independent; the cells written are those of the current input
+        return d_flags
+
+    def mock_check(self, copy_of=None, lookup_src=None, const_stream=None):
+        """MockProver::run(..).assert_satisfied() of the reference's Mock arm on the witness as it lies in HBM after a
+        step() / relayout(): every gate row, every lookup cell against the range table and — when the maps are given (device
+        buffers or int64 arrays) — every copy constraint and every constant.  Returns api.MockReport (rank-unsharded runs)."""
+        assert self.world == 1, "the mock check walks the whole witness"
+        d_flags = self.keygen_flags()
+        self._witness()           # the witness under test (the flag run above wrote the same cells)
+        own = []
+
+        def dev(a, dtype):
+            if a is None or isinstance(a, (api.DeviceBuffer,)) or hasattr(a, "ptr"):
+                return a
+            a = np.ascontiguousarray(a, dtype=dtype)
+            b = api.DeviceBuffer(max(a.nbytes, 32))
+            b.upload(a)
+            own.append(b)
+            return b
+        try:
+            c, l, k = dev(copy_of, np.int64), dev(lookup_src, np.int64), dev(const_stream, np.uint64)
+            return api.mock_check_dev(self.d_stream.ptr, self.n_cells, d_flags.ptr, self.d_lookup.ptr, self.n_lookup, self.L,
+                                      None if c is None else c.ptr, None if l is None else l.ptr, None if k is None else k.ptr)
+        finally:
+            d_flags.free()
+            for b in own:
+                b.free()
+
     def local_index(self, col):
         """Position in this rank's compact column buffer of global column `col` ([all advice | all lookup] numbering)."""
         if col < self.n_adv_cols:

@@ -379,6 +379,24 @@ int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
 int vdb_transcript_proof_len(const vdb_transcript *tr, size_t *len);
 int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t cap);
 
+/* ---- Mock stage: replaces MockProver::run(k, &circuit, instances).assert_satisfied() of the reference's Mock arm
+ *      (src/scaffold/mod.rs:263-266): every gate row a + b c = d, every lookup cell against the range table, every copy
+ *      constraint and every constant, checked on the witness where it lies in HBM (flat streams; device pointers).
+ *      flags_dev: the flag byte per advice cell of a keygen-style run (bit 0 gate start, bit 1 constant cell);
+ *      copy_of_dev[i] = the cell that cell i copies (i itself or negative: none); lookup_src_dev[j] = the advice cell
+ *      lookup cell j copies; const_stream_dev: a stream of the same circuit whose constant cells hold the fixed values.
+ *      Any of the last three may be null (that check is skipped).  Counts and the first offending index per kind. ------ */
+typedef struct {
+  uint64_t gate_rows_violated, first_gate_row;
+  uint64_t lookup_cells_out_of_table, first_lookup_cell;
+  uint64_t copies_unequal, first_copy;
+  uint64_t lookup_copies_unequal, first_lookup_copy;
+  uint64_t constants_changed, first_constant;
+} vdb_mock_report;
+int vdb_mock_check_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint8_t *flags_dev, const vdb_fr *lookup_dev, uint64_t n_lookup,
+                       uint32_t lookup_bits, const int64_t *copy_of_dev, const int64_t *lookup_src_dev, const vdb_fr *const_stream_dev,
+                       vdb_mock_report *out);
+
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,
  *      R_P=57 as examples/merkle.rs:15-18; call sites src/gadget/vectordb.rs:180-182, 213-215) --- */
 int vdb_poseidon_hash_many(const vdb_fr *inputs, size_t n_msgs, size_t msg_len, vdb_fr *digests);

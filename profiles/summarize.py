@@ -10,8 +10,20 @@ import sys
 tag = sys.argv[1]
 suffix = sys.argv[2] if len(sys.argv) > 2 else ""
 src = f"gpurun_out/prof_{tag}{suffix}"
-stats = glob.glob(f"{src}_stats/*/*_kernel_stats.csv")[0]
-shutil.copy(stats, f"profiles/{tag}{suffix}_kernel_stats.csv")
+stats = glob.glob(f"{src}_stats/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}{suffix}_kernel_stats.csv")
+else:
+    # rocprofv3 without --output-format csv leaves a rocpd SQLite database: the same per-kernel statistics from its `kernels` view
+    import sqlite3
+    con = sqlite3.connect(glob.glob(f"{src}_stats/*/*_results.db")[0])
+    rows_k = con.execute("select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows_k)
+    with open(f"profiles/{tag}{suffix}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows_k:
+            w.writerow([r[0], r[1], r[2], round(r[3], 3), round(100 * r[2] / tot, 2), r[4], r[5]])
 rows = []
 for kind in ("fetch", "write"):
     files = glob.glob(f"{src}_{kind}/*/*_counter_collection.csv")

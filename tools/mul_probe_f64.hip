@@ -28,6 +28,12 @@ struct F5Consts {
   uint64_t init[11];  // column accumulators start at minus the exponent patterns their terms will carry
 };
 
+// The compiler does not model the rounding mode as an input of floating-point instructions and moves them across
+// s_setreg; volatile asm statements keep their order among themselves, so every value that enters (leaves) the region
+// computed under the changed mode is passed through one placed after (before) the mode switch.
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void round_toward_zero_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3"); }
+__device__ __forceinline__ void round_toward_zero_off() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"); }
 __device__ __forceinline__ double bits_to_double(uint64_t b) { return __longlong_as_double((long long)b); }
 __device__ __forceinline__ uint64_t double_bits(double d) { return (uint64_t)__double_as_longlong(d); }
 // an integer below 2^52 as an exact double
@@ -94,7 +100,6 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, const uint32_t* w, F
     }
     for (int j = 0; j < 9; j++) s += a[0][j] ^ a[1][j];
   } else {
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);  // MODE.FP_ROUND[3:2] (f64 / f16) = round toward zero
     double a[2][5], W[5];
     for (int j = 0; j < 5; j++) {
       W[j] = (double)(((uint64_t)w[j] << 19 | threadIdx.x) & M52);
@@ -102,6 +107,8 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, const uint32_t* w, F
       a[1][j] = (double)((((uint64_t)w[j] * 5) << 17 | blockIdx.x) & M52);
     }
     W[4] = a[0][4] = a[1][4] = 1234567.0;  // keep the operands below r (top limb of r is 0x30644e72e131a ~ 2^45.6)
+    round_toward_zero_on();  // MODE.FP_ROUND[3:2] (f64 / f16) = round toward zero
+    for (int j = 0; j < 5; j++) pin(W[j]), pin(a[0][j]), pin(a[1][j]);
     for (int it = 0; it < iters; it++) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
@@ -111,8 +118,9 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, const uint32_t* w, F
         for (int j = 0; j < 5; j++) a[c][j] = r[j];
       }
     }
+    for (int j = 0; j < 5; j++) pin(a[0][j]), pin(a[1][j]);
+    round_toward_zero_off();
     for (int j = 0; j < 5; j++) s += (uint32_t)double_bits(a[0][j]) ^ (uint32_t)double_bits(a[1][j]);
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 0);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
@@ -121,12 +129,14 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, const uint32_t* w, F
 __global__ void check_kernel(const double* a, const double* b, double* r, F5Consts K, int n) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);
   double x[5], y[5], o[5];
   for (int j = 0; j < 5; j++) x[j] = a[t * 5 + j], y[j] = b[t * 5 + j];
+  round_toward_zero_on();
+  for (int j = 0; j < 5; j++) pin(x[j]), pin(y[j]);
   mont_f64(o, x, y, K);
+  for (int j = 0; j < 5; j++) pin(o[j]);
+  round_toward_zero_off();
   for (int j = 0; j < 5; j++) r[t * 5 + j] = o[j];
-  __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 0);
 }
 
 // ---- host big integers (little-endian 64-bit words), just enough for the check

@@ -432,11 +432,13 @@ class MockReport(ctypes.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-def mock_check_dev(stream_ptr, n_cells, flags_ptr, lookup_ptr, n_lookup, lookup_bits, copy_of_ptr=None, lookup_src_ptr=None, const_stream_ptr=None):
+def mock_check_dev(stream_ptr, n_cells, flags_ptr, lookup_ptr, n_lookup, lookup_bits, copy_of_ptr=None, lookup_src_ptr=None, const_stream_ptr=None,
+                   const_idx_ptr=None, const_table_ptr=None, n_consts=0):
     """MockProver-style check of a device-resident witness (vdb_mock_check_dev): every gate row, lookup cell, copy and constant"""
     rep = MockReport()
     check(_lib.init().vdb_mock_check_dev(stream_ptr, ctypes.c_uint64(n_cells), flags_ptr, lookup_ptr, ctypes.c_uint64(n_lookup), ctypes.c_uint32(lookup_bits),
-                                         copy_of_ptr, lookup_src_ptr, const_stream_ptr, ctypes.byref(rep)))
+                                         copy_of_ptr, lookup_src_ptr, const_stream_ptr, const_idx_ptr, const_table_ptr, ctypes.c_uint64(n_consts),
+                                         ctypes.byref(rep)))
     return rep
 
 

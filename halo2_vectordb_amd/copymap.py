@@ -122,7 +122,7 @@ def perm_cells(n_in):
     return {2: 18, 1: 15, 0: 12}[n_in] + 2238
 
 
-def merkle_copy_map(n, dim, flags, vectors_assigned=True):
+def merkle_copy_map(n, dim, flags, vectors_assigned=True, placements=None):
     """copy_of[i] = stream offset of the cell that cell i copies (i itself for new cells and constants) for merkle_commitment
     over n vectors of `dim` words; `flags`: the flag bytes of a keygen-style run of the same circuit (vdb_wit_merkle_dev with a
     selector buffer).  With `vectors_assigned` the stream starts with the n * dim assigned vector words
@@ -135,7 +135,10 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
     if n_in:
         if flags[:n_in].any():
             raise ValueError("the assigned vector words carry no gate or constant flag")
-        gadget, root, init = merkle_copy_map(n, dim, flags[n_in:], vectors_assigned=None)
+        inner = [] if placements is not None else None
+        gadget, root, init = merkle_copy_map(n, dim, flags[n_in:], vectors_assigned=None, placements=inner)
+        if placements is not None:
+            placements.extend((k, bases + n_in, states) for k, bases, states in inner)
         return np.concatenate([np.arange(n_in, dtype=np.int64), gadget + n_in]), root + n_in, init + n_in
     nperm = (dim + 1) // 2 + (1 if dim % 2 == 0 else 0)
     n_ins = [max(0, min(2, dim - 2 * p)) for p in range(nperm)]
@@ -162,6 +165,8 @@ def merkle_copy_map(n, dim, flags, vectors_assigned=True):
         """instantiate the template at every offset in `bases`; state_src / msg_src: per input, array of source offsets (or
         None: a free / constant-initialised cell)"""
         src, fin = template(n_in, int(bases[0]))
+        if placements is not None:      # (message words absorbed, instance offsets, which of the T state inputs start from the chip's initial state)
+            placements.append((n_in, bases.copy(), [st is None for st in state_src]))
         idx = bases[:, None] + np.arange(src.size)[None, :]
         val = np.where(src[None, :] >= 0, bases[:, None] + np.maximum(src, 0)[None, :], idx)
         for i in range(T):
@@ -211,37 +216,57 @@ def lookup_sources(flags, n_lookup):
     return src
 
 
-def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, lookup_rows=None):
-    """Permutation over an n_cols x rows grid (words col << 32 | row, the identity where nothing is tied) from a copy map
+def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, lookup_rows=None, const_idx=None, n_consts=0):
+    """Permutation over a grid of columns x rows (words col << 32 | row, the identity where nothing is tied) from a copy map
     over the stream cells that fill the first len(break_points) + 1 columns: every set of cells that copy one another
     (directly or through other copies) becomes one cycle, and the overlap cell that ends column c is the cell that starts
     column c + 1.  `lookup_src` (with `lookup_rows` cells per lookup column): lookup cell j, at row j % lookup_rows of column
-    n_adv + j // lookup_rows, joins the cycle of the advice cell lookup_src[j]."""
+    n_adv + j // lookup_rows, joins the cycle of the advice cell lookup_src[j].
+    `const_idx` (with `n_consts`): cell i with const_idx[i] = r >= 0 is tied to row r of ONE MORE column, number n_cols, the
+    fixed column that holds the circuit's constants — how halo2-base pins `QuantumCell::Constant` cells and
+    `assert_is_const` — and the grid gets n_cols + 1 columns."""
     copy_of = np.asarray(copy_of, dtype=np.int64)
+    n_cells = copy_of.size
     bp = np.asarray(break_points, dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(bp)])
+    with_consts = const_idx is not None
     root = copy_of.copy()
-    while True:                                                 # pointer jumping: sources are always earlier cells
+    if with_consts:
+        const_idx = np.asarray(const_idx, dtype=np.int64)
+        tied = np.flatnonzero(const_idx >= 0)
+        if (copy_of[tied] != tied).any():
+            raise ValueError("a cell tied to a constant must be the root of its copies")
+        root = np.concatenate([root, n_cells + np.arange(n_consts, dtype=np.int64)])      # the fixed column's cells follow the stream
+        root[tied] = n_cells + const_idx[tied]
+    while True:                                                 # pointer jumping: sources are earlier cells or fixed cells
         nxt = root[root]
         if np.array_equal(nxt, root):
             break
         root = nxt
-    s = np.arange(copy_of.size, dtype=np.int64)
+    s = np.arange(n_cells, dtype=np.int64)
     col = np.searchsorted(starts, s, side="right") - 1
     row = s - starts[col]
     # the overlap cell: stream offset starts[c + 1] also sits in column c at row bp[c]
-    dup_s = starts[1:][starts[1:] < copy_of.size]
+    dup_s = starts[1:][starts[1:] < n_cells]
     dup_col = np.arange(dup_s.size, dtype=np.int64)
-    pos_col = np.concatenate([col, dup_col])
-    pos_row = np.concatenate([row, bp[: dup_s.size]])
-    pos_root = np.concatenate([root, root[dup_s]])
+    pos_col = [col, dup_col]
+    pos_row = [row, bp[: dup_s.size]]
+    pos_root = [root[:n_cells], root[dup_s]]
     if lookup_src is not None and len(lookup_src):
         j = np.arange(len(lookup_src), dtype=np.int64)
-        pos_col = np.concatenate([pos_col, bp.size + 1 + j // lookup_rows])
-        pos_row = np.concatenate([pos_row, j % lookup_rows])
-        pos_root = np.concatenate([pos_root, root[np.asarray(lookup_src, dtype=np.int64)]])
-    if int(copy_of.size) * n_cols * rows < (1 << 62):           # one combined key sorts several times faster than three
-        order = np.argsort(pos_root * (n_cols * rows) + pos_col * rows + pos_row, kind="stable")
+        pos_col.append(bp.size + 1 + j // lookup_rows)
+        pos_row.append(j % lookup_rows)
+        pos_root.append(root[np.asarray(lookup_src, dtype=np.int64)])
+    total_cols = n_cols + (1 if with_consts else 0)
+    if with_consts:
+        if n_consts > rows:
+            raise ValueError("more distinct constants than rows in the fixed column")
+        pos_col.append(np.full(n_consts, n_cols, dtype=np.int64))
+        pos_row.append(np.arange(n_consts, dtype=np.int64))
+        pos_root.append(root[n_cells:])
+    pos_col, pos_row, pos_root = np.concatenate(pos_col), np.concatenate(pos_row), np.concatenate(pos_root)
+    if int(root.size) * total_cols * rows < (1 << 62):           # one combined key sorts several times faster than three
+        order = np.argsort(pos_root * (total_cols * rows) + pos_col * rows + pos_row, kind="stable")
     else:
         order = np.lexsort((pos_row, pos_col, pos_root))
     pc, prw, pr = pos_col[order], pos_row[order], pos_root[order]
@@ -249,6 +274,51 @@ def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, l
     group_start = np.maximum.accumulate(np.where(first, np.arange(pr.size), 0))
     last = np.concatenate([pr[1:] != pr[:-1], [True]])
     nxt_idx = np.where(last, group_start, np.arange(pr.size) + 1)
-    mapping = (np.arange(n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
+    mapping = (np.arange(total_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
     mapping[pc, prw] = (pc[nxt_idx].astype(np.uint64) << np.uint64(32)) | prw[nxt_idx].astype(np.uint64)
     return mapping
+
+
+def merkle_circuit_map(n, dim, flags, fetch, vectors_assigned=True):
+    """The Merkle circuit's whole constraint map as a circuit_sym.CopyMap, plus the root cell: merkle_copy_map's copies, the
+    lookup-free gate flags, and every constant cell with the fixed-column value it is tied to — the cells the kernels flag
+    (bit 1: Poseidon round constants, matrix entries, the ones and zeros of the gate templates), the zero cell of the padding,
+    and the sponge's initial state [2^64, 0, 0] at the start of every leaf and tree node, which the kernels emit as ordinary
+    cells.  Constants are data independent and repeat with the permutation template, so their values are read from ONE instance
+    of each template through `fetch(lo, hi)` -> canonical integers of stream cells [lo, hi) of a keygen-style run."""
+    from .circuit_sym import CopyMap
+    flags = np.asarray(flags, dtype=np.uint8)
+    placements = []
+    copy_of, root, _init = merkle_copy_map(n, dim, flags, vectors_assigned, placements)
+    const_idx = np.full(flags.size, -1, dtype=np.int64)
+    consts, cmap = [], {}
+
+    def cid(v):
+        if v not in cmap:
+            cmap[v] = len(consts)
+            consts.append(v)
+        return cmap[v]
+
+    first = {}
+    for n_in, bases, fresh_state in placements:
+        size = perm_cells(n_in)
+        if n_in not in first:
+            b0 = int(bases[0])
+            src, _ = permutation_template(flags[b0: b0 + size], n_in)
+            vals = fetch(b0, b0 + size)
+            cst = np.flatnonzero(flags[b0: b0 + size] & 2)
+            first[n_in] = (src, cst, np.asarray([cid(int(vals[i])) for i in cst], dtype=np.int64))
+        src, cst, ids = first[n_in]
+        const_idx[(bases[:, None] + cst[None, :]).reshape(-1)] = np.broadcast_to(ids[None, :], (bases.size, cst.size)).reshape(-1)
+        for i, fresh in enumerate(fresh_state):            # state word i starts from the chip's initial state: capacity 2^64, then zeros
+            cols = np.flatnonzero(src == -10 - i)
+            if fresh and cols.size:
+                const_idx[(bases[:, None] + cols[None, :]).reshape(-1)] = cid((1 << 64) if i == 0 else 0)
+    # flagged cells outside the permutations (the padding's load_zero cell)
+    rest = np.flatnonzero(((flags & 2) != 0) & (const_idx < 0))
+    for i in rest:
+        const_idx[i] = cid(int(fetch(int(i), int(i) + 1)[0]))
+    tied = const_idx >= 0
+    if (copy_of[tied] != np.flatnonzero(tied)).any():
+        raise ValueError("a constant cell of the Merkle circuit copies another cell")
+    return CopyMap(copy_of, const_idx, consts, np.zeros(flags.size, dtype=bool), (flags & 1).astype(bool), np.zeros(0, dtype=np.int64)), root

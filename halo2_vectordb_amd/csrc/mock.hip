@@ -7,7 +7,9 @@
 //   lookup    every lookup cell is a canonical value below 2^lookup_bits (the range table 0 .. 2^L - 1)
 //   copies    copy_of[i] != i: a[i] == a[copy_of[i]]  (Existing cells and the layout's own ties);
 //             lookup_src[j]: lookup[j] == a[lookup_src[j]]  (cells_to_lookup are copies of advice cells)
-//   constants every cell flagged constant (bit 1) equals the same cell of the keygen-time stream (what the fixed column holds)
+//   constants every cell flagged constant (bit 1) equals the same cell of the keygen-time stream (what the fixed column holds);
+//             or, with the circuit's constraint map: const_idx[i] = r >= 0 -> a[i] == const_table[r] (Constant cells and
+//             assert_is_const ties alike: both are copies of the fixed column's cell r)
 // Pure HBM streaming: 32 B per cell read once (+ 1 flag byte, + 8 B per copy index); the products are one per gate row.
 #include "common.hpp"
 
@@ -24,7 +26,8 @@ __device__ __forceinline__ void mock_report(MockCounters* m, int kind, uint64_t 
 }
 
 __global__ __launch_bounds__(256) void k_mock_cells(const u256* __restrict__ a, uint64_t n_cells, const uint8_t* __restrict__ flags,
-                                                   const int64_t* __restrict__ copy_of, const u256* __restrict__ consts, MockCounters* m) {
+                                                   const int64_t* __restrict__ copy_of, const u256* __restrict__ consts, const int64_t* __restrict__ const_idx,
+                                                   const u256* __restrict__ const_table, uint64_t n_consts, MockCounters* m) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
     const uint8_t f = flags ? flags[i] : 0;
@@ -42,6 +45,10 @@ __global__ __launch_bounds__(256) void k_mock_cells(const u256* __restrict__ a, 
       if (src >= 0 && (uint64_t)src != i && ((uint64_t)src >= n_cells || !u256_eq(v, ld256(a + src)))) mock_report(m, 2, i);
     }
     if ((f & 2) && consts && !u256_eq(v, ld256(consts + i))) mock_report(m, 4, i);
+    if (const_idx) {
+      const int64_t r = const_idx[i];
+      if (r >= 0 && ((uint64_t)r >= n_consts || !u256_eq(v, ld256(const_table + r)))) mock_report(m, 4, i);
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_mock_lookups(const u256* __restrict__ lk, uint64_t n_lookup, uint32_t lookup_bits, const u256* __restrict__ a,
@@ -63,9 +70,10 @@ using namespace vdb;
 
 extern "C" int vdb_mock_check_dev(const vdb_fr* stream_dev, uint64_t n_cells, const uint8_t* flags_dev, const vdb_fr* lookup_dev, uint64_t n_lookup,
                                   uint32_t lookup_bits, const int64_t* copy_of_dev, const int64_t* lookup_src_dev, const vdb_fr* const_stream_dev,
-                                  vdb_mock_report* out) {
+                                  const int64_t* const_idx_dev, const vdb_fr* const_table_dev, uint64_t n_consts, vdb_mock_report* out) {
   VDB_REQUIRE_INIT();
   VDB_ARG(out && (stream_dev || n_cells == 0) && (lookup_dev || n_lookup == 0) && lookup_bits >= 1 && lookup_bits <= 32, "bad argument");
+  VDB_ARG((const_idx_dev == nullptr) == (const_table_dev == nullptr), "constant indices and the constants' table go together");
   Context& c = ctx();
   MockCounters* d = (MockCounters*)scratch_get(5, sizeof(MockCounters));
   if (!d) return VDB_ERR_OOM;
@@ -76,7 +84,8 @@ extern "C" int vdb_mock_check_dev(const vdb_fr* stream_dev, uint64_t n_cells, co
   const unsigned grid = (unsigned)(c.cu_count * 16);
   if (n_cells) {
     VDB_PROF("k_mock_cells");
-    hipLaunchKernelGGL(k_mock_cells, dim3(grid), dim3(256), 0, c.stream, as_u256(stream_dev), n_cells, flags_dev, copy_of_dev, as_u256(const_stream_dev), d);
+    hipLaunchKernelGGL(k_mock_cells, dim3(grid), dim3(256), 0, c.stream, as_u256(stream_dev), n_cells, flags_dev, copy_of_dev, as_u256(const_stream_dev),
+                       const_idx_dev, as_u256(const_table_dev), n_consts, d);
   }
   VDB_LAUNCH_CHECK();
   if (n_lookup) {

@@ -270,7 +270,9 @@ class KmeansHotPath:
             check(lib.vdb_colsrc_build_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, ctypes.c_uint64(self.l_lo),
                                                   ctypes.c_uint64(self.l_hi), self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND,
                                                   self.d_src.at(self.my_adv * 24)))
-        self.d_ext = api.DeviceBuffer(max(self.my_cols, 1) * self.rows * 4 * B)
+        # one column more than this rank holds: the prover rounds keep the coset of the constants' fixed column behind the advice
+        # cosets, so that the permutation argument reads its columns from one contiguous block (rounds.py)
+        self.d_ext = api.DeviceBuffer((max(self.my_cols, 1) + 1) * self.rows * 4 * B)
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
         # (lookup columns hold no constants: their mask stays zero and their constant point is the identity)

@@ -2,12 +2,15 @@
 k-means hot path leaves resident: lookup permutation -> products -> quotient -> evaluations -> openings, every polynomial
 step on the GPU, nothing but commitments, evaluations and challenges crossing the C ABI.
 
+The circuit proved is the reference's circuit: the vertical gate on every gate row, every lookup cell in the range table,
+and the permutation argument over the advice columns, the lookup columns and ONE fixed column of constants, with every copy
+halo2-base records while the closure runs — `Existing` cells, `Constant` cells (tied to the fixed column), constrain_equal /
+assert_is_const, the lookup cells (copies of advice cells), the overlap cell the column layout duplicates — taken from the
+circuit's symbolic map (circuit_sym.py for the fixed-point gadgets, copymap.py for the Merkle circuit).
 What this is not: halo2's exact proof layout (the order of terms and challenges is recalled, [UPSTREAM-RECALL]; the
 Fiat–Shamir transcript is the library's own, vdb_transcript_*; the multi-open is SHPLONK, or one quotient per rotation point
-with multiopen="gwc"), and the reference's circuits in full: the copy constraints are
-the ones the column layout creates (the overlap cell between consecutive columns), not the gadgets' own cell reuse, and
-the order of the quotient's terms follows plonk/evaluation.rs as recalled ([UPSTREAM-RECALL]; parity unpinned, SURVEY
-§8c).  What the tests hold it to instead is what a verifier checks: the quotient identity at a random point recombined
+with multiopen="gwc"); the order of the quotient's terms follows plonk/evaluation.rs as recalled ([UPSTREAM-RECALL]; parity
+unpinned).  What the tests hold it to instead is what a verifier checks: the quotient identity at a random point recombined
 from the returned evaluations, and every opening against its commitments in the exponent (tests/test_gpu_rounds.py).
 """
 import ctypes
@@ -19,7 +22,7 @@ from ._lib import check
 from .pipeline import N_BLIND
 
 B = 32
-FIXED = ("sel", "qc", "fc", "sigma", "table", "lag", "inst")     # the fixed polynomials, in the order the transcript absorbs their commitments
+FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
@@ -79,7 +82,8 @@ class ProverRounds:
         self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
         self.usable = hp.rows - N_BLIND
         self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
-        self.n_sets = -(-self.n_cols // CHUNK_LEN)
+        self.n_perm = self.n_cols + 1                # the permutation argument's columns: advice, lookup, and the constants' fixed column
+        self.n_sets = -(-self.n_perm // CHUNK_LEN)
         self.delta = api.fr_delta()
         self.fixed = {}
 
@@ -127,76 +131,79 @@ class ProverRounds:
         return p
 
     # ------------------------------------------------------------------ keygen side (untimed): the fixed polynomials
-    def keygen(self, copy_of=None, instance_cells=None, tie_lookups=True):
-        """`copy_of`: optional copy map over the stream cells (copy_of[i] = the earlier cell that cell i copies, i itself
-        otherwise) to tie in the permutation argument besides the cells the layout duplicates.  For the Merkle circuit it is
-        built here (copymap.merkle_copy_map) unless given; the k-means / nearest gadgets' own maps are not built.
+    def circuit_map(self, d_flags):
+        """The circuit's constraint map (circuit_sym.CopyMap) for the gadget this hot path runs: the symbolic trace of the
+        fixed-point gadgets, or of the Poseidon sponge for the Merkle circuit."""
+        from .pipeline import MerkleHotPath, NearestHotPath
+        hp = self.hp
+        if isinstance(hp, MerkleHotPath):
+            from .copymap import merkle_circuit_map
+            flags = d_flags.download((hp.n_cells,), dtype=np.uint8)
+
+            def fetch(lo, hi):
+                c = api.fr_to_canonical(hp.d_stream.download((hi - lo, 4), offset=lo * B))
+                return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in c]
+            cm, self.root_cell = merkle_circuit_map(hp.n, hp.dim, flags, fetch)
+            return cm
+        from . import circuit_sym as CS
+        if isinstance(hp, NearestHotPath):
+            cm, _ = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L)
+        else:
+            cm, _ = CS.build_kmeans(hp.metric_name, hp.n, hp.dim, hp.K, hp.I, hp.P, hp.L)
+        return cm
+
+    def keygen(self, circuit=None, instance_cells=None, check=True):
+        """The Keygen arm's work for the rounds (src/scaffold/mod.rs:267-283 -> keygen_vk / keygen_pk): gate selectors, the
+        permutation (sigma columns) from the circuit's constraint map, the constants' fixed column, the range table.
+        `circuit`: a circuit_sym.CopyMap over the stream cells; None = the map of the gadget this hot path runs (circuit_map).
         `instance_cells`: stream cells whose values are public inputs of the statement (for the Merkle circuit: the root
         cell).  Each gets a fixed Lagrange polynomial L of its (column, row) and the term L (a - value) in the quotient — the
-        value enters the transcript and the verifier's identity; halo2 would tie the cell to an instance column instead."""
+        value enters the transcript and the verifier's identity; halo2 would tie the cell to an instance column instead.
+        `check`: run the device-side MockProver on the keygen witness with the whole map (vdb_mock_check_dev); the report is
+        kept in self.keygen_report (a circuit the witness does not satisfy can still be set up — the proof will not verify)."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
         # the derived columns (products, quotient, opening quotients) and the fixed sigma columns hold full-width scalars
         self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
         self.srs_few = api.Srs(k, hp.g_monomial, None)     # a handful of columns: the bucket folding dominates, fewer buckets win
         # gate selectors from a flag-recording witness run
-        d_flags = api.DeviceBuffer(hp.n_cells)
-        check(lib.vdb_memset_dev(d_flags.ptr, 0, _sz(hp.n_cells)))
-        hp._witness(sel=d_flags)
+        d_flags = hp.keygen_flags()
         d_q = api.DeviceBuffer(self.n_adv * rows * B)
-        check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
-        from .pipeline import MerkleHotPath
-        if copy_of is None and isinstance(hp, MerkleHotPath):
-            from .copymap import merkle_copy_map
-            flags_h = d_flags.download((hp.n_cells,), dtype=np.uint8)
-            copy_of, self.root_cell, init_cells = merkle_copy_map(hp.n, hp.dim, flags_h)
-            flags_h[init_cells] |= 2              # the sponge's initial state: pinned by the constants gate below like any constant
-            d_flags.upload(flags_h)
-            self.n_pinned_init = int(init_cells.size)
-        # the lookup columns hold copies of advice cells (cells_to_lookup): tie every lookup cell to the cell it copies, so that
-        # the range checks the lookup argument proves are range checks of the advice cells
-        self.lookup_src = None
-        if hp.n_lookup and tie_lookups:
-            from .copymap import lookup_sources
-            self.lookup_src = lookup_sources(d_flags.download((hp.n_cells,), dtype=np.uint8), hp.n_lookup)
-            if copy_of is None:
-                copy_of = np.arange(hp.n_cells, dtype=np.int64)
-        self.copy_of = copy_of
-        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
-        # constant cells as a gate: qc = one where a column holds a QuantumCell::Constant, fc = the constant there (from this
-        # keygen-style run's stream), zero elsewhere.  The overlap cell that ends a column is flagged in the next column only,
-        # exactly like the gate selectors.
-        n_el = self.n_adv * rows
-        d_mask = api.DeviceBuffer(n_el)
-        check(lib.vdb_layout_const_mask_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_mask.ptr))
-        for c in range(self.n_adv - 1):
-            check(lib.vdb_memset_dev(d_mask.at(c * rows + int(hp.bp[c])), 0, _sz(1)))
-        d_fc = api.DeviceBuffer(n_el * B)
-        check(lib.vdb_layout_columns_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_fc.ptr, None, 0))
-        check(lib.vdb_mask_select_dev(d_fc.ptr, d_mask.ptr, ctypes.c_uint64(n_el), 1, d_fc.ptr))
-        d_mask.free()
-        cflags = (d_flags.download((hp.n_cells,), dtype=np.uint8) >> 1) & 1
-        d_flags.upload(np.ascontiguousarray(cflags))
-        d_qc = api.DeviceBuffer(n_el * B)
-        check(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_qc.ptr))
+        from ._lib import check as _chk     # (`check` is this method's flag)
+        _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+        cm = circuit if circuit is not None else self.circuit_map(d_flags)
+        if cm.n_cells != hp.n_cells or (cm.lookup_src is not None and len(cm.lookup_src) != hp.n_lookup):
+            raise ValueError("the constraint map does not describe this circuit (cell counts differ)")
+        self.circuit = cm
+        self.consts = [int(v) for v in cm.consts]
+        if len(self.consts) > self.usable:
+            raise ValueError("more distinct constants than usable rows of the fixed column")
+        if check:
+            self.keygen_report = self.mock_check(d_flags)
         d_flags.free()
-        self._fixed_poly("qc", d_qc, self.n_adv, keep_lag=False, keep_ext=False)
-        self._fixed_poly("fc", d_fc, self.n_adv, keep_lag=False, keep_ext=False)
-        # sigma columns: the overlap cell that ends gate column c is the cell that starts column c + 1
-        if copy_of is not None:
-            from .copymap import mapping_from_copy_of
-            from .pipeline import MINIMUM_ROWS
-            mapping = mapping_from_copy_of(copy_of, hp.bp, self.n_cols, rows, self.lookup_src, rows - MINIMUM_ROWS)
-        else:
-            mapping = (np.arange(self.n_cols, dtype=np.uint64)[:, None] << np.uint64(32)) | np.arange(rows, dtype=np.uint64)[None, :]
-            for c in range(self.n_adv - 1):
-                last = int(hp.bp[c])
-                mapping[c, last], mapping[c + 1, 0] = np.uint64((c + 1) << 32), np.uint64((c << 32) | last)
+        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
+        # sigma columns over [advice | lookup | constants]
+        from .copymap import mapping_from_copy_of
+        from .pipeline import MINIMUM_ROWS
+        # (a map without lookup sources leaves the lookup columns untied: only the tests' negative cases want that)
+        mapping = mapping_from_copy_of(cm.copy_of, hp.bp, self.n_cols, rows, cm.lookup_src if hp.n_lookup else None, rows - MINIMUM_ROWS,
+                                       const_idx=cm.const_idx, n_consts=len(self.consts))
         d_map = api.DeviceBuffer(mapping.nbytes)
         d_map.upload(np.ascontiguousarray(mapping))
-        d_sigma = api.DeviceBuffer(self.n_cols * rows * B)
-        check(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_cols), k, api._p(self.delta), d_sigma.ptr))
+        del mapping
+        d_sigma = api.DeviceBuffer(self.n_perm * rows * B)
+        _chk(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_perm), k, api._p(self.delta), d_sigma.ptr))
         d_map.free()
-        self._fixed_poly("sigma", d_sigma, self.n_cols, keep_lag=False, keep_ext=False)
+        self._fixed_poly("sigma", d_sigma, self.n_perm, keep_lag=False, keep_ext=False)
+        # the constants' fixed column: constant r at row r (halo2-base assigns the distinct constants of a circuit to fixed cells
+        # and ties every Constant advice cell to its fixed cell through the permutation)
+        cst = np.zeros((rows, 4), dtype=np.uint64)
+        if self.consts:
+            cst[: len(self.consts)] = api.fr_from_canonical(np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in self.consts], dtype=np.uint64))
+        d_cst = api.DeviceBuffer(rows * B)
+        d_cst.upload(cst)
+        self._fixed_poly("cst", d_cst, 1)
+        # its coset sits behind the advice cosets (the permutation term of the quotient reads one contiguous block of columns)
+        _chk(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
         tab[tab >= (1 << hp.L)] = 0
@@ -225,6 +232,40 @@ class ProverRounds:
         api.sync()
         return self._alloc_working_set()
 
+    def mock_check(self, d_flags=None):
+        """The Mock stage on the witness in HBM with this circuit's whole constraint map (vdb_mock_check_dev): gate rows, the
+        range table, every copy, every lookup source, every constant and asserted constant.  api.MockReport."""
+        hp = self.hp
+        cm = self.circuit
+        own = d_flags is None
+        if own:
+            d_flags = hp.keygen_flags()
+            hp._witness()
+        bufs = []
+
+        def dev(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            b = api.DeviceBuffer(max(a.nbytes, 32))
+            if a.nbytes:
+                b.upload(a)
+            bufs.append(b)
+            return b
+        try:
+            d_copy = dev(cm.copy_of, np.int64)
+            d_lsrc = dev(cm.lookup_src, np.int64) if hp.n_lookup and cm.lookup_src is not None else None
+            d_cidx = dev(cm.const_idx, np.int64)
+            tab = np.zeros((max(len(cm.consts), 1), 4), dtype=np.uint64)
+            if len(cm.consts):
+                tab[: len(cm.consts)] = api.fr_from_canonical(np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in cm.consts], dtype=np.uint64))
+            d_tab = dev(tab, np.uint64)
+            return api.mock_check_dev(hp.d_stream.ptr, hp.n_cells, d_flags.ptr, hp.d_lookup.ptr, hp.n_lookup, hp.L, d_copy.ptr,
+                                      None if d_lsrc is None else d_lsrc.ptr, None, d_cidx.ptr, d_tab.ptr, len(cm.consts))
+        finally:
+            for b in bufs:
+                b.free()
+            if own:
+                d_flags.free()
+
     def _alloc_working_set(self):
         lib, rows = self.lib, self.rows
         # the working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
@@ -235,8 +276,8 @@ class ProverRounds:
         check(lib.vdb_scratch_release())
         n_der = 3 * self.n_lk + self.n_sets
         self.pool_der = api.DeviceBuffer(max(n_der, 1) * rows * B)
-        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, 2 * self.n_cols * rows) * B)
-        self.d_blk = api.DeviceBuffer(min(self.n_cols, max(self.block_cols, 510)) * self.ne * B)
+        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, 2 * self.n_perm * rows) * B)
+        self.d_blk = api.DeviceBuffer(min(self.n_perm, max(self.block_cols, 510)) * self.ne * B)
         self.d_h = api.DeviceBuffer(self.ne * B)
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         return self
@@ -268,9 +309,8 @@ class ProverRounds:
             self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
             self.srs_few = api.Srs(k, hp.g_monomial, None)
             omega = api.root_of_unity(k)
-            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("qc", self.n_adv, False, False), ("fc", self.n_adv, False, False),
-                                                     ("sigma", self.n_cols, False, False), ("table", 1, True, True), ("lag", 3, False, True),
-                                                     ("inst", None, False, True)):
+            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("sigma", self.n_perm, False, False), ("cst", 1, True, True),
+                                                     ("table", 1, True, True), ("lag", 3, False, True), ("inst", None, False, True)):
                 coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
                 if n_cols is None:                      # instance cells: their number and positions come with the key
                     self.instance_cells = [int(c) for c in doc["instance_cells"]]
@@ -289,6 +329,7 @@ class ProverRounds:
                     check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
                 self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None,
                                          commits=np.ascontiguousarray(doc[name + "_commits"]))
+        check(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         api.sync()
         return self._alloc_working_set()
 
@@ -348,8 +389,13 @@ class ProverRounds:
         write_points(adv_commits)
         squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
-        d_lag = _View(self.pool_ext, 0, n_cols * rows * B)
-        stage("relayout", lambda: hp._layout(dest=d_lag))
+        n_perm = self.n_perm
+        d_lag = _View(self.pool_ext, 0, n_perm * rows * B)      # the permutation's columns in Lagrange form: advice, lookup, constants
+
+        def relayout():
+            hp._layout(dest=d_lag)
+            check(lib.vdb_memcpy_d2d(d_lag.at(n_cols * rows * B), fx["cst"].lag.ptr, _sz(rows * B)))
+        stage("relayout", relayout)
         lk_lag = ctypes.c_void_p(d_lag.ptr.value + n_adv * rows * B)
         polys = {"adv": adv}
 
@@ -373,12 +419,12 @@ class ProverRounds:
         squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
-        d_sigma_lag = _View(self.pool_ext, n_cols * rows * B, n_cols * rows * B)
+        d_sigma_lag = _View(self.pool_ext, n_perm * rows * B, n_perm * rows * B)
 
         def products():
-            check(lib.vdb_memcpy_d2d(d_sigma_lag.ptr, fx["sigma"].coeff.ptr, _sz(n_cols * rows * B)))
-            check(lib.vdb_ntt_batch_dev(d_sigma_lag.ptr, _sz(n_cols), k, api._p(api.root_of_unity(k)), 0))
-            check(lib.vdb_permutation_product_dev(d_lag.ptr, d_sigma_lag.ptr, _sz(n_cols), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
+            check(lib.vdb_memcpy_d2d(d_sigma_lag.ptr, fx["sigma"].coeff.ptr, _sz(n_perm * rows * B)))
+            check(lib.vdb_ntt_batch_dev(d_sigma_lag.ptr, _sz(n_perm), k, api._p(api.root_of_unity(k)), 0))
+            check(lib.vdb_permutation_product_dev(d_lag.ptr, d_sigma_lag.ptr, _sz(n_perm), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
                                                   api._p(self.delta), d_zp.ptr))
             check(lib.vdb_lookup_product_dev(lk_lag, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
                                              d_zl.ptr))
@@ -403,7 +449,7 @@ class ProverRounds:
         d_h = self.d_h
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
 
-        blk = min(n_cols, self.block_cols)
+        blk = min(n_perm, self.block_cols)
         d_blk = self.d_blk
 
         def quotient():
@@ -413,25 +459,16 @@ class ProverRounds:
                 nb = min(blk, n_adv - c0)
                 check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
                 check(lib.vdb_gate_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
-            # constants gate: qc a per column (qc cosets in blocks), then minus sum_c y^(n-1-c) fc_c — combined in coefficient form,
-            # extended once
-            for c0 in range(0, n_adv, blk):
-                nb = min(blk, n_adv - c0)
-                check(lib.vdb_coeff_to_extended_dev(fx["qc"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
-                check(lib.vdb_const_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
-            check(lib.vdb_memset_dev(self.d_comb.ptr, 0, _sz(rows * B)))
-            check(lib.vdb_poly_lincomb_dev(fx["fc"].coeff.ptr, _sz(n_adv), _sz(rows), p["y"], self.d_comb.ptr))
-            check(lib.vdb_coeff_to_extended_dev(self.d_comb.ptr, d_blk.ptr, _sz(1), k, EXT_K))
-            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-1)), d_blk.ptr, _sz(ne)))
             # public inputs: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
             for i, (col, _row) in enumerate(self.instance_pos):
                 l_ext = fx["inst"].ext.at(i * ne * B)
                 check(lib.vdb_const_eval_dev(adv.ext.at(col * ne * B), l_ext, _sz(1), k, EXT_K, p["y"], d_h.ptr))
                 check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
-            for c0 in range(0, n_cols, blk):
-                nb = min(blk, n_cols - c0)
+            # the permutation's columns: the advice and lookup cosets and, right behind them in the same buffer, the constants' coset
+            for c0 in range(0, n_perm, blk):
+                nb = min(blk, n_perm - c0)
                 check(lib.vdb_coeff_to_extended_dev(fx["sigma"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
-                check(lib.vdb_permutation_eval_range_dev(adv.ext.ptr, d_blk.ptr, polys["zp"].ext.ptr, _sz(n_cols), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la,
+                check(lib.vdb_permutation_eval_range_dev(adv.ext.ptr, d_blk.ptr, polys["zp"].ext.ptr, _sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la,
                                                          p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr, _sz(c0 // CHUNK_LEN),
                                                          _sz(-(-(c0 + nb) // CHUNK_LEN))))
             check(lib.vdb_lookup_eval_dev(ctypes.c_void_p(adv.ext.ptr.value + n_adv * ne * B), fx["table"].ext.ptr, polys["pa"].ext.ptr, polys["ps"].ext.ptr,
@@ -447,7 +484,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "qc", "fc", "sigma", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
@@ -650,14 +687,12 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
-    qc, fc = ev("qc"), ev("fc")
-    for c in range(n_adv):
-        acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
     for l_i, (col, _row), value in zip(ev("inst"), pr.instance_pos, instances if instances is not None else []):
         acc = (acc * yv + l_i * (a0[col] - value)) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
-    n_cols, n_sets = len(a0), len(z0)
+    pcols = list(a0) + list(ev("cst"))                  # the permutation's columns: advice, lookup, the constants' fixed column
+    n_cols, n_sets = len(pcols), len(z0)
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
     for i in range(1, n_sets):
@@ -666,8 +701,8 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     for i in range(n_sets):
         left, right = z1[i], z0[i]
         for c in range(i * CHUNK_LEN, min((i + 1) * CHUNK_LEN, n_cols)):
-            left = left * (a0[c] + b * sg[c] + g) % R
-            right = right * (a0[c] + cur + g) % R
+            left = left * (pcols[c] + b * sg[c] + g) % R
+            right = right * (pcols[c] + cur + g) % R
             cur = cur * delta % R
         acc = (acc * yv + la * (left - right)) % R
     A, S, PA, PS, PAm, Z, Z1 = a0[n_adv:], ev("table")[0], ev("pa"), ev("ps"), ev("pa", -1), ev("zl"), ev("zl", 1)

@@ -384,8 +384,10 @@ int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t ca
  *      constraint and every constant, checked on the witness where it lies in HBM (flat streams; device pointers).
  *      flags_dev: the flag byte per advice cell of a keygen-style run (bit 0 gate start, bit 1 constant cell);
  *      copy_of_dev[i] = the cell that cell i copies (i itself or negative: none); lookup_src_dev[j] = the advice cell
- *      lookup cell j copies; const_stream_dev: a stream of the same circuit whose constant cells hold the fixed values.
- *      Any of the last three may be null (that check is skipped).  Counts and the first offending index per kind. ------ */
+ *      lookup cell j copies; const_stream_dev: a stream of the same circuit whose constant cells hold the fixed values;
+ *      const_idx_dev[i] = r >= 0: cell i is tied to entry r of const_table_dev (n_consts field elements) — Constant cells
+ *      and assert_is_const alike.  Any of these may be null (that check is skipped; index and table go together).
+ *      Counts and the first offending index per kind. ------ */
 typedef struct {
   uint64_t gate_rows_violated, first_gate_row;
   uint64_t lookup_cells_out_of_table, first_lookup_cell;
@@ -395,7 +397,7 @@ typedef struct {
 } vdb_mock_report;
 int vdb_mock_check_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint8_t *flags_dev, const vdb_fr *lookup_dev, uint64_t n_lookup,
                        uint32_t lookup_bits, const int64_t *copy_of_dev, const int64_t *lookup_src_dev, const vdb_fr *const_stream_dev,
-                       vdb_mock_report *out);
+                       const int64_t *const_idx_dev, const vdb_fr *const_table_dev, uint64_t n_consts, vdb_mock_report *out);
 
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,
  *      R_P=57 as examples/merkle.rs:15-18; call sites src/gadget/vectordb.rs:180-182, 213-215) --- */

@@ -1,0 +1,162 @@
+"""The fixed-point circuits with their whole constraint map (halo2_vectordb_amd/circuit_sym.py) on GPU witnesses and through
+the prover rounds: what the reference's Mock arm (MockProver) and Prove arm (create_proof's permutation argument over every
+copy halo2-base records, src/scaffold/mod.rs:263-266, 296) enforce.
+
+* device MockProver with the map: GPU witnesses of distance / nearest_vector / k-means satisfy every gate, copy, constant and
+  lookup tie; Euclidean k-means violates only qlog2's asserted constants at iteration 0 and its proof is rejected;
+* a witness whose copy of a qmul result was altered (gates repaired around it) proves without the map and is rejected with it;
+* BASELINE configs[1] (nearest_vector over 64 x 128 at k = 14) proves and verifies with the whole map."""
+import numpy as np
+import pytest
+
+from test_gpu_rounds import FIXED, TAU, _meta, _verify
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init(0)
+    return a
+
+
+def table(O, consts):
+    return O.fr_from_ints(consts) if len(consts) else np.zeros((1, 4), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan"])
+def test_distance_witness_against_the_symbolic_map(api, O, metric):
+    """examples/distances.rs shape (two assigned vectors, one distance), P = 48, LOOKUP_BITS = 12: the GPU's cells under the
+    whole map, on the device checker"""
+    from halo2_vectordb_amd import circuit_sym as CS
+    dim = 4
+    cm, outs = CS.trace_distance(metric, dim, 48, 12)
+    rng = np.random.default_rng(3)
+    for a, b in ((rng.uniform(-2, 2, dim), rng.uniform(-2, 2, dim)), ([0.123, 0.456, 1.789, 1.123], [1.123, 0.456, 0.789, 0.123])):
+        qa, qb = api.quantize([a]), api.quantize([b])
+        got = api.wit_distance(metric, qa, qb, L=12, selectors=True)
+        stream = np.concatenate([qa[0], qb[0], got["stream"]])
+        flags = np.concatenate([np.zeros(2 * dim, dtype=np.uint8), got["flags"]])
+        assert stream.shape[0] == cm.n_cells and np.array_equal((flags & 1).astype(bool), cm.gate)
+        assert (cm.const_idx[(flags & 2) != 0] >= 0).all()          # every cell the kernels flag constant is a constant of the map
+        bufs = [api.DeviceBuffer(max(x.nbytes, 32)) for x in (stream, flags, got["lookup"], cm.copy_of, cm.lookup_src, cm.const_idx, table(O, cm.consts))]
+        for b_, x in zip(bufs, (stream, flags, got["lookup"], cm.copy_of, cm.lookup_src, cm.const_idx, table(O, cm.consts))):
+            b_.upload(np.ascontiguousarray(x))
+        rep = api.mock_check_dev(bufs[0].ptr, cm.n_cells, bufs[1].ptr, bufs[2].ptr, len(cm.lookup_src), 12, bufs[3].ptr, bufs[4].ptr, None, bufs[5].ptr, bufs[6].ptr,
+                                 len(cm.consts))
+        for b_ in bufs:
+            b_.free()
+        assert rep.violations() == 0, rep.as_dict()
+        assert np.array_equal(stream[outs[0]], got["result"][0])
+
+
+def test_kmeans_cosine_is_satisfied_and_euclidean_is_not(api, O):
+    """examples/kmeans.rs:48-49: "until I can solve the bug with euclidean, we are not using Euclidean distance".  With every
+    constraint in place the cosine circuit is satisfied; the Euclidean one violates exactly the asserted constants of qlog2 at
+    iteration 0 (each initial centroid is its own vector: qsqrt(0)) and nothing else, and its proof does not verify."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    out = {}
+    for metric in ("cosine", "euclidean"):
+        hp = KmeansHotPath(n=8, dim=4, K=2, I=2, k=12, L=11, metric=metric, tau=TAU).setup()
+        pr = ProverRounds(hp).keygen()
+        try:
+            rep = pr.keygen_report
+            proof = pr.prove(None, seed=3)
+            vk = dict(meta=_meta(pr), opened=proof["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
+                      instances=proof["instances"])
+            out[metric] = (rep.as_dict(), quotient_identity_holds(pr, proof["challenges"], proof["evals"], proof["instances"]), _verify(O, api, proof["proof"], vk))
+            # another database of the same shape under the same key
+            rng = np.random.default_rng(12)
+            hp.set_vectors(rng.integers(0, 219, size=(8, 4)).astype(np.float64) + rng.random((8, 4)))
+            rep2 = pr.mock_check()
+            assert (rep2.violations() == 0) == (metric == "cosine"), rep2.as_dict()
+        finally:
+            pr.free()
+            hp.free()
+    rep, ident, ok = out["cosine"]
+    assert sum(v for k, v in rep.items() if not k.startswith("first")) == 0 and ident and ok
+    rep, ident, ok = out["euclidean"]
+    assert rep["constants_changed"] > 0 and rep["gate_rows_violated"] == rep["copies_unequal"] == rep["lookup_copies_unequal"] == rep["lookup_cells_out_of_table"] == 0
+    assert not ident and not ok
+
+
+def test_an_altered_copy_of_a_qmul_result_is_rejected(api, O):
+    """The cheating prover the permutation argument is there for: in nearest_vector's first inner product, the cell of
+    `res = qadd(res, a_i b_i)` that copies the qmul's result is given another value and the gate's output is recomputed, so every
+    gate row still holds and every lookup cell is still in the table.  Without the gadget's copy map the proof verifies; with it
+    the device checker reports the broken copies and the verifier rejects."""
+    from halo2_vectordb_amd.circuit_sym import CopyMap
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    hp = NearestHotPath(n=6, dim=4, k=12, L=11, tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    cm = pr.circuit
+    # a gate [res, a_i b_i, 1, out]: operand cell (row + 1) copies an earlier cell, row + 2 is the constant one, out is fresh
+    rows = np.flatnonzero(cm.gate)
+    cand = [r for r in rows[200:] if cm.copy_of[r + 1] != r + 1 and cm.const_idx[r + 2] >= 0 and cm.consts[cm.const_idx[r + 2]] == 1
+            and cm.copy_of[r + 3] == r + 3 and cm.const_idx[r + 3] < 0 and cm.const_idx[r + 1] < 0]
+    row = int(cand[0])
+    honest = hp._witness
+    one = O.fr_from_ints([1])
+
+    def tampered(sel=None):
+        honest(sel)
+        if sel is None:
+            for cell in (row + 1, row + 3):           # operand + 1 and output + 1: the row still satisfies a + b * 1 = d
+                v = hp.d_stream.download((1, 4), offset=cell * 32)
+                hp.d_stream.upload(O.fr_add(v, one), offset=cell * 32)
+
+    tau_h = PR.pt_mul(PR.G2, TAU)
+    loose = ProverRounds(hp).keygen(circuit=CopyMap(np.arange(hp.n_cells, dtype=np.int64), cm.const_idx, cm.consts, cm.asserted, cm.gate, cm.lookup_src))
+    results = {}
+    try:
+        for label, p in (("whole map", pr), ("without the gadget's copies", loose)):
+            vk = lambda o: dict(meta=_meta(p), opened=o["opened"], fixed={name: p.fixed[name].commits for name in FIXED}, tau_h=tau_h, instances=o["instances"])
+            good = p.prove(None, seed=5)
+            assert _verify(O, api, good["proof"], vk(good)), label
+            hp._witness = tampered
+            try:
+                bad = p.prove(None, seed=5)
+                d_flags = api.DeviceBuffer(hp.n_cells)
+                d_flags.upload(cm.gate.astype(np.uint8))
+                rep = p.mock_check(d_flags)          # the tampered witness is what lies in HBM now
+                d_flags.free()
+            finally:
+                hp._witness = honest
+            results[label] = (rep.gate_rows_violated, rep.lookup_cells_out_of_table, rep.copies_unequal > 0,
+                              quotient_identity_holds(p, bad["challenges"], bad["evals"], bad["instances"]), _verify(O, api, bad["proof"], vk(bad)))
+    finally:
+        loose.free()
+        pr.free()
+        hp.free()
+    assert results["whole map"] == (0, 0, True, False, False)
+    assert results["without the gadget's copies"] == (0, 0, False, True, True)
+
+
+def test_c2_nearest_64x128_proves_with_the_whole_map(api, O):
+    """BASELINE configs[1]: nearest_vector query over 64 x 128-dim SIFT-shaped vectors, k = 14, a real KZG proof on one MI355X:
+    the whole constraint map in the permutation argument, proof bytes accepted by the stand-alone verifier (pairing check)"""
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    hp = NearestHotPath(n=64, dim=128, k=14, L=13, tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        cm = pr.circuit
+        tied = (cm.copy_of != np.arange(cm.n_cells)) | (cm.const_idx >= 0)
+        assert cm.n_cells == hp.n_cells and tied.mean() > 0.5
+        out = pr.prove(None)
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
+                  instances=out["instances"])
+        assert _verify(O, api, out["proof"], vk)
+        bad = bytearray(out["proof"])
+        bad[40] ^= 1
+        assert not _verify(O, api, bytes(bad), vk)
+    finally:
+        pr.free()
+        hp.free()

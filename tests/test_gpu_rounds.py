@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
-FIXED = ("sel", "qc", "fc", "sigma", "table", "lag", "inst")
+FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
@@ -20,8 +20,11 @@ def circuit():
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds
     api.init(0)
-    hp = KmeansHotPath(n=8, dim=4, K=2, I=1, k=11, L=10, tau=TAU).setup()
+    # the cosine variant: the satisfiable one (examples/kmeans.rs:48-49); Euclidean k-means breaks qlog2's asserted constants
+    # at iteration 0, where every initial centroid is at distance 0 of its own vector (tests/test_gpu_copymap.py shows that)
+    hp = KmeansHotPath(n=8, dim=4, K=2, I=1, k=12, L=11, metric="cosine", tau=TAU).setup()
     pr = ProverRounds(hp).keygen()
+    assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
     yield hp, pr
     pr.free()
     hp.free()
@@ -48,15 +51,14 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
     a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
-    qc, fc = ev("qc"), ev("fc")
-    for c in range(n_adv):
-        acc = (acc * yv + qc[c] * a0[c] - fc[c]) % R
     assert len(instances) == len(meta["instance_pos"])
     for l_i, (col, _row), value in zip(ev("inst"), meta["instance_pos"], instances):        # public inputs: L (a - value)
         acc = (acc * yv + l_i * (a0[col] - value)) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
-    n_cols, n_sets = len(a0), len(z0)
+    pcols = list(a0) + list(ev("cst"))      # the permutation's columns: advice, lookup, the constants' fixed column
+    n_cols, n_sets = len(pcols), len(z0)
+    assert n_cols == meta["n_cols"] + 1 and len(sg) == n_cols
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
     for i in range(1, n_sets):
@@ -65,8 +67,8 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
     for i in range(n_sets):
         left, right = z1[i], z0[i]
         for c in range(i * chunk, min((i + 1) * chunk, n_cols)):
-            left = left * (a0[c] + b * sg[c] + g) % R
-            right = right * (a0[c] + cur + g) % R
+            left = left * (pcols[c] + b * sg[c] + g) % R
+            right = right * (pcols[c] + cur + g) % R
             cur = cur * delta % R
         acc = (acc * yv + la * (left - right)) % R
     A, S, PA, PS, PAm, Z, Z1 = a0[n_adv:], ev("table")[0], ev("pa"), ev("ps"), ev("pa", -1), ev("zl"), ev("zl", 1)
@@ -128,10 +130,10 @@ def test_quotient_identity_from_the_returned_evaluations(circuit, proved, O):
     wrong = dict(out["evals"])
     wrong[("zl", 1)] = [(e + 1) % O.R_MOD for e in wrong[("zl", 1)]]
     assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
-    # the constants gate is part of the identity: a different constant polynomial breaks it
-    assert any(out["evals"][("qc", 0)]) and any(out["evals"][("fc", 0)])
+    # the constants' fixed column is one of the permutation's columns: another evaluation of it breaks the identity
+    assert len(out["evals"][("cst", 0)]) == 1 and len(out["evals"][("sigma", 0)]) == circuit[1].n_cols + 1
     wrong = dict(out["evals"])
-    wrong[("fc", 0)] = [(e + 1) % O.R_MOD for e in wrong[("fc", 0)]]
+    wrong[("cst", 0)] = [(e + 1) % O.R_MOD for e in wrong[("cst", 0)]]
     assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
 
 
@@ -182,7 +184,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
@@ -357,7 +359,7 @@ def test_proving_key_round_trip_gives_the_same_proof(circuit, tmp_path):
         assert got == want and len(got) > 0
     finally:
         pr2.free()
-    other = KmeansHotPath(n=8, dim=4, K=2, I=1, k=11, L=9, tau=TAU).setup()      # another lookup width: another circuit
+    other = KmeansHotPath(n=8, dim=4, K=2, I=1, k=12, L=10, metric="cosine", tau=TAU).setup()      # another lookup width: another circuit
     try:
         with pytest.raises(ValueError):
             ProverRounds(other).load_proving_key(path)
@@ -371,7 +373,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "qc": meta["n_adv"], "fc": meta["n_adv"], "sigma": meta["n_cols"], "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     pos = 0
     tr = api.Transcript()
@@ -535,9 +537,16 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
     hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU).setup()      # 6 leaves padded to 8 (the zero cell), odd width: 3 permutations per leaf
     pr = ProverRounds(hp).keygen()
     try:
-        copy_of = pr.copy_of
-        assert copy_of is not None and copy_of.size == hp.n_cells and (copy_of <= np.arange(copy_of.size)).all()
-        assert pr.n_pinned_init == 3 * (6 + 7)           # the initial sponge state of 6 leaves and 7 tree nodes, pinned as constants
+        cm = pr.circuit
+        copy_of = cm.copy_of
+        assert copy_of.size == hp.n_cells and (copy_of <= np.arange(copy_of.size)).all()
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        flags_d = hp.keygen_flags()
+        flagged = (flags_d.download((hp.n_cells,), dtype=np.uint8) & 2) != 0
+        flags_d.free()
+        # the constants: every cell the kernels flag, and the initial sponge state of 6 leaves and 7 tree nodes they emit unflagged
+        assert (cm.const_idx[flagged] >= 0).all() and int(((cm.const_idx >= 0) & ~flagged).sum()) == 3 * (6 + 7)
+        assert (1 << 64) in cm.consts and 0 in cm.consts and 1 in cm.consts
         tied = int((copy_of != np.arange(copy_of.size)).sum())
         assert tied > 0.4 * copy_of.size
         for seed in (1, 2):
@@ -550,10 +559,12 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
             assert np.array_equal(stream[: 6 * 5], hp.qvec.reshape(-1, 4))                  # the assigned vector words ...
             assert (copy_of[30:] < 30).sum() == 6 * 5                                       # ... each absorbed exactly once
             assert np.array_equal(stream[pr.root_cell], api.poseidon_merkle_root(hp.qvec))
-        # the permutation built from it is a permutation
-        mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows)
+            cst = np.flatnonzero(cm.const_idx >= 0)                                         # every constant cell holds its constant
+            assert np.array_equal(stream[cst], O.fr_from_ints(cm.consts)[cm.const_idx[cst]])
+        # the permutation built from it is a permutation of [advice | constants]
+        mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows, const_idx=cm.const_idx, n_consts=len(cm.consts))
         flat = (mapping >> np.uint64(32)).astype(np.int64) * pr.rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        assert np.array_equal(np.sort(flat.reshape(-1)), np.arange(pr.n_cols * pr.rows))
+        assert mapping.shape[0] == pr.n_cols + 1 and np.array_equal(np.sort(flat.reshape(-1)), np.arange((pr.n_cols + 1) * pr.rows))
         out = pr.prove(None, seed=8)
         assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
         assert out["instances"] == [O.fr_to_ints(api.poseidon_merkle_root(hp.qvec).reshape(1, 4))[0]]                # the public input is the root
@@ -585,8 +596,13 @@ def test_copy_constraints_are_enforced(O):
 
     tau_h = PR.pt_mul(PR.G2, TAU)
     results = {}
-    for label, copy_of in (("full map", None), ("layout ties only", np.arange(hp.n_cells, dtype=np.int64))):
-        pr = ProverRounds(hp).keygen(copy_of=copy_of)
+    from halo2_vectordb_amd.circuit_sym import CopyMap
+    for label in ("full map", "layout ties only"):
+        pr = ProverRounds(hp).keygen()
+        if label == "layout ties only":        # the same circuit with the copies of the Poseidon trace left out (constants stay pinned)
+            cm = pr.circuit
+            pr.free()
+            pr = ProverRounds(hp).keygen(circuit=CopyMap(np.arange(hp.n_cells, dtype=np.int64), cm.const_idx, cm.consts, cm.asserted, cm.gate, cm.lookup_src))
         try:
             vk = lambda out: dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=tau_h,
                                   instances=out["instances"])
@@ -613,11 +629,18 @@ def test_lookup_cells_are_tied_to_the_advice_cells_they_copy(circuit, O):
     from halo2_vectordb_amd import api
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     hp, pr = circuit
-    assert pr.lookup_src is not None and len(pr.lookup_src) == hp.n_lookup and (np.diff(pr.lookup_src) > 0).all()
+    from halo2_vectordb_amd.circuit_sym import CopyMap
+    from halo2_vectordb_amd.copymap import lookup_sources
+    cm = pr.circuit
+    assert len(cm.lookup_src) == hp.n_lookup
     hp._witness()
     api.sync()
     stream, lookup = hp.d_stream.download((hp.n_cells, 4)), hp.d_lookup.download((hp.n_lookup, 4))
-    assert np.array_equal(lookup, stream[pr.lookup_src])
+    assert np.array_equal(lookup, stream[cm.lookup_src])
+    # the kernels mark the same cells as lookup sources (flag bit 2) in the same order
+    d_flags = hp.keygen_flags()
+    assert np.array_equal(lookup_sources(d_flags.download((hp.n_cells,), dtype=np.uint8), hp.n_lookup), cm.lookup_src)
+    d_flags.free()
     honest = hp._witness
     swapped = O.fr_from_ints([(O.fr_to_ints(lookup[5].reshape(1, 4))[0] + 1) % (1 << hp.L)])       # another value of the table
 
@@ -626,7 +649,7 @@ def test_lookup_cells_are_tied_to_the_advice_cells_they_copy(circuit, O):
         if sel is None:
             hp.d_lookup.upload(swapped, offset=5 * 32)
 
-    loose = ProverRounds(hp).keygen(tie_lookups=False)
+    loose = ProverRounds(hp).keygen(circuit=CopyMap(cm.copy_of, cm.const_idx, cm.consts, cm.asserted, cm.gate, None))
     results = {}
     try:
         for label, p in (("tied", pr), ("untied", loose)):
@@ -650,7 +673,7 @@ def test_rounds_on_a_nearest_vector_circuit(O):
     hp = NearestHotPath(n=12, dim=6, k=12, L=11, tau=TAU).setup()
     pr = ProverRounds(hp).keygen()
     try:
-        assert pr.n_lk >= 1 and len(pr.lookup_src) == hp.n_lookup
+        assert pr.n_lk >= 1 and len(pr.circuit.lookup_src) == hp.n_lookup and pr.keygen_report.violations() == 0
         out = pr.prove(None, seed=6)
         vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
                   instances=out["instances"])

@@ -715,6 +715,13 @@ class DeviceBuffer:
             pass
 
 
+def mem_info():
+    """(free, total) bytes of HBM on this device"""
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    check(_lib.init().vdb_mem_info(ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
+
+
 def sync():
     check(_lib.init().vdb_sync())
 

@@ -315,6 +315,12 @@ int vdb_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   VDB_HIP(hipStreamSynchronize(ctx().stream));
   return VDB_OK;
 }
+int vdb_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(free_bytes && total_bytes, "null pointer");
+  VDB_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return VDB_OK;
+}
 int vdb_scratch_release(void) {
   VDB_REQUIRE_INIT();
   Context& c = ctx();

@@ -173,6 +173,8 @@ class KmeansHotPath:
         self.balance_shards = True  # equalise estimated time per rank instead of column count
         self.virtual_layout = True  # commit and transform straight from the witness stream (no stream -> column copy)
         self.msm_window_bits = 0    # 0 = the library's default (11 bits for k > 8: most witness scalars are short)
+        self.ext_block_cols = None  # columns of extended cosets held at a time; None = all if they fit, else what leaves ext_reserve_bytes free
+        self.ext_reserve_bytes = 64 << 30
 
     # ------------------------------------------------------------------ keygen-like setup (untimed)
     def setup(self, pinning=None):
@@ -270,9 +272,6 @@ class KmeansHotPath:
             check(lib.vdb_colsrc_build_lookup_dev(self.d_lookup.ptr, ctypes.c_uint64(self.n_lookup), self.k, MINIMUM_ROWS, ctypes.c_uint64(self.l_lo),
                                                   ctypes.c_uint64(self.l_hi), self.d_blind.at(self.n_adv_cols * N_BLIND * B), N_BLIND,
                                                   self.d_src.at(self.my_adv * 24)))
-        # one column more than this rank holds: the prover rounds keep the coset of the constants' fixed column behind the advice
-        # cosets, so that the permutation argument reads its columns from one contiguous block (rounds.py)
-        self.d_ext = api.DeviceBuffer((max(self.my_cols, 1) + 1) * self.rows * 4 * B)
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
         # (lookup columns hold no constants: their mask stays zero and their constant point is the identity)
@@ -299,6 +298,21 @@ class KmeansHotPath:
         self.const_cell_fraction = float(d_fmask.download((n_el,), dtype=np.uint8).mean()) if n_el <= (1 << 28) else None
         d_fmask.free()
         api.sync()
+        # The extended cosets, last: all of them when they fit beside everything above and leave the MSM its work space (C4:
+        # 68 GB), otherwise the largest block of columns that does — the cosets are then produced block after block into the
+        # same buffer (a circuit larger than HBM streams through: C4' cosine, 20.3 k columns = 170 GB of cosets; C5's Merkle).
+        # One column more than this rank holds: the prover rounds keep the coset of the constants' fixed column behind the
+        # advice cosets, so that the permutation argument reads its columns from one contiguous block (rounds.py).
+        check(lib.vdb_scratch_release())
+        per_col = self.rows * 4 * B
+        want = max(self.my_cols, 1) + 1
+        if self.ext_block_cols is None:
+            free, _ = api.mem_info()
+            fit = (free - self.ext_reserve_bytes) // per_col
+            self.ext_cols = want if fit >= want else int(max(min(want, 256), fit // 256 * 256))
+        else:
+            self.ext_cols = min(want, int(self.ext_block_cols))
+        self.d_ext = api.DeviceBuffer(self.ext_cols * per_col)
         return self
 
     # ------------------------------------------------------------------ blinding
@@ -409,7 +423,11 @@ class KmeansHotPath:
                 check(lib.vdb_lagrange_to_coeff_src_dev(self.d_src.ptr, my, ctypes.c_size_t(self.my_cols), self.k, N_BLIND))
             else:
                 check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
-            check(lib.vdb_coeff_to_extended_dev(my, self.d_ext.ptr, ctypes.c_size_t(self.my_cols), self.k, 2))
+            # cosets of all columns when the buffer holds them, else block after block into the same buffer
+            blk = min(self.ext_cols, max(self.my_cols, 1))
+            for c0 in range(0, self.my_cols, blk):
+                nb = min(blk, self.my_cols - c0)
+                check(lib.vdb_coeff_to_extended_dev(self.d_cols.at(c0 * self.rows * B), self.d_ext.ptr, ctypes.c_size_t(nb), self.k, 2))
             if self.blind_seed is None and blind_seed is None:
                 self._entropy = self._draw_entropy(None)      # the next proof's blinds, drawn while the GPU works on this one
             check(lib.vdb_msm_batch_end(api._p(self.commitments), ctypes.c_size_t(self.my_cols)))

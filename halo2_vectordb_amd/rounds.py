@@ -76,6 +76,7 @@ class _Poly:
 class ProverRounds:
     def __init__(self, hp, block_cols=BLOCK_COLS):
         assert hp.world == 1, "the prover rounds run on one rank's full column set"
+        assert hp.ext_cols >= hp.n_cols + 1, "the prover rounds read every advice coset from HBM: this circuit's cosets do not fit beside its streams"
         assert block_cols % CHUNK_LEN == 0
         self.block_cols = block_cols
         self.hp, self.lib = hp, hp.lib

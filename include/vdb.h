@@ -73,6 +73,7 @@ int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 /* Frees the library's cached work buffers (MSM buckets and sort records — up to half of the free HBM —, NTT staging); they
  * are re-created on demand.  For callers that need the memory between two phases.  Waits for queued work. */
 int vdb_scratch_release(void);
+int vdb_mem_info(size_t *free_bytes, size_t *total_bytes); /* HBM of the calling thread's device (hipMemGetInfo) */
 int vdb_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous on the library stream */
 int vdb_memset_dev(void *dst_dev, int value, size_t bytes);
 int vdb_sync(void);

@@ -270,3 +270,30 @@ def test_two_rank_timed_path_with_the_collective(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["gathered_commitments_match_unsharded_job"] is True
     assert out["value"] > 0 and out["roofline"]["launches_per_step"] > 0
+
+
+def test_extended_cosets_in_column_blocks(api, O):
+    """A circuit whose cosets do not fit HBM streams through: coeff_to_extended runs block after block into one buffer.
+    Forced here on a small circuit: same commitments and coefficients as the resident run, and the buffer ends up holding
+    the cosets of the last block, equal to the resident run's cosets of those columns and to the oracle's."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    cfg = dict(n=14, dim=6, K=3, I=2, k=11, P=48, L=9, seed=11, blind_seed=8)
+    full = KmeansHotPath(**cfg).setup()
+    assert full.ext_cols == full.n_cols + 1                      # everything fits: resident
+    com = full.step().copy()
+    ext_all = full.d_ext.download((full.n_cols, 4 * full.rows, 4))
+    coeff = full.d_cols.download((full.n_cols, full.rows, 4))
+    full.free()
+    hp = KmeansHotPath(**cfg)
+    hp.ext_block_cols = 7
+    hp.setup()
+    assert hp.ext_cols == 7 and hp.n_cols > 3 * 7
+    assert np.array_equal(hp.step(), com) and np.array_equal(hp.d_cols.download((hp.n_cols, hp.rows, 4)), coeff)
+    last0 = (hp.n_cols - 1) // 7 * 7
+    nb = hp.n_cols - last0
+    got = hp.d_ext.download((nb, 4 * hp.rows, 4))
+    assert np.array_equal(got, ext_all[last0:])
+    hp.relayout()
+    cols = hp.download_columns([last0])
+    assert np.array_equal(got[0], O.lde_batch(cols, ext=2)[1][0])
+    hp.free()

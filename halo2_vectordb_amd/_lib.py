@@ -87,6 +87,7 @@ _SIGNATURES = {
     "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
     "vdb_scratch_release": [], "vdb_mem_info": [_P, _P],
+    "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_axpy_dev": [_P, _P, _P, _SZ],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],

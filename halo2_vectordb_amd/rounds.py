@@ -182,18 +182,37 @@ class ProverRounds:
             self.keygen_report = self.mock_check(d_flags)
         d_flags.free()
         self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
-        # sigma columns over [advice | lookup | constants]
-        from .copymap import mapping_from_copy_of
+        # sigma columns over [advice | lookup | constants]: the cycles of the copy classes, built on the device
+        # (vdb_permutation_mapping_dev: pointer jumping, one radix sort; copymap.mapping_from_copy_of is the host restatement
+        # the tests compare it with).  A map without lookup sources leaves the lookup columns untied: only the tests' negative
+        # cases want that.
         from .pipeline import MINIMUM_ROWS
-        # (a map without lookup sources leaves the lookup columns untied: only the tests' negative cases want that)
-        mapping = mapping_from_copy_of(cm.copy_of, hp.bp, self.n_cols, rows, cm.lookup_src if hp.n_lookup else None, rows - MINIMUM_ROWS,
-                                       const_idx=cm.const_idx, n_consts=len(self.consts))
-        d_map = api.DeviceBuffer(mapping.nbytes)
-        d_map.upload(np.ascontiguousarray(mapping))
-        del mapping
+        parent = cm.copy_of.astype(np.int64, copy=True)
+        tied = cm.const_idx >= 0
+        if (parent[tied] != np.flatnonzero(tied)).any():
+            raise ValueError("a cell tied to a constant must be the root of its copies")
+        parent[tied] = hp.n_cells + cm.const_idx[tied]
+        d_parent = api.DeviceBuffer(parent.nbytes)
+        d_parent.upload(parent)
+        del parent
+        tie_lookups = bool(hp.n_lookup) and cm.lookup_src is not None
+        d_lsrc = None
+        if tie_lookups:
+            d_lsrc = api.DeviceBuffer(hp.n_lookup * 8)
+            d_lsrc.upload(np.ascontiguousarray(cm.lookup_src, dtype=np.int64))
+        d_map = api.DeviceBuffer(self.n_perm * rows * 8)
+        bp64 = np.ascontiguousarray(hp.bp, dtype=np.uint64)
+        _chk(lib.vdb_permutation_mapping_dev(d_parent.ptr, ctypes.c_uint64(hp.n_cells), ctypes.c_uint64(len(self.consts)), api._p(bp64), ctypes.c_uint64(len(bp64)), k,
+                                             d_lsrc.ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
+                                             ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols), d_map.ptr))
+        d_parent.free()
+        if d_lsrc is not None:
+            d_lsrc.free()
+        self._d_map_for_tests = d_map if getattr(self, "keep_mapping", False) else None
         d_sigma = api.DeviceBuffer(self.n_perm * rows * B)
         _chk(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_perm), k, api._p(self.delta), d_sigma.ptr))
-        d_map.free()
+        if self._d_map_for_tests is None:
+            d_map.free()
         self._fixed_poly("sigma", d_sigma, self.n_perm, keep_lag=False, keep_ext=False)
         # the constants' fixed column: constant r at row r (halo2-base assigns the distinct constants of a circuit to fixed cells
         # and ties every Constant advice cell to its fixed cell through the permutation)

@@ -380,6 +380,17 @@ int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
 int vdb_transcript_proof_len(const vdb_transcript *tr, size_t *len);
 int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t cap);
 
+/* ---- keygen: the permutation of the copy constraints, on the device.  Replaces the cycle construction of halo2's
+ *      keygen_vk / keygen_pk (plonk/permutation/keygen.rs Assembly, reached from src/scaffold/mod.rs:273) for circuits of
+ *      10^8 - 10^9 cells.  parent_dev[i], i < n_cells: the stream cell that advice cell i copies (an earlier cell, or i), or
+ *      n_cells + r: row r of the constants' fixed column (QuantumCell::Constant, assert_is_const); OVERWRITTEN with the roots.
+ *      break_points (host): rows per advice column as vdb_layout_plan gives them; lookup_src_dev[j]: the advice cell lookup cell
+ *      j copies (lookup cell j sits at row j % lookup_rows of column n_adv + j / lookup_rows).  n_cols = advice + lookup
+ *      columns; the fixed column is column n_cols.  mapping_dev: (n_cols + 1) x 2^k words col << 32 | row, the input of
+ *      vdb_permutation_sigma_dev. ------------------------------------------------------------------------------------ */
+int vdb_permutation_mapping_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
+                                const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols, uint64_t *mapping_dev);
+
 /* ---- Mock stage: replaces MockProver::run(k, &circuit, instances).assert_satisfied() of the reference's Mock arm
  *      (src/scaffold/mod.rs:263-266): every gate row a + b c = d, every lookup cell against the range table, every copy
  *      constraint and every constant, checked on the witness where it lies in HBM (flat streams; device pointers).

@@ -160,3 +160,36 @@ def test_c2_nearest_64x128_proves_with_the_whole_map(api, O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_device_permutation_mapping_has_the_cycles_of_the_host_construction(api, O):
+    """vdb_permutation_mapping_dev (pointer jumping + radix sort on the device) against copymap.mapping_from_copy_of (numpy): both
+    are permutations of the (n_cols + 1) x rows grid with exactly the same classes — the order inside a cycle is free"""
+    from halo2_vectordb_amd.copymap import mapping_from_copy_of
+    from halo2_vectordb_amd.pipeline import MINIMUM_ROWS, KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    hp = KmeansHotPath(n=6, dim=3, K=2, I=1, k=11, L=10, metric="cosine", tau=TAU).setup()
+    pr = ProverRounds(hp)
+    pr.keep_mapping = True
+    pr.keygen()
+    try:
+        cm, rows, n_perm = pr.circuit, pr.rows, pr.n_perm
+        dev = pr._d_map_for_tests.download((n_perm, rows), dtype=np.uint64)
+        host = mapping_from_copy_of(cm.copy_of, hp.bp, pr.n_cols, rows, cm.lookup_src, rows - MINIMUM_ROWS, const_idx=cm.const_idx, n_consts=len(cm.consts))
+
+        def classes(mapping):
+            nxt = ((mapping >> np.uint64(32)).astype(np.int64) * rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)).reshape(-1)
+            assert np.array_equal(np.sort(nxt), np.arange(nxt.size))              # a permutation
+            label = np.arange(nxt.size)
+            while True:                                                            # smallest index of each cycle, by pointer doubling
+                new = np.minimum(label, label[nxt])
+                nxt = nxt[nxt]
+                if np.array_equal(new, label):
+                    return label
+                label = new
+        assert np.array_equal(classes(dev), classes(host))
+        assert (classes(dev) != np.arange(n_perm * rows)).mean() > 0.3
+    finally:
+        pr._d_map_for_tests.free()
+        pr.free()
+        hp.free()

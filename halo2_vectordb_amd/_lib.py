@@ -95,6 +95,8 @@ _SIGNATURES = {
     "vdb_permutation_eval_range_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _SZ],
     "vdb_lookup_eval_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_product_dev": [_P, _P, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P],
+    "vdb_permutation_product_range_dev": [_P, _P, _SZ, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P], "vdb_permutation_chain_dev": [_P, _SZ, _U32, _SZ],
+    "vdb_permutation_eval_parts_dev": [_P, _SZ, _P, _P, _SZ, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _I, _SZ, _SZ, _SZ, _SZ],
     "vdb_colsrc_build_dev": [_P, _U64, _P, _U64, _U32, _U64, _U64, _P, _U32, _P],
     "vdb_colsrc_build_lookup_dev": [_P, _U64, _U32, _U32, _U64, _U64, _P, _U32, _P],
     "vdb_msm_batch_src_dev_begin": [_P, _I, _P, _SZ, _SZ, _U32, _P, _P], "vdb_lagrange_to_coeff_src_dev": [_P, _P, _SZ, _U32, _U32],

@@ -442,9 +442,18 @@ struct QuotArgs {
 // Sets [set_lo, set_hi) of the product terms; the terms that involve only the product columns come with set_lo == 0.
 // `sigma` points at the first column of set_lo (the sigma cosets may be produced block by block); bx = beta X, dstart =
 // 32 delta^(set_lo chunk_len).
+// Streaming form: `adv` holds the cosets of columns adv_col0 .., `z` those of product sets z_set0 .., `z_first` / `z_last` the
+// cosets of the first and the last product set (one column each); `head`: fold in the two terms that read only those;
+// [chain_lo, chain_hi): the sets i whose chaining term l0 (z_i - z_{i-1}(..)) is folded in (needs sets chain_lo - 1 .. chain_hi - 1
+// in `z`); [set_lo, set_hi): the sets whose product term is folded in.  A resident caller passes whole arrays and zero offsets.
+struct PermParts {
+  uint64_t adv_col0, z_set0, chain_lo, chain_hi;
+  const u256 *z_first, *z_last;
+  int head;
+};
 __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv, const u256* __restrict__ sigma, const u256* __restrict__ z, uint64_t n_cols,
                                                    uint32_t chunk_len, uint64_t set_lo, uint64_t set_hi, const u256* __restrict__ bx, u256 dstart, QuotArgs q,
-                                                   u256* __restrict__ acc) {
+                                                   PermParts pp, u256* __restrict__ acc) {
   const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
   const uint64_t mask = ne - 1, r = 1ull << q.e;
@@ -452,17 +461,22 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
   const L9 Y = l9_split(q.y), B = l9_split(q.beta), G = l9_split(q.gamma), D = l9_split(q.delta);
   const L9 L0 = l9_split32(ld256(q.l0 + j)), LL = l9_split32(ld256(q.l_last + j)), LA = l9_split32(ld256(q.l_active + j));
   L9 h = l9_split32(ld256(acc + j));
-  if (set_lo == 0) {
+  (void)n_sets;
+  z -= pp.z_set0 * ne;          // index by global set number from here on (only sets the caller provides are touched)
+  adv -= pp.adv_col0 * ne;
+  if (pp.head) {
     // l0 (1 - z_0)
-    h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(mont_one<Fr>()), l9_split32(ld256(z + j)), q.c34), L0);
+    h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(mont_one<Fr>()), l9_split32(ld256(pp.z_first + j)), q.c34), L0);
     // l_last (z_last^2 - z_last)
     {
-      const L9 zl = l9_split32(ld256(z + (n_sets - 1) * ne + j));
+      const L9 zl = l9_split32(ld256(pp.z_last + j));
       h = l9_mul2<Fr>(h, Y, l9_sub(l9_mul<Fr>(zl, zl), zl, q.c34), LL);
     }
+  }
+  if (pp.chain_lo < pp.chain_hi) {
     // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
     const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
-    for (uint64_t i = 1; i < n_sets; i++)
+    for (uint64_t i = pp.chain_lo; i < pp.chain_hi; i++)
       h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(ld256(z + i * ne + j)), l9_split32(ld256(z + (i - 1) * ne + jb)), q.c34), L0);
   }
   // l_active (z_i(w X) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma))
@@ -755,6 +769,55 @@ int vdb_permutation_sigma_dev(const uint64_t* mapping_dev, size_t n_cols, uint32
   return VDB_OK;
 }
 
+int vdb_permutation_chain_dev(vdb_fr* z_dev, size_t n_chunks, uint32_t k, size_t usable_rows) {
+  VDB_REQUIRE_INIT();
+  const uint64_t n = 1ull << (k <= 28 ? k : 0);
+  VDB_ARG(z_dev && k <= 28 && usable_rows < n, "bad argument");
+  if (n_chunks <= 1) return VDB_OK;
+  Context& cx = ctx();
+  u256* fac = (u256*)scratch_get(5, n_chunks * sizeof(u256));
+  if (!fac) return VDB_ERR_OOM;
+  {
+    VDB_PROF("k_chain");
+    hipLaunchKernelGGL(k_chain_factors, dim3(1), dim3(GP_THREADS), 0, cx.stream, as_u256(z_dev), (uint64_t)n_chunks, n, (uint64_t)usable_rows, fac);
+    hipLaunchKernelGGL(k_scale_columns, dim3((unsigned)((usable_rows + 1 + 255) / 256), (unsigned)(n_chunks - 1)), dim3(256), 0, cx.stream, as_u256(z_dev), n,
+                       (uint64_t)usable_rows + 1, fac);
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_permutation_product_range_dev(const vdb_fr* cols_block_dev, const vdb_fr* sigma_block_dev, size_t n_block_cols, size_t col0, uint32_t k, size_t usable_rows,
+                                      size_t chunk_len, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, vdb_fr* z_block_dev) {
+  VDB_REQUIRE_INIT();
+  const uint64_t n = 1ull << (k <= 28 ? k : 0);
+  VDB_ARG(cols_block_dev && sigma_block_dev && beta && gamma && delta && z_block_dev && k <= 28 && chunk_len >= 1 && usable_rows < n, "bad argument");
+  VDB_ARG(col0 % chunk_len == 0, "a block of columns starts at a chunk boundary");
+  if (n_block_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  const size_t n_chunks = (n_block_cols + chunk_len - 1) / chunk_len;
+  u256 bv, gv, dv;
+  memcpy(&bv, beta, 32);
+  memcpy(&gv, gamma, 32);
+  memcpy(&dv, delta, 32);
+  u256* buf = (u256*)scratch_get(5, (n + n_chunks + 2 * n_chunks * n) * sizeof(u256));
+  if (!buf) return VDB_ERR_OOM;
+  u256 *bw = buf, *dstart = bw + n, *num = dstart + n_chunks, *den = num + n_chunks * n;
+  u256 dchunk = mont_one<Fr>();
+  for (size_t i = 0; i < chunk_len; i++) dchunk = fr_mul(dchunk, dv);
+  // delta^(first column of chunk c of the block) = delta^col0 * (delta^chunk_len)^c
+  u256 e = u256_zero();
+  e.w[0] = (uint32_t)col0;
+  e.w[1] = (uint32_t)((uint64_t)col0 >> 32);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k), bv, n, bw);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, cx.stream, dchunk, mont_pow<Fr>(dv, e), (uint64_t)n_chunks, dstart);
+  if (usable_rows) {
+    VDB_PROF("k_perm_terms");
+    hipLaunchKernelGGL(k_perm_terms, dim3((unsigned)((usable_rows + 255) / 256), (unsigned)n_chunks), dim3(256), 0, cx.stream, as_u256(cols_block_dev),
+                       as_u256(sigma_block_dev), (uint64_t)n_block_cols, n, (uint64_t)usable_rows, (uint32_t)chunk_len, bw, bv, gv, dv, dstart, num, den);
+  }
+  VDB_LAUNCH_CHECK();
+  return product_columns(num, den, n_chunks, n, usable_rows, as_u256(z_block_dev));
+}
 int vdb_permutation_product_dev(const vdb_fr* cols_dev, const vdb_fr* sigma_dev, size_t n_cols, uint32_t k, size_t usable_rows, size_t chunk_len,
                                 const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, vdb_fr* z_dev) {
   VDB_REQUIRE_INIT();
@@ -838,10 +901,40 @@ static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const 
   return VDB_OK;
 }
 
+static int permutation_eval_parts(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
+                                  uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                                  const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
+                                  size_t set_lo, size_t set_hi, PermParts pp);
 int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
                                    uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
                                    const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
                                    size_t set_lo, size_t set_hi) {
+  // everything resident: whole arrays; the terms of the product columns alone come with the first range
+  VDB_ARG(z_ext_dev && chunk_len >= 1, "bad argument");
+  const size_t n_sets = (n_cols + chunk_len - 1) / chunk_len;
+  const uint64_t ne = 1ull << (k + ext_k);
+  PermParts pp{0, 0, set_lo == 0 ? 1u : 0u, set_lo == 0 ? n_sets : 0u, as_u256(z_ext_dev), as_u256(z_ext_dev) + (n_sets ? n_sets - 1 : 0) * ne, set_lo == 0};
+  return permutation_eval_parts(adv_ext_dev, sigma_ext_block_dev, z_ext_dev, n_cols, chunk_len, k, ext_k, usable_rows, l0_ext_dev, l_last_ext_dev, l_active_ext_dev,
+                                beta, gamma, delta, y, acc_dev, set_lo, set_hi, pp);
+}
+int vdb_permutation_eval_parts_dev(const vdb_fr* adv_ext_block_dev, size_t adv_col0, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_block_dev, size_t z_set0,
+                                   const vdb_fr* z_first_ext_dev, const vdb_fr* z_last_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k, uint32_t ext_k,
+                                   size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev, const vdb_fr* l_active_ext_dev, const vdb_fr* beta,
+                                   const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev, int head, size_t chain_lo, size_t chain_hi,
+                                   size_t set_lo, size_t set_hi) {
+  VDB_ARG(!head || (z_first_ext_dev && z_last_ext_dev), "the head terms read the first and the last product coset");
+  VDB_ARG(chain_lo >= chain_hi || (chain_lo >= 1 && chain_lo - 1 >= z_set0), "the chaining term of set i reads set i - 1");
+  VDB_ARG(set_lo >= set_hi || (set_lo >= z_set0 && set_lo * chunk_len >= adv_col0), "the block buffers start after the first set asked for");
+  PermParts pp{adv_col0, z_set0, chain_lo, chain_hi, as_u256(z_first_ext_dev), as_u256(z_last_ext_dev), head};
+  // (a call without product terms still needs non-null column pointers for the argument check: any device pointer does)
+  return permutation_eval_parts(adv_ext_block_dev ? adv_ext_block_dev : acc_dev, sigma_ext_block_dev ? sigma_ext_block_dev : acc_dev,
+                                z_ext_block_dev ? z_ext_block_dev : acc_dev, n_cols, chunk_len, k, ext_k, usable_rows, l0_ext_dev, l_last_ext_dev,
+                                l_active_ext_dev, beta, gamma, delta, y, acc_dev, set_lo, set_hi, pp);
+}
+static int permutation_eval_parts(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
+                                  uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                                  const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
+                                  size_t set_lo, size_t set_hi, PermParts pp) {
   VDB_REQUIRE_INIT();
   VDB_ARG(adv_ext_dev && sigma_ext_block_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta && gamma && delta && y && acc_dev,
           "null pointer");
@@ -867,7 +960,7 @@ int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigm
     e.w[1] = (uint32_t)(pw >> 32);
     hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_block_dev),
                        as_u256(z_ext_dev), (uint64_t)n_cols, (uint32_t)chunk_len, (uint64_t)set_lo, (uint64_t)set_hi, bx,
-                       fr_mul(mont_pow<Fr>(delta_m, e), host_fr_from_u64(32)), q, as_u256(acc_dev));
+                       fr_mul(mont_pow<Fr>(delta_m, e), host_fr_from_u64(32)), q, pp, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;

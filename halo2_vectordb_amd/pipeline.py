@@ -390,7 +390,9 @@ class KmeansHotPath:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
     # ------------------------------------------------------------------ one pass of the hot path
-    def step(self, timings=None, blind_seed=None):
+    def step(self, timings=None, blind_seed=None, with_ext=True):
+        """`with_ext`: False leaves coeff_to_extended out (a caller that streams the cosets itself, block by block: rounds.py on
+        circuits whose cosets do not fit HBM)"""
         lib, B = self.lib, 32
         self.refresh_blinds(blind_seed)
 
@@ -425,7 +427,7 @@ class KmeansHotPath:
                 check(lib.vdb_lagrange_to_coeff_dev(my, ctypes.c_size_t(self.my_cols), self.k))
             # cosets of all columns when the buffer holds them, else block after block into the same buffer
             blk = min(self.ext_cols, max(self.my_cols, 1))
-            for c0 in range(0, self.my_cols, blk):
+            for c0 in range(0, self.my_cols if with_ext else 0, blk):
                 nb = min(blk, self.my_cols - c0)
                 check(lib.vdb_coeff_to_extended_dev(self.d_cols.at(c0 * self.rows * B), self.d_ext.ptr, ctypes.c_size_t(nb), self.k, 2))
             if self.blind_seed is None and blind_seed is None:

@@ -76,7 +76,6 @@ class _Poly:
 class ProverRounds:
     def __init__(self, hp, block_cols=BLOCK_COLS):
         assert hp.world == 1, "the prover rounds run on one rank's full column set"
-        assert hp.ext_cols >= hp.n_cols + 1, "the prover rounds read every advice coset from HBM: this circuit's cosets do not fit beside its streams"
         assert block_cols % CHUNK_LEN == 0
         self.block_cols = block_cols
         self.hp, self.lib = hp, hp.lib
@@ -223,7 +222,8 @@ class ProverRounds:
         d_cst.upload(cst)
         self._fixed_poly("cst", d_cst, 1)
         # its coset sits behind the advice cosets (the permutation term of the quotient reads one contiguous block of columns)
-        _chk(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
+        if hp.ext_cols >= self.n_cols + 1:
+            _chk(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
         tab[tab >= (1 << hp.L)] = 0
@@ -288,16 +288,21 @@ class ProverRounds:
 
     def _alloc_working_set(self):
         lib, rows = self.lib, self.rows
-        # the working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
-        # [pa | ps | zp | zl] in Lagrange / coefficient form, their extended cosets, a block of fixed cosets, h.  The
-        # Lagrange images of the advice and sigma columns (the latter recovered from its coefficients by a forward transform
-        # each time) are dead before the derived cosets exist and share their memory.  The
-        # library's MSM scratch is released first so that it is re-sized to what is left.
+        # The working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
+        # [pa | ps | zp | zl] (Lagrange, then coefficient form in place), the lookup columns laid out, and block buffers of
+        # `block_cols` columns — two in Lagrange form (the permutation's columns and their sigma columns), two of extended
+        # cosets, one of product cosets — through which every per-column stage streams.  The library's MSM scratch is released
+        # first so that it is re-sized to what is left.
         check(lib.vdb_scratch_release())
         n_der = 3 * self.n_lk + self.n_sets
+        blk = max(2 * CHUNK_LEN, min(self.block_cols, -(-self.n_perm // (2 * CHUNK_LEN)) * (2 * CHUNK_LEN)) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
+        self.blk_alloc = blk
         self.pool_der = api.DeviceBuffer(max(n_der, 1) * rows * B)
-        self.pool_ext = api.DeviceBuffer(max(max(n_der, 1) * self.ne, 2 * self.n_perm * rows) * B)
-        self.d_blk = api.DeviceBuffer(min(self.n_perm, max(self.block_cols, 510)) * self.ne * B)
+        self.d_lklag = api.DeviceBuffer(max(self.n_lk, 1) * rows * B)
+        self.d_lag_a, self.d_lag_s = api.DeviceBuffer(blk * rows * B), api.DeviceBuffer(blk * rows * B)
+        self.d_ea, self.d_eb = api.DeviceBuffer(blk * self.ne * B), api.DeviceBuffer(blk * self.ne * B)
+        self.d_ez = api.DeviceBuffer((blk // CHUNK_LEN + 1) * self.ne * B)
+        self.d_zf, self.d_zlast = api.DeviceBuffer(self.ne * B), api.DeviceBuffer(self.ne * B)
         self.d_h = api.DeviceBuffer(self.ne * B)
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         return self
@@ -349,7 +354,8 @@ class ProverRounds:
                     check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
                 self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None,
                                          commits=np.ascontiguousarray(doc[name + "_commits"]))
-        check(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
+        if hp.ext_cols >= self.n_cols + 1:
+            check(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         api.sync()
         return self._alloc_working_set()
 
@@ -398,7 +404,8 @@ class ProverRounds:
             return r
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
-        adv_commits = hp.step(T, blind_seed=None if seed is None else [int(seed), 0]).copy()
+        resident = hp.ext_cols >= n_cols + 1       # every advice coset stays in HBM; otherwise they are recomputed block by block below
+        adv_commits = hp.step(T, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident).copy()
         if instances is None:
             instances = [hp.d_stream.download((4,), offset=cell * 32) for cell in self.instance_cells]
         instances = [np.ascontiguousarray(v, dtype=np.uint64) for v in instances]
@@ -408,27 +415,58 @@ class ProverRounds:
                 tr.common_scalar(v)
         write_points(adv_commits)
         squeeze("theta")
-        adv = _Poly("adv", n_cols, coeff=hp.d_cols, ext=hp.d_ext, commits=adv_commits)
+        adv = _Poly("adv", n_cols, coeff=hp.d_cols, commits=adv_commits)
         n_perm = self.n_perm
-        d_lag = _View(self.pool_ext, 0, n_perm * rows * B)      # the permutation's columns in Lagrange form: advice, lookup, constants
-
-        def relayout():
-            hp._layout(dest=d_lag)
-            check(lib.vdb_memcpy_d2d(d_lag.at(n_cols * rows * B), fx["cst"].lag.ptr, _sz(rows * B)))
-        stage("relayout", relayout)
-        lk_lag = ctypes.c_void_p(d_lag.ptr.value + n_adv * rows * B)
         polys = {"adv": adv}
+        # Everything below works on blocks of `blk` columns: the Lagrange forms, the sigma columns and every extended coset
+        # exist one block at a time (the advice cosets too, unless the hot path keeps them resident); what stays in HBM is the
+        # streams, the coefficient forms and the derived columns.
+        blk = max(2 * CHUNK_LEN, min(self.block_cols, self.blk_alloc) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
+        blk_l = blk // 2
+        d_lag_a, d_lag_s, d_ea, d_eb, d_ez, d_zf, d_zlast, d_lklag = self.d_lag_a, self.d_lag_s, self.d_ea, self.d_eb, self.d_ez, self.d_zf, self.d_zlast, self.d_lklag
+        omega = api.root_of_unity(k)
+        bp_p, n_bp = api._p(hp.bp), ctypes.c_uint64(len(hp.bp))
+        from .pipeline import MINIMUM_ROWS
+        lk_blind = hp.d_blind.at(hp.n_adv_cols * N_BLIND * B)
+
+        def lagrange_block(c0, nb, dest):
+            """the permutation's columns c0 .. c0 + nb in Lagrange form: advice from the stream, lookup from their laid-out copy, constants"""
+            a1, l0_, l1_ = min(c0 + nb, n_adv), max(c0, n_adv), min(c0 + nb, n_cols)
+            if c0 < a1:
+                check(lib.vdb_layout_columns_range_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), bp_p, n_bp, k, ctypes.c_uint64(c0), ctypes.c_uint64(a1),
+                                                       dest.ptr, hp.d_blind.ptr, N_BLIND))
+            if l0_ < l1_:
+                check(lib.vdb_memcpy_d2d(dest.at((l0_ - c0) * rows * B), d_lklag.at((l0_ - n_adv) * rows * B), _sz((l1_ - l0_) * rows * B)))
+            if c0 + nb > n_cols:
+                check(lib.vdb_memcpy_d2d(dest.at((n_cols - c0) * rows * B), fx["cst"].lag.ptr, _sz(rows * B)))
+
+        def adv_ext_block(c0, nb):
+            """(pointer, first column) of a buffer that holds the cosets of the permutation's columns c0 .. c0 + nb"""
+            if resident:
+                return hp.d_ext.ptr, 0
+            n_real = max(0, min(c0 + nb, n_cols) - c0)
+            if n_real:
+                check(lib.vdb_coeff_to_extended_dev(hp.d_cols.at(c0 * rows * B), d_ea.ptr, _sz(n_real), k, EXT_K))
+            if c0 + nb > n_cols:
+                check(lib.vdb_memcpy_d2d(d_ea.at(n_real * ne * B), fx["cst"].ext.ptr, _sz(ne * B)))
+            return d_ea.ptr, c0
+
+        def col_ptr(base, col0, c):
+            return ctypes.c_void_p(base.value + (c - col0) * ne * B)
 
         # round 2: the lookup argument's permuted columns
         counts = {"pa": n_lk, "ps": n_lk, "zp": n_sets, "zl": n_lk}
-        der, ext_of, off = {}, {}, 0
+        der, off = {}, 0
         for name, m in counts.items():
-            der[name], ext_of[name] = _View(self.pool_der, off * rows * B, m * rows * B), _View(self.pool_ext, off * ne * B, m * ne * B)
+            der[name] = _View(self.pool_der, off * rows * B, m * rows * B)
             off += m
         d_pa, d_ps, d_zp, d_zl = der["pa"], der["ps"], der["zp"], der["zl"]
 
         def permute():
-            check(lib.vdb_lookup_permute_dev(lk_lag, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
+            if n_lk:
+                check(lib.vdb_layout_lookup_range_dev(hp.d_lookup.ptr, ctypes.c_uint64(hp.n_lookup), k, MINIMUM_ROWS, ctypes.c_uint64(0), ctypes.c_uint64(n_lk),
+                                                      d_lklag.ptr, lk_blind, N_BLIND))
+            check(lib.vdb_lookup_permute_dev(d_lklag.ptr, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
         stage("lookup_permute", permute)
         self._blind(d_pa, n_lk, usable, next(seeds))
         self._blind(d_ps, n_lk, usable, next(seeds))
@@ -439,14 +477,16 @@ class ProverRounds:
         squeeze("beta", "gamma")
 
         # round 3 (beta, gamma): the running products of both arguments
-        d_sigma_lag = _View(self.pool_ext, n_perm * rows * B, n_perm * rows * B)
-
         def products():
-            check(lib.vdb_memcpy_d2d(d_sigma_lag.ptr, fx["sigma"].coeff.ptr, _sz(n_perm * rows * B)))
-            check(lib.vdb_ntt_batch_dev(d_sigma_lag.ptr, _sz(n_perm), k, api._p(api.root_of_unity(k)), 0))
-            check(lib.vdb_permutation_product_dev(d_lag.ptr, d_sigma_lag.ptr, _sz(n_perm), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
-                                                  api._p(self.delta), d_zp.ptr))
-            check(lib.vdb_lookup_product_dev(lk_lag, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
+            for c0 in range(0, n_perm, blk):
+                nb = min(blk, n_perm - c0)
+                lagrange_block(c0, nb, d_lag_a)
+                check(lib.vdb_memcpy_d2d(d_lag_s.ptr, fx["sigma"].coeff.at(c0 * rows * B), _sz(nb * rows * B)))
+                check(lib.vdb_ntt_batch_dev(d_lag_s.ptr, _sz(nb), k, api._p(omega), 0))
+                check(lib.vdb_permutation_product_range_dev(d_lag_a.ptr, d_lag_s.ptr, _sz(nb), _sz(c0), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
+                                                            api._p(self.delta), d_zp.at(c0 // CHUNK_LEN * rows * B)))
+            check(lib.vdb_permutation_chain_dev(d_zp.ptr, _sz(n_sets), k, _sz(usable)))
+            check(lib.vdb_lookup_product_dev(d_lklag.ptr, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
                                              d_zl.ptr))
         stage("products", products)
         self._blind(d_zp, n_sets, usable + 1, next(seeds))
@@ -463,36 +503,65 @@ class ProverRounds:
                 q = polys[name]
                 check(lib.vdb_lagrange_to_coeff_dev(q.lag.ptr, _sz(q.n_cols), k))      # in place: the Lagrange form is not needed again
                 q.coeff, q.lag = q.lag, None
-                q.ext = ext_of[name]
-                check(lib.vdb_coeff_to_extended_dev(q.coeff.ptr, q.ext.ptr, _sz(q.n_cols), k, EXT_K))
         stage("derived_ntt", derived_forms)
         d_h = self.d_h
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
+        zp = polys["zp"]
 
-        blk = min(n_perm, self.block_cols)
-        d_blk = self.d_blk
+        def to_ext(coeff_ptr, dest_ptr, m):
+            check(lib.vdb_coeff_to_extended_dev(coeff_ptr, dest_ptr, _sz(m), k, EXT_K))
 
         def quotient():
             check(lib.vdb_memset_dev(d_h.ptr, 0, _sz(ne * B)))
-            # the selector and sigma cosets are produced from their coefficients a block of columns at a time
+            # the gates: advice and selector cosets a block of columns at a time
             for c0 in range(0, n_adv, blk):
                 nb = min(blk, n_adv - c0)
-                check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
-                check(lib.vdb_gate_eval_dev(adv.ext.at(c0 * ne * B), d_blk.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
+                base, col0 = adv_ext_block(c0, nb)
+                to_ext(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
+                check(lib.vdb_gate_eval_dev(col_ptr(base, col0, c0), d_eb.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
             # public inputs: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
             for i, (col, _row) in enumerate(self.instance_pos):
                 l_ext = fx["inst"].ext.at(i * ne * B)
-                check(lib.vdb_const_eval_dev(adv.ext.at(col * ne * B), l_ext, _sz(1), k, EXT_K, p["y"], d_h.ptr))
+                base, col0 = adv_ext_block(col, 1)
+                check(lib.vdb_const_eval_dev(col_ptr(base, col0, col), l_ext, _sz(1), k, EXT_K, p["y"], d_h.ptr))
                 check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
-            # the permutation's columns: the advice and lookup cosets and, right behind them in the same buffer, the constants' coset
+            # the permutation argument.  First the terms of the product columns alone: l0 (1 - z_0), l_last (z_last^2 - z_last), and
+            # the chaining l0 (z_i - z_{i-1}(..)) for i = 1 .. n_sets - 1, the product cosets a block of sets at a time
+            to_ext(zp.coeff.ptr, d_zf.ptr, 1)
+            to_ext(zp.coeff.at((n_sets - 1) * rows * B), d_zlast.ptr, 1)
+            zcap = blk // CHUNK_LEN + 1                                # product cosets d_ez holds
+            perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr)
+            s0 = 0
+            while True:
+                s1 = min(n_sets, s0 + zcap - 1 if s0 else zcap)
+                z0 = max(s0 - 1, 0)
+                to_ext(zp.coeff.at(z0 * rows * B), d_ez.ptr, s1 - z0)
+                check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), d_zf.ptr, d_zlast.ptr, *perm_args, int(s0 == 0), _sz(max(s0, 1)), _sz(s1),
+                                                         _sz(0), _sz(0)))
+                s0 = s1
+                if s0 >= n_sets:
+                    break
+            # then the product terms, set after set: the columns of a block with their sigma columns and their product columns
             for c0 in range(0, n_perm, blk):
                 nb = min(blk, n_perm - c0)
-                check(lib.vdb_coeff_to_extended_dev(fx["sigma"].coeff.at(c0 * rows * B), d_blk.ptr, _sz(nb), k, EXT_K))
-                check(lib.vdb_permutation_eval_range_dev(adv.ext.ptr, d_blk.ptr, polys["zp"].ext.ptr, _sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la,
-                                                         p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr, _sz(c0 // CHUNK_LEN),
-                                                         _sz(-(-(c0 + nb) // CHUNK_LEN))))
-            check(lib.vdb_lookup_eval_dev(ctypes.c_void_p(adv.ext.ptr.value + n_adv * ne * B), fx["table"].ext.ptr, polys["pa"].ext.ptr, polys["ps"].ext.ptr,
-                                          polys["zl"].ext.ptr, _sz(n_lk), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], d_h.ptr))
+                set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
+                base, col0 = adv_ext_block(c0, nb)
+                to_ext(fx["sigma"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
+                to_ext(zp.coeff.at(set_lo * rows * B), d_ez.ptr, set_hi - set_lo)
+                check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(set_lo), None, None, *perm_args, 0, _sz(0), _sz(0), _sz(set_lo), _sz(set_hi)))
+            # the lookup argument, a block of lookup columns at a time: [input | product] cosets in one buffer, [permuted input | table] in the other
+            for j0 in range(0, n_lk, blk_l):
+                nb = min(blk_l, n_lk - j0)
+                if resident:
+                    a_ext, z_ext = hp.d_ext.at((n_adv + j0) * ne * B), d_ea.ptr
+                else:
+                    to_ext(hp.d_cols.at((n_adv + j0) * rows * B), d_ea.ptr, nb)
+                    a_ext, z_ext = d_ea.ptr, d_ea.at(blk_l * ne * B)
+                to_ext(polys["zl"].coeff.at(j0 * rows * B), z_ext, nb)
+                to_ext(polys["pa"].coeff.at(j0 * rows * B), d_eb.ptr, nb)
+                to_ext(polys["ps"].coeff.at(j0 * rows * B), d_eb.at(blk_l * ne * B), nb)
+                check(lib.vdb_lookup_eval_dev(a_ext, fx["table"].ext.ptr, d_eb.ptr, d_eb.at(blk_l * ne * B), z_ext, _sz(nb), k, EXT_K, l0, ll, la,
+                                              p["beta"], p["gamma"], p["y"], d_h.ptr))
             check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
             check(lib.vdb_extended_to_coeff_dev(d_h.ptr, _sz(1), k, EXT_K))
         stage("quotient", quotient)
@@ -684,7 +753,7 @@ class ProverRounds:
         for q in self.fixed.values():
             q.free()
         self.fixed = {}
-        for name in ("pool_der", "pool_ext", "d_blk", "d_h", "d_comb", "d_quot"):
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_comb", "d_quot"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

@@ -318,6 +318,24 @@ int vdb_permutation_eval_range_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigm
                                    uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
                                    const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev,
                                    size_t set_lo, size_t set_hi);
+/* Streaming forms for circuits whose columns do not all fit HBM at once (the rounds then work on blocks of columns):
+ * vdb_permutation_product_range_dev: the running products of the chunks of ONE block of columns (cols_block / sigma_block hold
+ * columns col0 .. col0 + n_block_cols, col0 a multiple of chunk_len), each starting from one; vdb_permutation_chain_dev then
+ * puts all chunks of all blocks on one chain (z_c starts where z_{c-1} ended), as vdb_permutation_product_dev does in one go.
+ * vdb_permutation_eval_parts_dev: the permutation part of the quotient numerator with block buffers — adv_ext_block holds the
+ * cosets of columns adv_col0 .., z_ext_block those of product sets z_set0 .., z_first / z_last the cosets of the first and last
+ * set; `head`: fold in l0 (1 - z_0) and l_last (z_last^2 - z_last); [chain_lo, chain_hi): fold in l0 (z_i - z_{i-1}(..)) for these
+ * sets (reads sets chain_lo - 1 .. chain_hi - 1); [set_lo, set_hi): fold in the product terms of these sets (reads their columns,
+ * sigma_ext_block starting at column set_lo * chunk_len).  Terms must be folded in the order head, chain 1 .. n_sets - 1, products
+ * 0 .. n_sets - 1 to agree with the resident form. */
+int vdb_permutation_product_range_dev(const vdb_fr *cols_block_dev, const vdb_fr *sigma_block_dev, size_t n_block_cols, size_t col0, uint32_t k,
+                                      size_t usable_rows, size_t chunk_len, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *delta, vdb_fr *z_block_dev);
+int vdb_permutation_chain_dev(vdb_fr *z_dev, size_t n_chunks, uint32_t k, size_t usable_rows);
+int vdb_permutation_eval_parts_dev(const vdb_fr *adv_ext_block_dev, size_t adv_col0, const vdb_fr *sigma_ext_block_dev, const vdb_fr *z_ext_block_dev, size_t z_set0,
+                                   const vdb_fr *z_first_ext_dev, const vdb_fr *z_last_ext_dev, size_t n_cols, size_t chunk_len, uint32_t k, uint32_t ext_k,
+                                   size_t usable_rows, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev, const vdb_fr *l_active_ext_dev, const vdb_fr *beta,
+                                   const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev, int head, size_t chain_lo, size_t chain_hi,
+                                   size_t set_lo, size_t set_hi);
 int vdb_lookup_eval_dev(const vdb_fr *input_ext_dev, const vdb_fr *table_ext_dev, const vdb_fr *perm_input_ext_dev, const vdb_fr *perm_table_ext_dev,
                         const vdb_fr *z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *l0_ext_dev, const vdb_fr *l_last_ext_dev,
                         const vdb_fr *l_active_ext_dev, const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);

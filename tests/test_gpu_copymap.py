@@ -193,3 +193,30 @@ def test_device_permutation_mapping_has_the_cycles_of_the_host_construction(api,
         pr._d_map_for_tests.free()
         pr.free()
         hp.free()
+
+
+def test_streamed_rounds_give_the_resident_proof(api, O):
+    """A circuit whose extended cosets do not fit HBM proves by streaming: the advice cosets are recomputed a block of columns at
+    a time inside the quotient, the permutation's Lagrange and sigma columns and every derived coset exist one block at a time.
+    Forced here on a small circuit (7 coset columns held, blocks of 12 columns): byte-identical proof to the resident run."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    cfg = dict(n=8, dim=4, K=2, I=1, k=12, L=11, metric="cosine", tau=TAU)
+    proofs = {}
+    for label, ext_block, block_cols in (("resident", None, 510), ("streamed", 7, 12)):
+        hp = KmeansHotPath(**cfg)
+        hp.ext_block_cols = ext_block
+        hp.setup()
+        pr = ProverRounds(hp, block_cols=block_cols).keygen()
+        try:
+            assert (hp.ext_cols >= hp.n_cols + 1) == (label == "resident") and pr.n_perm > 5 * 12
+            out = pr.prove(None, seed=9)
+            vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
+                      instances=out["instances"])
+            assert _verify(O, api, out["proof"], vk), label
+            proofs[label] = out["proof"]
+        finally:
+            pr.free()
+            hp.free()
+    assert proofs["resident"] == proofs["streamed"]

@@ -163,7 +163,8 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   const uint64_t total = n_cells + n_bp + n_lookup + n_consts;
   uint64_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
   for (uint64_t** q : {&keys, &vals, &keys2, &vals2}) {
-    VDB_HIP(hipMalloc(q, total * sizeof(uint64_t)));
+    hipError_t e = hipMalloc(q, total * sizeof(uint64_t));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(permutation records: 4 x 8 B per grid position of a copy class)", __FILE__, __LINE__);
     guard.p.push_back(*q);
   }
   {
@@ -174,15 +175,19 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   // 3. sort by root
   unsigned end_bit = 1;
   while (end_bit < 64 && ((n_cells + n_consts) >> end_bit)) end_bit++;
+  // double-buffered: the two copies of the records are the sort's own ping-pong storage, the temporary storage is histograms only
+  rocprim::double_buffer<uint64_t> dk(keys, keys2), dv(vals, vals2);
   size_t tmp_bytes = 0;
-  VDB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)total, 0u, end_bit, cx.stream));
+  VDB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)total, 0u, end_bit, cx.stream));
   void* tmp = nullptr;
   VDB_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
   guard.p.push_back(tmp);
   {
     VDB_PROF("rocprim_radix_sort_pairs");
-    VDB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)total, 0u, end_bit, cx.stream));
+    VDB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, (size_t)total, 0u, end_bit, cx.stream));
   }
+  keys2 = dk.current();
+  vals2 = dv.current();
   // 4. cycles
   const uint64_t n_grid = (n_cols + 1) * rows;
   hipLaunchKernelGGL(k_pm_identity, dim3((unsigned)((n_grid + 255) / 256)), dim3(256), 0, cx.stream, mapping_dev, n_cols + 1, rows);

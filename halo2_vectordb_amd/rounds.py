@@ -167,9 +167,7 @@ class ProverRounds:
         self.srs_few = api.Srs(k, hp.g_monomial, None)     # a handful of columns: the bucket folding dominates, fewer buckets win
         # gate selectors from a flag-recording witness run
         d_flags = hp.keygen_flags()
-        d_q = api.DeviceBuffer(self.n_adv * rows * B)
         from ._lib import check as _chk     # (`check` is this method's flag)
-        _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
         cm = circuit if circuit is not None else self.circuit_map(d_flags)
         if cm.n_cells != hp.n_cells or (cm.lookup_src is not None and len(cm.lookup_src) != hp.n_lookup):
             raise ValueError("the constraint map does not describe this circuit (cell counts differ)")
@@ -179,8 +177,6 @@ class ProverRounds:
             raise ValueError("more distinct constants than usable rows of the fixed column")
         if check:
             self.keygen_report = self.mock_check(d_flags)
-        d_flags.free()
-        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # sigma columns over [advice | lookup | constants]: the cycles of the copy classes, built on the device
         # (vdb_permutation_mapping_dev: pointer jumping, one radix sort; copymap.mapping_from_copy_of is the host restatement
         # the tests compare it with).  A map without lookup sources leaves the lookup columns untied: only the tests' negative
@@ -213,6 +209,11 @@ class ProverRounds:
         if self._d_map_for_tests is None:
             d_map.free()
         self._fixed_poly("sigma", d_sigma, self.n_perm, keep_lag=False, keep_ext=False)
+        # gate selectors (after the permutation's work space is gone: both are tens of GB at BASELINE sizes)
+        d_q = api.DeviceBuffer(self.n_adv * rows * B)
+        _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+        d_flags.free()
+        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
         # the constants' fixed column: constant r at row r (halo2-base assigns the distinct constants of a circuit to fixed cells
         # and ties every Constant advice cell to its fixed cell through the permutation)
         cst = np.zeros((rows, 4), dtype=np.uint64)

@@ -131,11 +131,11 @@ void poseidon_plain_params(int t, int r_f, int r_p, std::vector<u256>& rc, std::
     for (int j = 0; j < t; j++) mds[(size_t)i * t + j] = mont_inv<Fr>(fr_add(xs[i], ys[j]));
 }
 
-// Builds the optimized schedule used by the halo2-lib Poseidon chip (PSE poseidon `Spec`):
+// Builds the optimized schedule used by the halo2-lib Poseidon chip (PSE poseidon `Spec`) for any width:
 // round constants folded through M^-1, partial rounds as sparse matrices M = M' * M''.
-void poseidon_build_spec(PoseidonSpec* out) {
-  const int t = PSD_T, half = PSD_HALF, rp = PSD_RP, rounds = PSD_RF + PSD_RP;
-  GrainLfsr g(254, t, PSD_RF, PSD_RP);
+void poseidon_build_opt(int t, int r_f, int r_p, PoseidonOpt* out) {
+  const int half = r_f / 2, rp = r_p, rounds = r_f + r_p;
+  GrainLfsr g(254, t, r_f, r_p);
   std::vector<std::vector<u256>> rc(rounds, std::vector<u256>(t));
   for (auto& row : rc)
     for (auto& c : row) c = g.next_field(true);
@@ -146,11 +146,19 @@ void poseidon_build_spec(PoseidonSpec* out) {
   for (int i = 0; i < t; i++)
     for (int j = 0; j < t; j++) mds[i][j] = mont_inv<Fr>(fr_add(xs[i], ys[j]));  // Cauchy matrix
   Mat minv = mat_inverse(mds);
+  out->t = t, out->half = half, out->rp = rp;
+  out->start.assign((size_t)(half + 1) * t, u256_zero());
+  out->partial.assign(rp, u256_zero());
+  out->end.assign((size_t)(half > 1 ? half - 1 : 0) * t, u256_zero());
+  out->mds.assign((size_t)t * t, u256_zero());
+  out->pre_sparse.assign((size_t)t * t, u256_zero());
+  out->sparse_row.assign((size_t)rp * t, u256_zero());
+  out->sparse_col.assign((size_t)rp * (t - 1), u256_zero());
 
-  for (int i = 0; i < t; i++) out->start[0][i] = rc[0][i];
+  for (int i = 0; i < t; i++) out->start[i] = rc[0][i];
   for (int r = 1; r < half; r++) {
     auto v = mat_vec(minv, rc[r]);
-    for (int i = 0; i < t; i++) out->start[r][i] = v[i];
+    for (int i = 0; i < t; i++) out->start[(size_t)r * t + i] = v[i];
   }
   std::vector<u256> acc = rc[half + rp];
   for (int p = rp - 1; p >= 0; p--) {
@@ -161,11 +169,11 @@ void poseidon_build_spec(PoseidonSpec* out) {
   }
   {
     auto v = mat_vec(minv, acc);
-    for (int i = 0; i < t; i++) out->start[half][i] = v[i];
+    for (int i = 0; i < t; i++) out->start[(size_t)half * t + i] = v[i];
   }
   for (int r = 0; r < half - 1; r++) {
     auto v = mat_vec(minv, rc[half + rp + 1 + r]);
-    for (int i = 0; i < t; i++) out->end[r][i] = v[i];
+    for (int i = 0; i < t; i++) out->end[(size_t)r * t + i] = v[i];
   }
   // sparse factorisation, walking from the last partial round back to the first
   Mat mT = mat_transpose(mds), cur = mT;
@@ -183,16 +191,36 @@ void poseidon_build_spec(PoseidonSpec* out) {
       for (int j = 1; j < t; j++) mprime[i][j] = hat[i - 1][j - 1];
     int dst = rp - 1 - p;
     // the chip applies transpose(M''): first row = (c00, w_hat...), first column below = v
-    out->sparse_row[dst][0] = cur[0][0];
-    for (int j = 1; j < t; j++) out->sparse_row[dst][j] = what[j - 1];
-    for (int i = 1; i < t; i++) out->sparse_col[dst][i - 1] = cur[0][i];
+    out->sparse_row[(size_t)dst * t] = cur[0][0];
+    for (int j = 1; j < t; j++) out->sparse_row[(size_t)dst * t + j] = what[j - 1];
+    for (int i = 1; i < t; i++) out->sparse_col[(size_t)dst * (t - 1) + i - 1] = cur[0][i];
     cur = mat_mul(mT, mprime);
   }
   Mat pre = mat_transpose(cur);
   for (int i = 0; i < t; i++)
     for (int j = 0; j < t; j++) {
-      out->mds[i][j] = mds[i][j];
-      out->pre_sparse[i][j] = pre[i][j];
+      out->mds[(size_t)i * t + j] = mds[i][j];
+      out->pre_sparse[(size_t)i * t + j] = pre[i][j];
+    }
+}
+// the chip's width, in the fixed-size layout the kernels read
+void poseidon_build_spec(PoseidonSpec* out) {
+  PoseidonOpt o;
+  poseidon_build_opt(PSD_T, PSD_RF, PSD_RP, &o);
+  const int t = PSD_T;
+  for (int r = 0; r <= PSD_HALF; r++)
+    for (int i = 0; i < t; i++) out->start[r][i] = o.start[(size_t)r * t + i];
+  for (int p = 0; p < PSD_RP; p++) {
+    out->partial[p] = o.partial[p];
+    for (int j = 0; j < t; j++) out->sparse_row[p][j] = o.sparse_row[(size_t)p * t + j];
+    for (int j = 0; j < t - 1; j++) out->sparse_col[p][j] = o.sparse_col[(size_t)p * (t - 1) + j];
+  }
+  for (int r = 0; r < PSD_HALF - 1; r++)
+    for (int i = 0; i < t; i++) out->end[r][i] = o.end[(size_t)r * t + i];
+  for (int i = 0; i < t; i++)
+    for (int j = 0; j < t; j++) {
+      out->mds[i][j] = o.mds[(size_t)i * t + j];
+      out->pre_sparse[i][j] = o.pre_sparse[(size_t)i * t + j];
     }
   u256 cap = u256_zero();
   cap.w[2] = 1;  // 2^64

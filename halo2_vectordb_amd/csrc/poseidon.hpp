@@ -28,6 +28,17 @@ struct PoseidonSpec {
   u256 one;
 };
 
+// the same schedule for any width (row-major vectors): the transcript's sponge (t = 5) runs it on the host
+struct PoseidonOpt {
+  int t, half, rp;
+  std::vector<u256> start;       // (half + 1) x t; row 0 = the first round's constants, added before the first S-box layer
+  std::vector<u256> partial;     // rp
+  std::vector<u256> end;         // (half - 1) x t
+  std::vector<u256> mds, pre_sparse;  // t x t
+  std::vector<u256> sparse_row;  // rp x t
+  std::vector<u256> sparse_col;  // rp x (t - 1)
+};
+void poseidon_build_opt(int t, int r_f, int r_p, PoseidonOpt* out);
 // host: plain parameters (round constants, MDS) for any width
 void poseidon_plain_params(int t, int r_f, int r_p, std::vector<u256>& rc, std::vector<u256>& mds);
 // host: Grain-LFSR parameter generation + optimisation (poseidon_spec.cpp)

@@ -21,7 +21,8 @@ using namespace vdb;
 
 struct vdb_transcript {
   int t, rate, r_f, r_p;
-  std::vector<u256> rc, mds, state, buf;
+  std::vector<u256> state, buf;
+  PoseidonOpt opt;  // the permutation's optimised schedule (sparse partial rounds), poseidon.hip
   std::vector<uint8_t> bytes;
 };
 
@@ -98,26 +99,103 @@ inline F4 f4_mul(const F4& a, const F4& b) {  // CIOS
   return r;
 }
 
-void permute(vdb_transcript* tr) {
-  const int t = tr->t, half = tr->r_f / 2;
-  F4 st[16], nx[16];
-  for (int i = 0; i < t; i++) st[i] = to_f4(tr->state[i]);
-  const F4* rc = reinterpret_cast<const F4*>(tr->rc.data());
-  const F4* mds = reinterpret_cast<const F4*>(tr->mds.data());
-  for (int r = 0; r < tr->r_f + tr->r_p; r++) {
-    for (int i = 0; i < t; i++) st[i] = f4_add(st[i], rc[(size_t)r * t + i]);
-    const bool full = r < half || r >= half + tr->r_p;
-    for (int i = 0; i < (full ? t : 1); i++) {
-      const F4 x2 = f4_mul(st[i], st[i]);
-      st[i] = f4_mul(f4_mul(x2, x2), st[i]);
+// sum_j a[j] b[j] with ONE Montgomery reduction: the n (<= 16) double-width products are summed in 576 bits, then reduced
+// word by word.  A proof of 2 x 10^4 columns absorbs ~2 x 10^5 values, i.e. ~5 x 10^4 permutations: this dot product and the
+// sparse partial rounds below are what the transcript's host time is made of.
+inline F4 f4_dot(const F4* a, const F4* b, int n, size_t stride_b = 1) {
+  // product scanning: column c collects every x_i y_j with i + j = c of every pair into a three-word accumulator
+  uint64_t T[9];
+  uint64_t a0 = 0, a1 = 0, a2 = 0;
+  for (int c = 0; c < 7; c++) {
+    const int ilo = c > 3 ? c - 3 : 0, ihi = c < 3 ? c : 3;
+    for (int k = 0; k < n; k++) {
+      const uint64_t* x = a[k].l;
+      const uint64_t* y = b[(size_t)k * stride_b].l;
+      for (int i = ilo; i <= ihi; i++) {
+        const unsigned __int128 pr = (unsigned __int128)x[i] * y[c - i];
+        const unsigned __int128 s = (unsigned __int128)a0 + (uint64_t)pr;
+        a0 = (uint64_t)s;
+        const unsigned __int128 s1 = (unsigned __int128)a1 + (uint64_t)(pr >> 64) + (uint64_t)(s >> 64);
+        a1 = (uint64_t)s1;
+        a2 += (uint64_t)(s1 >> 64);
+      }
     }
-    for (int i = 0; i < t; i++) {
-      F4 acc = f4_mul(mds[(size_t)i * t], st[0]);
-      for (int j = 1; j < t; j++) acc = f4_add(acc, f4_mul(mds[(size_t)i * t + j], st[j]));
-      nx[i] = acc;
-    }
-    for (int i = 0; i < t; i++) st[i] = nx[i];
+    T[c] = a0;
+    a0 = a1;
+    a1 = a2;
+    a2 = 0;
   }
+  T[7] = a0;
+  T[8] = a1;
+  for (int i = 0; i < 4; i++) {  // T += m r 2^(64 i) clears word i
+    const uint64_t m = T[i] * FR_INV;
+    unsigned __int128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (unsigned __int128)m * FR_P[j] + T[i + j];
+      T[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    for (int w = i + 4; w < 9; w++) {
+      c += T[w];
+      T[w] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  // below n r + r: a few conditional subtractions, the word above 256 bits included
+  uint64_t hi = T[8];
+  F4 r = {{T[4], T[5], T[6], T[7]}};
+  while (hi || geq_p(r.l)) {
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 d = (unsigned __int128)r.l[i] - FR_P[i] - (uint64_t)bw;
+      r.l[i] = (uint64_t)d;
+      bw = (d >> 64) & 1;
+    }
+    hi -= (uint64_t)bw;
+  }
+  return r;
+}
+inline F4 f4_pow5(const F4& x) {
+  const F4 x2 = f4_mul(x, x);
+  return f4_mul(f4_mul(x2, x2), x);
+}
+
+// The permutation in the optimised schedule of the PSE `poseidon` Spec (the one the chip runs on the device): the first
+// round's constants, half - 1 full rounds with folded constants and the MDS matrix, one with the pre-sparse matrix, the
+// partial rounds as sparse matrices (2 t - 1 products instead of t^2), the remaining full rounds.  Same function as the
+// textbook schedule (tests/test_transcript_cpu.py holds it against an independent Python restatement of that one).
+void permute(vdb_transcript* tr) {
+  const PoseidonOpt& o = tr->opt;
+  const int t = o.t, half = o.half;
+  F4 st[16], nx[16];
+  const F4* start = reinterpret_cast<const F4*>(o.start.data());
+  const F4* mds = reinterpret_cast<const F4*>(o.mds.data());
+  const F4* pre = reinterpret_cast<const F4*>(o.pre_sparse.data());
+  const F4* srow = reinterpret_cast<const F4*>(o.sparse_row.data());
+  const F4* scol = reinterpret_cast<const F4*>(o.sparse_col.data());
+  const F4* end = reinterpret_cast<const F4*>(o.end.data());
+  const F4* partial = reinterpret_cast<const F4*>(o.partial.data());
+  for (int i = 0; i < t; i++) st[i] = f4_add(to_f4(tr->state[i]), start[i]);
+  auto dense = [&](const F4* m) {
+    for (int i = 0; i < t; i++) nx[i] = f4_dot(m + (size_t)i * t, st, t);
+    for (int i = 0; i < t; i++) st[i] = nx[i];
+  };
+  for (int r = 1; r <= half; r++) {
+    for (int i = 0; i < t; i++) st[i] = f4_add(f4_pow5(st[i]), start[(size_t)r * t + i]);
+    dense(r < half ? mds : pre);
+  }
+  for (int p = 0; p < o.rp; p++) {
+    st[0] = f4_add(f4_pow5(st[0]), partial[p]);
+    const F4 n0 = f4_dot(srow + (size_t)p * t, st, t);
+    for (int i = 1; i < t; i++) st[i] = f4_add(f4_mul(st[0], scol[(size_t)p * (t - 1) + i - 1]), st[i]);
+    st[0] = n0;
+  }
+  for (int r = 0; r < half - 1; r++) {
+    for (int i = 0; i < t; i++) st[i] = f4_add(f4_pow5(st[i]), end[(size_t)r * t + i]);
+    dense(mds);
+  }
+  for (int i = 0; i < t; i++) st[i] = f4_pow5(st[i]);
+  dense(mds);
   for (int i = 0; i < t; i++) tr->state[i] = from_f4(st[i]);
 }
 
@@ -157,8 +235,13 @@ int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript** 
   tr->rate = (int)t - 1;
   tr->r_f = (int)r_f;
   tr->r_p = (int)r_p;
-  poseidon_plain_params(tr->t, tr->r_f, tr->r_p, tr->rc, tr->mds);
-  tr->state.assign(t, u256_zero());
+  try {
+    poseidon_build_opt(tr->t, tr->r_f, tr->r_p, &tr->opt);
+    tr->state.assign(t, u256_zero());
+  } catch (...) {
+    delete tr;
+    return VDB_ERR_OOM;
+  }
   u256 cap = u256_zero();
   cap.w[2] = 1;  // 2^64
   tr->state[0] = to_mont<Fr>(cap);
@@ -172,7 +255,11 @@ int vdb_transcript_common_scalar(vdb_transcript* tr, const vdb_fr* s) {
   VDB_ARG(tr && s, "null pointer");
   u256 v;
   memcpy(&v, s, 32);
-  tr->buf.push_back(v);
+  try {
+    tr->buf.push_back(v);
+  } catch (...) {  // nothing may propagate across the C ABI
+    return VDB_ERR_OOM;
+  }
   return VDB_OK;
 }
 
@@ -180,8 +267,12 @@ int vdb_transcript_common_point(vdb_transcript* tr, const vdb_g1* p) {
   VDB_ARG(tr && p, "null pointer");
   u256 xy[2];
   memcpy(xy, p, 64);
-  tr->buf.push_back(fq_to_fr(xy[0]));
-  tr->buf.push_back(fq_to_fr(xy[1]));
+  try {
+    tr->buf.push_back(fq_to_fr(xy[0]));
+    tr->buf.push_back(fq_to_fr(xy[1]));
+  } catch (...) {
+    return VDB_ERR_OOM;
+  }
   return VDB_OK;
 }
 
@@ -190,7 +281,11 @@ int vdb_transcript_write_scalar(vdb_transcript* tr, const vdb_fr* s) {
   if (rc) return rc;
   u256 v;
   memcpy(&v, s, 32);
-  put_le(tr->bytes, from_mont<Fr>(v), 0);
+  try {
+    put_le(tr->bytes, from_mont<Fr>(v), 0);
+  } catch (...) {
+    return VDB_ERR_OOM;
+  }
   return VDB_OK;
 }
 
@@ -201,7 +296,11 @@ int vdb_transcript_write_point(vdb_transcript* tr, const vdb_g1* p) {
   memcpy(xy, p, 64);
   const u256 x = from_mont<Fq>(xy[0]), y = from_mont<Fq>(xy[1]);
   const bool identity = u256_is_zero(x) && u256_is_zero(y);
-  put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? 0x40 : 0);
+  try {
+    put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? 0x40 : 0);
+  } catch (...) {
+    return VDB_ERR_OOM;
+  }
   return VDB_OK;
 }
 

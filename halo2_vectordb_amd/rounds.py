@@ -304,7 +304,7 @@ class ProverRounds:
         self.d_ea, self.d_eb = api.DeviceBuffer(blk * self.ne * B), api.DeviceBuffer(blk * self.ne * B)
         self.d_ez = api.DeviceBuffer((blk // CHUNK_LEN + 1) * self.ne * B)
         self.d_zf, self.d_zlast = api.DeviceBuffer(self.ne * B), api.DeviceBuffer(self.ne * B)
-        self.d_h = api.DeviceBuffer(self.ne * B)
+        self.d_h, self.d_h2, self.d_h3, self.d_h4 = (api.DeviceBuffer(self.ne * B) for _ in range(4))
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         return self
 
@@ -513,56 +513,60 @@ class ProverRounds:
             check(lib.vdb_coeff_to_extended_dev(coeff_ptr, dest_ptr, _sz(m), k, EXT_K))
 
         def quotient():
-            check(lib.vdb_memset_dev(d_h.ptr, 0, _sz(ne * B)))
-            # the gates: advice and selector cosets a block of columns at a time
-            for c0 in range(0, n_adv, blk):
-                nb = min(blk, n_adv - c0)
+            # The numerator is sum_i term_i y^(N-1-i) over the terms in halo2's order: gates (one per advice column), public inputs,
+            # the permutation argument (two terms of the product columns alone, the chaining of the sets, one product term per set),
+            # the lookup argument (five per lookup column).  Each group is folded into an accumulator of its own (acc <- acc y +
+            # term, from zero) while ONE sweep over blocks of columns produces every coset once — the advice / lookup / constants
+            # cosets (unless resident), selectors, sigma, product and lookup-argument cosets — and the groups are joined at the end:
+            # h = ((A1 y^n2 + A2) y^n3 + A3) y^n4 + A4.
+            a1, a2, a3, a4 = d_h, self.d_h2, self.d_h3, self.d_h4
+            for a in (a1, a2, a3, a4):
+                check(lib.vdb_memset_dev(a.ptr, 0, _sz(ne * B)))
+            perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
+            # l0 (1 - z_0), l_last (z_last^2 - z_last): the first two terms of group 2
+            to_ext(zp.coeff.ptr, d_zf.ptr, 1)
+            to_ext(zp.coeff.at((n_sets - 1) * rows * B), d_zlast.ptr, 1)
+            check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
+            third = blk // 3
+            for c0 in range(0, n_perm, blk):
+                nb = min(blk, n_perm - c0)
                 base, col0 = adv_ext_block(c0, nb)
-                to_ext(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
-                check(lib.vdb_gate_eval_dev(col_ptr(base, col0, c0), d_eb.ptr, _sz(nb), k, EXT_K, p["y"], d_h.ptr))
-            # public inputs: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
+                g1 = min(c0 + nb, n_adv)
+                if c0 < g1:                                            # gates of the block's advice columns
+                    to_ext(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, g1 - c0)
+                    check(lib.vdb_gate_eval_dev(col_ptr(base, col0, c0), d_eb.ptr, _sz(g1 - c0), k, EXT_K, p["y"], a1.ptr))
+                # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
+                set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
+                z0 = max(set_lo - 1, 0)
+                to_ext(fx["sigma"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
+                to_ext(zp.coeff.at(z0 * rows * B), d_ez.ptr, set_hi - z0)
+                if max(set_lo, 1) < set_hi:
+                    check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
+                                                             _sz(0), _sz(0)))
+                check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 0, _sz(0), _sz(0), _sz(set_lo),
+                                                         _sz(set_hi)))
+                # lookup argument of the block's lookup columns: [permuted input | permuted table | product] cosets in thirds of one buffer
+                j_lo, j_hi = max(c0, n_adv) - n_adv, min(c0 + nb, n_cols) - n_adv
+                for j0 in range(j_lo, max(j_hi, j_lo), third):
+                    m = min(third, j_hi - j0)
+                    to_ext(polys["pa"].coeff.at(j0 * rows * B), d_eb.ptr, m)
+                    to_ext(polys["ps"].coeff.at(j0 * rows * B), d_eb.at(third * ne * B), m)
+                    to_ext(polys["zl"].coeff.at(j0 * rows * B), d_eb.at(2 * third * ne * B), m)
+                    check(lib.vdb_lookup_eval_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
+                                                  _sz(m), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
+            # public inputs close group 1: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
             for i, (col, _row) in enumerate(self.instance_pos):
                 l_ext = fx["inst"].ext.at(i * ne * B)
                 base, col0 = adv_ext_block(col, 1)
-                check(lib.vdb_const_eval_dev(col_ptr(base, col0, col), l_ext, _sz(1), k, EXT_K, p["y"], d_h.ptr))
-                check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
-            # the permutation argument.  First the terms of the product columns alone: l0 (1 - z_0), l_last (z_last^2 - z_last), and
-            # the chaining l0 (z_i - z_{i-1}(..)) for i = 1 .. n_sets - 1, the product cosets a block of sets at a time
-            to_ext(zp.coeff.ptr, d_zf.ptr, 1)
-            to_ext(zp.coeff.at((n_sets - 1) * rows * B), d_zlast.ptr, 1)
-            zcap = blk // CHUNK_LEN + 1                                # product cosets d_ez holds
-            perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"], d_h.ptr)
-            s0 = 0
-            while True:
-                s1 = min(n_sets, s0 + zcap - 1 if s0 else zcap)
-                z0 = max(s0 - 1, 0)
-                to_ext(zp.coeff.at(z0 * rows * B), d_ez.ptr, s1 - z0)
-                check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), d_zf.ptr, d_zlast.ptr, *perm_args, int(s0 == 0), _sz(max(s0, 1)), _sz(s1),
-                                                         _sz(0), _sz(0)))
-                s0 = s1
-                if s0 >= n_sets:
-                    break
-            # then the product terms, set after set: the columns of a block with their sigma columns and their product columns
-            for c0 in range(0, n_perm, blk):
-                nb = min(blk, n_perm - c0)
-                set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
-                base, col0 = adv_ext_block(c0, nb)
-                to_ext(fx["sigma"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
-                to_ext(zp.coeff.at(set_lo * rows * B), d_ez.ptr, set_hi - set_lo)
-                check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(set_lo), None, None, *perm_args, 0, _sz(0), _sz(0), _sz(set_lo), _sz(set_hi)))
-            # the lookup argument, a block of lookup columns at a time: [input | product] cosets in one buffer, [permuted input | table] in the other
-            for j0 in range(0, n_lk, blk_l):
-                nb = min(blk_l, n_lk - j0)
-                if resident:
-                    a_ext, z_ext = hp.d_ext.at((n_adv + j0) * ne * B), d_ea.ptr
-                else:
-                    to_ext(hp.d_cols.at((n_adv + j0) * rows * B), d_ea.ptr, nb)
-                    a_ext, z_ext = d_ea.ptr, d_ea.at(blk_l * ne * B)
-                to_ext(polys["zl"].coeff.at(j0 * rows * B), z_ext, nb)
-                to_ext(polys["pa"].coeff.at(j0 * rows * B), d_eb.ptr, nb)
-                to_ext(polys["ps"].coeff.at(j0 * rows * B), d_eb.at(blk_l * ne * B), nb)
-                check(lib.vdb_lookup_eval_dev(a_ext, fx["table"].ext.ptr, d_eb.ptr, d_eb.at(blk_l * ne * B), z_ext, _sz(nb), k, EXT_K, l0, ll, la,
-                                              p["beta"], p["gamma"], p["y"], d_h.ptr))
+                check(lib.vdb_const_eval_dev(col_ptr(base, col0, col), l_ext, _sz(1), k, EXT_K, p["y"], a1.ptr))
+                check(lib.vdb_poly_axpy_dev(a1.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
+            # join the groups (acc_next += y^(terms of the next group) * acc)
+            y_int = _fr_to_int(ch["y"])
+            n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
+            check(lib.vdb_poly_axpy_dev(a2.ptr, api._p(_fr_from_int(pow(y_int, n2, R_MOD))), a1.ptr, _sz(ne)))
+            check(lib.vdb_poly_axpy_dev(a3.ptr, api._p(_fr_from_int(pow(y_int, n3, R_MOD))), a2.ptr, _sz(ne)))
+            check(lib.vdb_poly_axpy_dev(a4.ptr, api._p(_fr_from_int(pow(y_int, n4, R_MOD))), a3.ptr, _sz(ne)))
+            check(lib.vdb_memcpy_d2d(d_h.ptr, a4.ptr, _sz(ne * B)))
             check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
             check(lib.vdb_extended_to_coeff_dev(d_h.ptr, _sz(1), k, EXT_K))
         stage("quotient", quotient)
@@ -754,7 +758,7 @@ class ProverRounds:
         for q in self.fixed.values():
             q.free()
         self.fixed = {}
-        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_comb", "d_quot"):
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_comb", "d_quot"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

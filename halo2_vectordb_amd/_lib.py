@@ -82,7 +82,7 @@ _SIGNATURES = {
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
     "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
     "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
-    "vdb_transcript_new": [_U32, _U32, _U32, _P], "vdb_transcript_free": [_P], "vdb_transcript_common_scalar": [_P, _P], "vdb_transcript_common_point": [_P, _P],
+    "vdb_transcript_new": [_U32, _U32, _U32, _P], "vdb_transcript_free": [_P], "vdb_transcript_set_sign_bit": [_P, _U32], "vdb_transcript_common_scalar": [_P, _P], "vdb_transcript_common_point": [_P, _P],
     "vdb_transcript_write_points": [_P, _P, _SZ], "vdb_transcript_write_scalars": [_P, _P, _SZ], "vdb_transcript_common_points": [_P, _P, _SZ],
     "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],

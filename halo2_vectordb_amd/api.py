@@ -631,6 +631,10 @@ class Transcript:
         self.h = ctypes.c_void_p()
         check(self.L.vdb_transcript_new(t, r_f, r_p, ctypes.byref(self.h)))
 
+    def set_sign_bit(self, bit):
+        """bit of a compressed point's last byte that says "y is odd": 6 (default) or 7"""
+        check(self.L.vdb_transcript_set_sign_bit(self.h, ctypes.c_uint32(bit)))
+
     def common_scalar(self, s):
         check(self.L.vdb_transcript_common_scalar(self.h, _p(_fr(s))))
 

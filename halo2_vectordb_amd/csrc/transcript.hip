@@ -7,8 +7,10 @@
 //     value, and when the buffer length is a multiple of RATE (empty included) one more permutation absorbs only that +1 —
 //     and returns state[1] (the same sponge rule as PoseidonChip);
 //   * a G1 point is absorbed as its affine x and y, each reduced into Fr; the identity as (0, 0);
-//   * written to the proof: points compressed to 32 bytes (x little-endian, bit 6 of the last byte = y is odd, the identity
-//     all zero), scalars as 32 little-endian bytes of the canonical value.
+//   * written to the proof: points compressed to 32 bytes (x little-endian, one of the two spare top bits of the last byte =
+//     y is odd, the identity all zero), scalars as 32 little-endian bytes of the canonical value.  Which spare bit depends on
+//     the halo2curves version as recalled — bit 6 (0x40) from 0.4 on, bit 7 (0x80) in the 0.3.x releases of the reference's
+//     dependency era; the default is bit 6, vdb_transcript_set_sign_bit selects the other.
 // Parity unpinned: the parameters and encodings above are recalled, the reference holds no proof bytes.
 // The sponge is cross-checked against an independent Python restatement (tests/test_transcript_cpu.py), and at T = 3
 // against the chip's optimised schedule.
@@ -23,6 +25,7 @@ struct vdb_transcript {
   int t, rate, r_f, r_p;
   std::vector<u256> state, buf;
   PoseidonOpt opt;  // the permutation's optimised schedule (sparse partial rounds), poseidon.hip
+  uint8_t sign_mask = 0x40;  // where a compressed point carries "y is odd" (vdb_transcript_set_sign_bit)
   std::vector<uint8_t> bytes;
 };
 
@@ -251,6 +254,12 @@ int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript** 
 
 void vdb_transcript_free(vdb_transcript* tr) { delete tr; }
 
+int vdb_transcript_set_sign_bit(vdb_transcript* tr, uint32_t bit) {
+  VDB_ARG(tr && (bit == 6 || bit == 7), "the y-parity flag of a compressed point sits in bit 6 or bit 7 of the last byte");
+  tr->sign_mask = (uint8_t)(1u << bit);
+  return VDB_OK;
+}
+
 int vdb_transcript_common_scalar(vdb_transcript* tr, const vdb_fr* s) {
   VDB_ARG(tr && s, "null pointer");
   u256 v;
@@ -297,7 +306,7 @@ int vdb_transcript_write_point(vdb_transcript* tr, const vdb_g1* p) {
   const u256 x = from_mont<Fq>(xy[0]), y = from_mont<Fq>(xy[1]);
   const bool identity = u256_is_zero(x) && u256_is_zero(y);
   try {
-    put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? 0x40 : 0);
+    put_le(tr->bytes, x, (!identity && (y.w[0] & 1)) ? tr->sign_mask : 0);
   } catch (...) {
     return VDB_ERR_OOM;
   }

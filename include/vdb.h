@@ -385,6 +385,9 @@ int vdb_fr_root_of_unity(uint32_t k, vdb_fr *out);
  *      (points: 32 bytes, x little-endian, bit 6 of the last byte = y odd; scalars: 32 bytes little-endian canonical). */
 typedef struct vdb_transcript vdb_transcript;
 int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript **out);
+/* where a compressed point carries "y is odd": bit 6 (default; halo2curves >= 0.4 as recalled) or bit 7 (halo2curves 0.3.x) of the
+ * last byte — parity unpinned either way, the reference holds no proof bytes */
+int vdb_transcript_set_sign_bit(vdb_transcript *tr, uint32_t bit);
 void vdb_transcript_free(vdb_transcript *tr);
 int vdb_transcript_common_scalar(vdb_transcript *tr, const vdb_fr *s);
 int vdb_transcript_common_point(vdb_transcript *tr, const vdb_g1 *p);

@@ -86,3 +86,27 @@ def test_points_and_proof_bytes(api, O, PY):
     assert ch == _sponge(PY.Poseidon(5, 8, 60), O.R_MOD, 5, [absorbed])[0]
     # bit 6 of the last byte is bit 254 of the little-endian integer
     assert all((proof[32 * i + 31] >> 7) == 0 for i in range(4))
+
+
+def test_compressed_point_sign_bit_is_selectable():
+    """the y-parity flag of a written point: bit 6 by default, bit 7 on request (halo2curves 0.3.x as recalled); the challenge does
+    not depend on the byte encoding"""
+    import numpy as np
+    from halo2_vectordb_amd import api
+    g = np.zeros(8, dtype=np.uint64)                  # the generator (1, 2) in Montgomery form has an even y; use (1, -2): odd y
+    q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    mont = lambda v: [(v * (1 << 256) % q >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    g[:4], g[4:] = mont(1), mont(q - 2)
+    out = {}
+    for bit in (None, 6, 7):
+        tr = api.Transcript()
+        if bit is not None:
+            tr.set_sign_bit(bit)
+        tr.write_point(g)
+        out[bit] = (tr.proof(), tr.squeeze().tobytes())
+        tr.free()
+    assert out[None] == out[6] and out[6][1] == out[7][1]
+    assert out[6][0][31] == 0x40 and out[7][0][31] == 0x80 and out[6][0][:31] == out[7][0][:31]
+    with pytest.raises(api.VdbError):
+        tr = api.Transcript()
+        tr.set_sign_bit(5)

@@ -46,7 +46,7 @@ def load():
 _P, _SZ, _U32, _U64, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
 # argument types of every entry point of include/vdb.h (pointers are passed as void*)
 _SIGNATURES = {
-    "vdb_fr_from_wide_dev": [_P, _SZ, _P], "vdb_mock_check_dev": [_P, _U64, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _U64, _P],
+    "vdb_fr_from_wide_dev": [_P, _SZ, _P], "vdb_fr_horner": [_P, _SZ, _P, _P], "vdb_mock_check_dev": [_P, _U64, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _U64, _P],
     "vdb_init": [_I], "vdb_init_devices": [_I], "vdb_set_device": [_I], "vdb_srs_device": [_P, _P],
     "vdb_srs_load_all": [_U32, _P, _P, _U32, _P, _I], "vdb_msm_batch_multi": [_P, _I, _I, _P, _SZ, _SZ, _P],
     "vdb_ntt_batch_multi": [_P, _SZ, _U32, _P, _I], "vdb_malloc": [_P, _SZ], "vdb_free": [_P], "vdb_memcpy_h2d": [_P, _P, _SZ], "vdb_memcpy_d2h": [_P, _P, _SZ],

@@ -230,6 +230,22 @@ void put_le(std::vector<uint8_t>& out, const u256& canonical, uint8_t top_flags)
 
 extern "C" {
 
+// acc <- acc x + v_i for i = 0 .. n - 1 on the host (the multi-open combines tens of thousands of evaluations with powers of a
+// challenge before anything goes back to the device; Python integers cost microseconds apiece)
+int vdb_fr_horner(const vdb_fr* values, size_t n, const vdb_fr* x, vdb_fr* acc) {
+  VDB_ARG((values || n == 0) && x && acc, "null pointer");
+  F4 a, xx;
+  memcpy(a.l, acc, 32);
+  memcpy(xx.l, x, 32);
+  for (size_t i = 0; i < n; i++) {
+    F4 v;
+    memcpy(v.l, values + i, 32);
+    a = f4_add(f4_mul(a, xx), v);
+  }
+  memcpy(acc, a.l, 32);
+  return VDB_OK;
+}
+
 int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript** out) {
   VDB_ARG(out && t >= 2 && t <= 16 && r_f >= 2 && r_f % 2 == 0 && r_f <= 64 && r_p <= 256, "bad argument");
   vdb_transcript* tr = new (std::nothrow) vdb_transcript();

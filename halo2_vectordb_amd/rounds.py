@@ -14,6 +14,7 @@ unpinned).  What the tests hold it to instead is what a verifier ch
 from the returned evaluations, and every opening against its commitments in the exponent (tests/test_gpu_rounds.py).
 """
 import ctypes
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -58,6 +59,26 @@ class _View:
 
     def free(self):
         pass
+
+
+class _Evals(Mapping):
+    """evaluations as returned by prove(): (name, rotation) -> list of canonical Python integers, converted from the
+    Montgomery arrays the device returned when first asked for (a proof of 2 x 10^4 columns carries ~2 x 10^5 of them)"""
+
+    def __init__(self, raw):
+        self.raw, self._ints = raw, {}
+
+    def __getitem__(self, key):
+        if key not in self._ints:
+            a = np.ascontiguousarray(self.raw[key], dtype=np.uint64).reshape(-1, 4)
+            self._ints[key] = [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in api.fr_to_canonical(a)] if len(a) else []
+        return self._ints[key]
+
+    def __iter__(self):
+        return iter(self.raw)
+
+    def __len__(self):
+        return len(self.raw)
 
 
 class _Poly:
@@ -636,7 +657,7 @@ class ProverRounds:
             tr.free()
         api.sync()
         commitments = {name: q.commits for name, q in allp.items()}
-        return dict(commitments=commitments, evals={key: [_fr_to_int(r) for r in val] for key, val in evals.items()}, openings=openings, points=points,
+        return dict(commitments=commitments, evals=_Evals(evals), openings=openings, points=points,
                     proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened,
                         instances=[_fr_to_int(v) for v in instances], instance_pos=list(self.instance_pos))
 
@@ -668,7 +689,7 @@ class ProverRounds:
         m = len(sets)
         d_q = [api.DeviceBuffer(rows * B) for _ in sets]
         d_f, d_a, d_b = api.DeviceBuffer(rows * B), self.d_comb, self.d_quot
-        ev_int = {key: [_fr_to_int(e) for e in val] for key, val in evals.items()}
+        ev_int = _Evals(evals)
 
         def interpolate(pts, vals):          # coefficients (low first) of the polynomial through (pts, vals)
             coeffs = [0] * len(pts)
@@ -704,12 +725,12 @@ class ProverRounds:
                     q = allp[name]
                     check(lib.vdb_poly_lincomb_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), p["yo"], d_q[s_i].ptr))
                 vals = []
-                for rot in rots:
-                    acc = 0
+                for rot in rots:                                   # the set's evaluations at this point, combined with powers of yo (host, compiled)
+                    acc = np.zeros(4, dtype=np.uint64)
                     for name in names:
-                        for e in ev_int[(name, rot)]:
-                            acc = (acc * yo + e) % R
-                    vals.append(acc)
+                        e = np.ascontiguousarray(evals[(name, rot)], dtype=np.uint64)
+                        check(lib.vdb_fr_horner(api._p(e), _sz(e.shape[0]), p["yo"], api._p(acc)))
+                    vals.append(_fr_to_int(acc))
                 r = interpolate([points[rot] for rot in rots], vals)
                 r_polys.append(r)
                 # (q_S - r_S) / Z_S: the low coefficients on the host, one division per point on the device

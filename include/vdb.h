@@ -89,6 +89,9 @@ int vdb_profile_begin_deferred(void);
 int vdb_profile_end(char *json_out, size_t cap);
 
 /* ---- field helpers (tests / staging) -------------------------------------------------------- */
+/* acc <- acc x + values[i], i = 0 .. n - 1, on the host (Montgomery in and out; needs no GPU): combining the evaluations of a
+ * multi-open with powers of a challenge (halo2 poly/kzg/multiopen) */
+int vdb_fr_horner(const vdb_fr *values, size_t n, const vdb_fr *x, vdb_fr *acc);
 /* out[i] = (64 little-endian bytes wide[64 i ..]) mod r, Montgomery: Fr::random / Fr::from_u512 of halo2curves — how the
  * prover's blinding scalars are drawn from OS entropy (halo2 create_proof: Blind(Scalar::random(rng)), reached from
  * src/scaffold/mod.rs:296).  Device pointers; asynchronous on the library stream. */

@@ -140,16 +140,33 @@ struct Gadgets {
   HD Gadgets(WCtx& ctx) : c(ctx), T(*ctx.T) {}
 
   HD u256 zero() const { return u256_zero(); }
-  HD u256 small(uint32_t v) const { return T.small[v < 260 ? v : 0]; }
-  // Montgomery form of a small canonical integer (< 2^L) via the limb table
-  HD u256 limb_mont(uint32_t v) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return T.limb_tab[v];
-#else
-    (void)v;
-    return u256_zero();  // host runs only count the cells
-#endif
+  // Montgomery form v * 2^256 mod r of a small integer (v < 2^24) WITHOUT a table: v c - q r with c = 2^256 mod r and
+  // q = floor(v mu / 2^32), mu = floor(c 2^32 / r) — never above floor(v c / r) and at most one below, so the difference is
+  // below 2 r and one conditional subtraction finishes.  ~45 vector instructions instead of a 32-byte gather whose index is
+  // data dependent: in the gadget chains such a load queues behind every store issued before it (one in-order vmcnt), and
+  // the range checks make dozens of them per qmul.
+  HD static u256 mont_small(uint32_t v) {
+    constexpr uint32_t MU = 0x4a474626u;
+    const uint32_t q = (uint32_t)(((uint64_t)v * MU) >> 32);
+    u256 t;
+    uint64_t a = 0, b = 0;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      a += (uint64_t)v * FrParams::R1[i];   // words of v c
+      b += (uint64_t)q * FrParams::P[i];    // words of q r
+      const uint32_t aw = (uint32_t)a, bw = (uint32_t)b;
+      const uint64_t d = (uint64_t)aw - bw - borrow;
+      t.w[i] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 63);
+      a >>= 32;
+      b >>= 32;
+    }
+    return lazy_canon<Fr>(t);
   }
+  HD u256 small(uint32_t v) const { return mont_small(v < 260 ? v : 0); }
+  // Montgomery form of a limb (< 2^L)
+  HD u256 limb_mont(uint32_t v) const { return mont_small(v); }
   // value of the inverse cell of an is_zero block that starts at the current position (the cell is pos + 2)
   HD u256 inv_cell(const u256& x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -671,7 +688,7 @@ struct Gadgets {
         if (c.skip(12)) {
           c.pos += 12;
         } else {
-          u256 ci = i < 260 ? T.small[i] : to_mont<Fr>(u256_from_u64(i));
+          u256 ci = mont_small(i);
           u256 d = fr_sub(idx, ci);  // is_equal(idx, Constant(i)) = sub [d, i, 1, idx] + is_zero
           c.push(d, true); c.push(ci, false, true); c.push(mont_one<Fr>(), false, true); c.push(idx, false);
           g_is_zero_inv(d, signed_small_inv(d, diff));
@@ -778,7 +795,7 @@ struct Gadgets {
     u256 shm = shift < 0 ? fr_neg(small_or_mont((uint64_t)(-shift))) : small_or_mont((uint64_t)shift);
     return fr_add(ln, fr_mul(fr_neg(shm), T.scale));
   }
-  HD u256 small_or_mont(uint64_t v) const { return v < 260 ? T.small[v] : to_mont<Fr>(u256_from_u64(v)); }
+  HD u256 small_or_mont(uint64_t v) const { return v < (1u << 24) ? mont_small((uint32_t)v) : to_mont<Fr>(u256_from_u64(v)); }
   HD u256 fp_qlog2(const u256& a) {  // :736-795
     if (c.skip2(T.sz.qlog2)) {
       uint64_t p0 = c.pos, l0 = c.lpos;

@@ -67,3 +67,27 @@ def test_example_prove_commits_what_the_oracle_commits(O, tmp_path):
     # the first advice column starts with the assigned vectors, the lookup column with range-checked cells
     assert np.array_equal(cols[0, : n * dim], qv.reshape(-1, 4))
     assert np.array_equal(cols[2, :8], c.lookup()[:8])
+
+
+def test_example_mock_is_the_mock_arm_in_compiled_code(O):
+    """host/example_mock.cpp: the reference's Mock arm (src/scaffold/mod.rs:263-266) for the distance examples through the C ABI
+    alone — witness with keygen flags, device MockProver — on data/euclid.in's vectors (BASELINE configs[0]: LOOKUP_BITS 12):
+    satisfied; the same witness with one cell altered is not, and the first violated row is the gate that holds the cell"""
+    exe = os.path.join(ROOT, "halo2_vectordb_amd", "host", "example_mock")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "halo2_vectordb_amd", "csrc"), "../host/example_mock"])
+    a, b = [0.123, 0.456, 1.789, 1.123], [1.123, 0.456, 0.789, 0.123]
+    txt = "4 " + " ".join(repr(x) for x in a + b) + "\n"
+    qa, qb = O.quantize(np.array(a)), O.quantize(np.array(b))
+    for metric, name in ((0, "euclidean"), (1, "cosine"), (2, "manhattan")):
+        out = subprocess.run([exe, str(metric), "12"], input=txt, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        c = O.Ctx(store=True, keygen=True)
+        r = c.distance(name, qa, qb, L=12)
+        head = out.stdout.splitlines()[0].split()
+        assert int(head[1]) == len(c) and int(head[3]) == c.n_lookup and abs(float(head[5]) - float(O.dequantize(r))) < 1e-9
+        assert "gate_rows_violated 0 lookup_cells_out_of_table 0 lookup_copies_unequal 0 constants_changed 0" in out.stdout
+    bad = subprocess.run([exe, "0", "12", "1003"], input=txt, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 4, (bad.stdout, bad.stderr)
+    rep = bad.stdout.splitlines()[1].split()
+    assert int(rep[1]) >= 1 and 1000 <= int(rep[9]) <= 1003

@@ -124,19 +124,22 @@ def whole_proof(api):
     hp.setup()
     pr = ProverRounds(hp).keygen()
     keygen_s = time.perf_counter() - t0
+    # untimed proofs for `proof_ms` (the host's transcript work runs beside whatever the device still has queued), then one
+    # instrumented proof for the device time per stage (its timers wait for the device after every stage)
     best = None
     for _ in range(2):
-        T = {}
         t0 = time.perf_counter()
-        out = pr.prove(None, timings=T)
+        out = pr.prove(None)
         wall = (time.perf_counter() - t0) * 1e3
         if best is None or wall < best[0]:
-            best = (wall, T, out)
-    wall, T, out = best
+            best = (wall, dict(pr.host_ms), out)
+    wall, host_ms, out = best
+    T = {}
+    pr.prove(None, timings=T)
     rep = pr.keygen_report
     res = {"circuit": "kmeans K=4 I=8 over 256x128, P=48, LOOKUP_BITS=15, COSINE (the satisfiable variant of BASELINE configs[3]), k=16",
            "cells": hp.n_cells + hp.n_lookup, "columns": hp.n_cols, "product_columns": pr.n_sets + pr.n_lk,
-           "proof_ms": wall, "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
+           "proof_ms": wall, "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
            "constraints_per_s": (hp.n_cells + hp.n_lookup) / (wall * 1e-3), "proof_bytes": len(out["proof"]),
            "keygen_and_setup_s": round(keygen_s, 1),
            "mock_prover_violations": rep.violations(),

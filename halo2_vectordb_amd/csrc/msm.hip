@@ -818,15 +818,17 @@ int msm_collect() {
   Context& cx = ctx();
   if (!cx.msm_pending) return VDB_OK;
   cx.msm_pending = false;
-  VDB_HIP(hipStreamSynchronize(cx.aux));
   if (!cx.msm_counters) {  // the batch ran synchronously (profiling): nothing left to check
+    VDB_HIP(hipStreamSynchronize(cx.aux));
     VDB_HIP(hipStreamSynchronize(cx.stream));
     return VDB_OK;
   }
+  // the auxiliary stream is ordered after the batch's main-stream kernels (ev_tail): reading the flag there does not wait
+  // for whatever the caller queued on the main stream behind the MSM (the NTTs of the same columns)
   uint32_t h_counters[2] = {0, 0};
-  VDB_HIP(hipMemcpyAsync(h_counters, cx.msm_counters, sizeof(h_counters), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipMemcpyAsync(h_counters, cx.msm_counters, sizeof(h_counters), hipMemcpyDeviceToHost, cx.aux));
   cx.msm_counters = nullptr;
-  VDB_HIP(hipStreamSynchronize(cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.aux));
   if (h_counters[1]) {
     set_error("msm: internal task buffer overflow");
     return VDB_ERR_HIP;
@@ -1037,8 +1039,9 @@ int vdb_msm_batch_end(vdb_g1* out_host, size_t n_cols) {
   if (n_cols == 0) return VDB_OK;
   const void* dout = ctx().msm_out;
   VDB_ARG(dout, "no deferred MSM to collect");
-  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().stream));
-  VDB_HIP(hipStreamSynchronize(ctx().stream));
+  // on the auxiliary stream, where the points were produced: work queued on the main stream after _begin keeps running
+  VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(Affine), hipMemcpyDeviceToHost, ctx().aux));
+  VDB_HIP(hipStreamSynchronize(ctx().aux));
   return VDB_OK;
 }
 int vdb_msm_batch_masked_dev(const vdb_srs* srs, int basis, const vdb_fr* scalars_dev, size_t n_cols, size_t n, const uint8_t* skip_mask_dev,

@@ -297,18 +297,20 @@ __global__ __launch_bounds__(256) void k_lp_rows(const uint32_t* __restrict__ in
 struct GateK {
   uint32_t c2[9];  // 2 r written with dominating limbs (l9_offset_limbs): subtracting a canonical value
 };
+// `sub` > 0: the advice cosets live on 2^(log_ne + sub) points and the gate is evaluated on every 2^sub-th of them — the gate
+// has degree 3, so its share of the quotient is determined on the coset of 2 n points inside the 4 n the permutation needs.
 __global__ __launch_bounds__(256) void k_gate_eval(const u256* __restrict__ adv, const u256* __restrict__ sel, uint64_t n_cols, uint32_t log_ne, uint32_t e,
-                                                   u256 y32 /* 32 y */, GateK gk, u256* __restrict__ acc) {
+                                                   uint32_t sub, u256 y32 /* 32 y */, GateK gk, u256* __restrict__ acc) {
   const uint64_t ne = 1ull << log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
-  const uint64_t mask = ne - 1, r = 1ull << e;
+  const uint64_t ne_a = ne << sub, mask = ne_a - 1, r = 1ull << (e + sub), ja = j << sub;
   const L9 Y = l9_split(y32);
   L9 h = l9_split(ld256(acc + j));
   for (uint64_t c = 0; c < n_cols; c++) {
-    const u256* a = adv + c * ne;
+    const u256* a = adv + c * ne_a;
     const L9 q32 = l9_split32(ld256(sel + c * ne + j));
-    const L9 bc = l9_mul<Fr>(l9_split(ld256(a + ((j + r) & mask))), l9_split32(ld256(a + ((j + 2 * r) & mask))));
-    const L9 g = l9_sub(l9_add(l9_split(ld256(a + j)), bc), l9_split(ld256(a + ((j + 3 * r) & mask))), gk.c2);
+    const L9 bc = l9_mul<Fr>(l9_split(ld256(a + ((ja + r) & mask))), l9_split32(ld256(a + ((ja + 2 * r) & mask))));
+    const L9 g = l9_sub(l9_add(l9_split(ld256(a + ja)), bc), l9_split(ld256(a + ((ja + 3 * r) & mask))), gk.c2);
     h = l9_mul2<Fr>(h, Y, g, q32);
   }
   st256(acc + j, l9_canon<Fr>(h));
@@ -655,9 +657,11 @@ int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const v
   return VDB_OK;
 }
 
-int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
+int vdb_gate_eval_sub_dev(const vdb_fr* adv_ext_dev, uint32_t adv_ext_k, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y,
+                          vdb_fr* acc_dev) {
   VDB_REQUIRE_INIT();
-  VDB_ARG(adv_ext_dev && sel_ext_dev && y && acc_dev && k + ext_k <= 28, "bad argument");
+  VDB_ARG(adv_ext_dev && sel_ext_dev && y && acc_dev && adv_ext_k >= ext_k && k + adv_ext_k <= 28, "bad argument");
+  if (n_cols == 0) return VDB_OK;
   u256 yv;
   memcpy(&yv, y, 32);
   const uint64_t ne = 1ull << (k + ext_k);
@@ -666,10 +670,13 @@ int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size
     GateK gk;
     l9_offset_limbs<FrParams>(2, gk.c2);
     hipLaunchKernelGGL(k_gate_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(adv_ext_dev), as_u256(sel_ext_dev), (uint64_t)n_cols,
-                     k + ext_k, ext_k, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
+                     k + ext_k, ext_k, adv_ext_k - ext_k, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
+}
+int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
+  return vdb_gate_eval_sub_dev(adv_ext_dev, ext_k, sel_ext_dev, n_cols, k, ext_k, y, acc_dev);
 }
 int vdb_const_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* qc_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
   VDB_REQUIRE_INIT();

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hostperm.hpp"
 #include "poseidon.hpp"
 
 using namespace vdb;
@@ -31,175 +32,32 @@ struct vdb_transcript {
 
 namespace {
 
-// Host arithmetic for the sponge: the same Montgomery representatives (R = 2^256) on four 64-bit limbs with 128-bit
-// products — a proof of a few thousand columns absorbs tens of thousands of values, i.e. ~10^4 permutations of 68 rounds,
-// and the device-oriented 29-bit-limb product is several times slower on a CPU core.
-struct F4 {
-  uint64_t l[4];
+// The sponge's arithmetic lives in hostperm.cpp (four 64-bit limbs; built twice, the BMI2 + ADX build is picked when the CPU
+// has both; VDB_HOST_GENERIC=1 forces the portable build, which the tests use to hold the two against each other).
+struct HostKernels {
+  host_permute_fn permute;
+  host_horner_fn horner;
 };
-constexpr uint64_t FR_P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
-constexpr uint64_t FR_INV = 0xc2e1f593efffffffull;  // -r^-1 mod 2^64
-inline F4 to_f4(const u256& a) {
-  F4 r;
-  memcpy(r.l, a.w, 32);
-  return r;
-}
-inline u256 from_f4(const F4& a) {
-  u256 r;
-  memcpy(r.w, a.l, 32);
-  return r;
-}
-inline bool geq_p(const uint64_t t[4]) {
-  for (int i = 3; i >= 0; i--)
-    if (t[i] != FR_P[i]) return t[i] > FR_P[i];
-  return true;
-}
-inline void sub_p(uint64_t t[4]) {
-  unsigned __int128 b = 0;
-  for (int i = 0; i < 4; i++) {
-    unsigned __int128 d = (unsigned __int128)t[i] - FR_P[i] - (uint64_t)b;
-    t[i] = (uint64_t)d;
-    b = (d >> 64) & 1;
-  }
-}
-inline F4 f4_add(const F4& a, const F4& b) {
-  F4 r;
-  unsigned __int128 c = 0;
-  for (int i = 0; i < 4; i++) {
-    c += (unsigned __int128)a.l[i] + b.l[i];
-    r.l[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  if (c || geq_p(r.l)) sub_p(r.l);  // a + b < 2 r < 2^255: no carry out in fact
-  return r;
-}
-inline F4 f4_mul(const F4& a, const F4& b) {  // CIOS
-  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
-    unsigned __int128 c = 0;
-    for (int j = 0; j < 4; j++) {
-      c += (unsigned __int128)a.l[j] * b.l[i] + t[j];
-      t[j] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[4];
-    t[4] = (uint64_t)c;
-    t[5] = (uint64_t)(c >> 64);
-    const uint64_t m = t[0] * FR_INV;
-    c = (unsigned __int128)m * FR_P[0] + t[0];
-    c >>= 64;
-    for (int j = 1; j < 4; j++) {
-      c += (unsigned __int128)m * FR_P[j] + t[j];
-      t[j - 1] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[4];
-    t[3] = (uint64_t)c;
-    t[4] = t[5] + (uint64_t)(c >> 64);
-  }
-  F4 r = {{t[0], t[1], t[2], t[3]}};
-  if (t[4] || geq_p(r.l)) sub_p(r.l);
-  return r;
+const HostKernels& host_kernels() {
+  static const HostKernels k = [] {
+    const char* force = getenv("VDB_HOST_GENERIC");
+    bool fast = !(force && force[0] == '1');
+#if defined(__x86_64__)
+    fast = fast && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+#else
+    fast = false;
+#endif
+    return fast ? HostKernels{host_permute_mulx, host_horner_mulx} : HostKernels{host_permute_generic, host_horner_generic};
+  }();
+  return k;
 }
 
-// sum_j a[j] b[j] with ONE Montgomery reduction: the n (<= 16) double-width products are summed in 576 bits, then reduced
-// word by word.  A proof of 2 x 10^4 columns absorbs ~2 x 10^5 values, i.e. ~5 x 10^4 permutations: this dot product and the
-// sparse partial rounds below are what the transcript's host time is made of.
-inline F4 f4_dot(const F4* a, const F4* b, int n, size_t stride_b = 1) {
-  // product scanning: column c collects every x_i y_j with i + j = c of every pair into a three-word accumulator
-  uint64_t T[9];
-  uint64_t a0 = 0, a1 = 0, a2 = 0;
-  for (int c = 0; c < 7; c++) {
-    const int ilo = c > 3 ? c - 3 : 0, ihi = c < 3 ? c : 3;
-    for (int k = 0; k < n; k++) {
-      const uint64_t* x = a[k].l;
-      const uint64_t* y = b[(size_t)k * stride_b].l;
-      for (int i = ilo; i <= ihi; i++) {
-        const unsigned __int128 pr = (unsigned __int128)x[i] * y[c - i];
-        const unsigned __int128 s = (unsigned __int128)a0 + (uint64_t)pr;
-        a0 = (uint64_t)s;
-        const unsigned __int128 s1 = (unsigned __int128)a1 + (uint64_t)(pr >> 64) + (uint64_t)(s >> 64);
-        a1 = (uint64_t)s1;
-        a2 += (uint64_t)(s1 >> 64);
-      }
-    }
-    T[c] = a0;
-    a0 = a1;
-    a1 = a2;
-    a2 = 0;
-  }
-  T[7] = a0;
-  T[8] = a1;
-  for (int i = 0; i < 4; i++) {  // T += m r 2^(64 i) clears word i
-    const uint64_t m = T[i] * FR_INV;
-    unsigned __int128 c = 0;
-    for (int j = 0; j < 4; j++) {
-      c += (unsigned __int128)m * FR_P[j] + T[i + j];
-      T[i + j] = (uint64_t)c;
-      c >>= 64;
-    }
-    for (int w = i + 4; w < 9; w++) {
-      c += T[w];
-      T[w] = (uint64_t)c;
-      c >>= 64;
-    }
-  }
-  // below n r + r: a few conditional subtractions, the word above 256 bits included
-  uint64_t hi = T[8];
-  F4 r = {{T[4], T[5], T[6], T[7]}};
-  while (hi || geq_p(r.l)) {
-    unsigned __int128 bw = 0;
-    for (int i = 0; i < 4; i++) {
-      unsigned __int128 d = (unsigned __int128)r.l[i] - FR_P[i] - (uint64_t)bw;
-      r.l[i] = (uint64_t)d;
-      bw = (d >> 64) & 1;
-    }
-    hi -= (uint64_t)bw;
-  }
-  return r;
-}
-inline F4 f4_pow5(const F4& x) {
-  const F4 x2 = f4_mul(x, x);
-  return f4_mul(f4_mul(x2, x2), x);
-}
-
-// The permutation in the optimised schedule of the PSE `poseidon` Spec (the one the chip runs on the device): the first
-// round's constants, half - 1 full rounds with folded constants and the MDS matrix, one with the pre-sparse matrix, the
-// partial rounds as sparse matrices (2 t - 1 products instead of t^2), the remaining full rounds.  Same function as the
-// textbook schedule (tests/test_transcript_cpu.py holds it against an independent Python restatement of that one).
 void permute(vdb_transcript* tr) {
   const PoseidonOpt& o = tr->opt;
-  const int t = o.t, half = o.half;
-  F4 st[16], nx[16];
-  const F4* start = reinterpret_cast<const F4*>(o.start.data());
-  const F4* mds = reinterpret_cast<const F4*>(o.mds.data());
-  const F4* pre = reinterpret_cast<const F4*>(o.pre_sparse.data());
-  const F4* srow = reinterpret_cast<const F4*>(o.sparse_row.data());
-  const F4* scol = reinterpret_cast<const F4*>(o.sparse_col.data());
-  const F4* end = reinterpret_cast<const F4*>(o.end.data());
-  const F4* partial = reinterpret_cast<const F4*>(o.partial.data());
-  for (int i = 0; i < t; i++) st[i] = f4_add(to_f4(tr->state[i]), start[i]);
-  auto dense = [&](const F4* m) {
-    for (int i = 0; i < t; i++) nx[i] = f4_dot(m + (size_t)i * t, st, t);
-    for (int i = 0; i < t; i++) st[i] = nx[i];
-  };
-  for (int r = 1; r <= half; r++) {
-    for (int i = 0; i < t; i++) st[i] = f4_add(f4_pow5(st[i]), start[(size_t)r * t + i]);
-    dense(r < half ? mds : pre);
-  }
-  for (int p = 0; p < o.rp; p++) {
-    st[0] = f4_add(f4_pow5(st[0]), partial[p]);
-    const F4 n0 = f4_dot(srow + (size_t)p * t, st, t);
-    for (int i = 1; i < t; i++) st[i] = f4_add(f4_mul(st[0], scol[(size_t)p * (t - 1) + i - 1]), st[i]);
-    st[0] = n0;
-  }
-  for (int r = 0; r < half - 1; r++) {
-    for (int i = 0; i < t; i++) st[i] = f4_add(f4_pow5(st[i]), end[(size_t)r * t + i]);
-    dense(mds);
-  }
-  for (int i = 0; i < t; i++) st[i] = f4_pow5(st[i]);
-  dense(mds);
-  for (int i = 0; i < t; i++) tr->state[i] = from_f4(st[i]);
+  static_assert(sizeof(u256) == 32, "field elements are 32 bytes");
+  auto w = [](const std::vector<u256>& v) { return reinterpret_cast<const uint64_t*>(v.data()); };
+  const HostPermView view = {o.t, o.half, o.rp, w(o.start), w(o.partial), w(o.end), w(o.mds), w(o.pre_sparse), w(o.sparse_row), w(o.sparse_col)};
+  host_kernels().permute(view, reinterpret_cast<uint64_t*>(tr->state.data()));
 }
 
 void absorb_chunk(vdb_transcript* tr, const u256* in, int n_in) {
@@ -234,15 +92,7 @@ extern "C" {
 // challenge before anything goes back to the device; Python integers cost microseconds apiece)
 int vdb_fr_horner(const vdb_fr* values, size_t n, const vdb_fr* x, vdb_fr* acc) {
   VDB_ARG((values || n == 0) && x && acc, "null pointer");
-  F4 a, xx;
-  memcpy(a.l, acc, 32);
-  memcpy(xx.l, x, 32);
-  for (size_t i = 0; i < n; i++) {
-    F4 v;
-    memcpy(v.l, values + i, 32);
-    a = f4_add(f4_mul(a, xx), v);
-  }
-  memcpy(acc, a.l, 32);
+  host_kernels().horner(reinterpret_cast<const uint64_t*>(values), n, reinterpret_cast<const uint64_t*>(x), reinterpret_cast<uint64_t*>(acc));
   return VDB_OK;
 }
 

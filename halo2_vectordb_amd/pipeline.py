@@ -390,9 +390,11 @@ class KmeansHotPath:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
     # ------------------------------------------------------------------ one pass of the hot path
-    def step(self, timings=None, blind_seed=None, with_ext=True):
+    def step(self, timings=None, blind_seed=None, with_ext=True, sync=True):
         """`with_ext`: False leaves coeff_to_extended out (a caller that streams the cosets itself, block by block: rounds.py on
-        circuits whose cosets do not fit HBM)"""
+        circuits whose cosets do not fit HBM).  `sync`: False returns as soon as the commitments are on the host, the transforms
+        still running on the library's stream (the caller absorbs the commitments into its transcript meanwhile; everything it
+        queues next is ordered behind them)."""
         lib, B = self.lib, 32
         self.refresh_blinds(blind_seed)
 
@@ -441,7 +443,8 @@ class KmeansHotPath:
             # a deferred MSM must always be collected, or every later MSM is refused ("deferred batch has not been collected")
             lib.vdb_msm_batch_end(None, ctypes.c_size_t(0))
             raise
-        api.sync()
+        if sync:
+            api.sync()
         return self.commitments
 
     # ------------------------------------------------------------------ the Mock stage (src/scaffold/mod.rs:263-266)

@@ -16,6 +16,8 @@ from the returned evaluations, and every opening against its commitments in the 
 import ctypes
 from collections.abc import Mapping
 
+import time
+
 import numpy as np
 
 from . import api
@@ -26,6 +28,7 @@ B = 32
 FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
+GATE_EXT_K = 1   # the vertical gate q (a + b c - d) has degree 3: its share of the quotient is determined on the coset of 2 n points
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
@@ -107,6 +110,7 @@ class ProverRounds:
         self.n_sets = -(-self.n_perm // CHUNK_LEN)
         self.delta = api.fr_delta()
         self.fixed = {}
+        self._vk_digest = None
 
     # ------------------------------------------------------------------ helpers on device-resident columns
     def _to_coeff(self, lag_buf, n_cols):
@@ -121,10 +125,23 @@ class ProverRounds:
         check(self.lib.vdb_coeff_to_extended_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, EXT_K))
         return e
 
+    def _srs_for(self, n_cols, basis, dense):
+        return self.hp.srs if basis == 1 and not dense else (self.srs_few if basis == 0 and n_cols <= 8 else self.srs_m)
+
     def _commit(self, buf, n_cols, basis, dense=True):
         out = np.zeros((n_cols, 8), dtype=np.uint64)
-        srs = self.hp.srs if basis == 1 and not dense else (self.srs_few if basis == 0 and n_cols <= 8 else self.srs_m)
-        check(self.lib.vdb_msm_batch_dev(srs.h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
+        check(self.lib.vdb_msm_batch_dev(self._srs_for(n_cols, basis, dense).h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
+        return out
+
+    def _commit_begin(self, buf, n_cols, basis, dense=True):
+        """queue the commitment of n_cols columns and return (vdb_msm_batch_masked_dev_begin); _commit_end collects the points"""
+        if n_cols:
+            check(self.lib.vdb_msm_batch_masked_dev_begin(self._srs_for(n_cols, basis, dense).h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), None, None))
+
+    def _commit_end(self, n_cols):
+        out = np.zeros((n_cols, 8), dtype=np.uint64)
+        if n_cols:
+            check(self.lib.vdb_msm_batch_end(api._p(out), _sz(n_cols)))
         return out
 
     def _blind(self, buf, n_cols, from_row, seed):
@@ -138,6 +155,18 @@ class ProverRounds:
         check(self.lib.vdb_fill_rows_dev(buf.ptr, _sz(n_cols), _sz(self.rows), _sz(from_row), d.ptr))
         api.sync()
         d.free()
+
+    def vk_digest(self):
+        """The verifying key's entry into the transcript: ONE scalar, as halo2 absorbs vk.transcript_repr (a hash of the key made
+        at keygen) — here the squeeze of a sponge of its own over every fixed commitment in FIXED order, computed once per key (the
+        38 k points of the k = 16 cosine circuit would otherwise cost every proof 19 k permutations on the host)."""
+        if self._vk_digest is None:
+            tr0 = api.Transcript()
+            for name in FIXED:
+                tr0.common_points(self.fixed[name].commits)
+            self._vk_digest = tr0.squeeze()
+            tr0.free()
+        return self._vk_digest
 
     def _fixed_poly(self, name, lag_buf, n_cols, keep_lag=True, keep_ext=True):
         """commitment and coefficient form of a fixed polynomial; its extended coset only when it is small (the selector and
@@ -326,7 +355,10 @@ class ProverRounds:
         self.d_ez = api.DeviceBuffer((blk // CHUNK_LEN + 1) * self.ne * B)
         self.d_zf, self.d_zlast = api.DeviceBuffer(self.ne * B), api.DeviceBuffer(self.ne * B)
         self.d_h, self.d_h2, self.d_h3, self.d_h4 = (api.DeviceBuffer(self.ne * B) for _ in range(4))
+        self.d_hg = api.DeviceBuffer((rows << GATE_EXT_K) * B)      # the gates' accumulator, on the coset of 2 n points
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
+        self._vk_digest = None
+        self.vk_digest()            # part of the key, made here so that no proof pays for it
         return self
 
     # ------------------------------------------------------------------ the proving key on disk
@@ -384,8 +416,8 @@ class ProverRounds:
     # ------------------------------------------------------------------ the rounds
     def prove(self, challenges=None, seed=None, timings=None, multiopen="shplonk", instances=None):
         """challenges: dict of Montgomery field elements beta, gamma, y, x, v, or None to derive them with the Fiat–Shamir
-        transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the fixed commitments
-        (in place of the verifying key's digest); advice commitments -> theta (squeezed as halo2 does, unused: the lookups
+        transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the verifying key's
+        digest (vk_digest: one scalar made of the fixed commitments at keygen); the public inputs; advice commitments -> theta (squeezed as halo2 does, unused: the lookups
         are single-column); permuted input / table commitments -> beta, gamma; product commitments -> y; the quotient's
         pieces -> x; all evaluations, rotation by rotation -> then the multi-open: "gwc": v, one quotient per rotation
         point; "shplonk" (what the reference's gen_snark_shplonk runs, [UPSTREAM-RECALL] for the order of its challenges):
@@ -402,24 +434,33 @@ class ProverRounds:
         ch = {} if challenges is None else {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
         p = {name: api._p(v) for name, v in ch.items()}
 
+        host = self.host_ms = {"transcript": 0.0}     # wall-clock ms the host spent in the sponge (read by the benches)
+
         def squeeze(*names):
             if tr is not None:
+                t0 = time.perf_counter()
                 for name in names:
                     ch[name] = tr.squeeze()
                     p[name] = api._p(ch[name])
+                host["transcript"] += (time.perf_counter() - t0) * 1e3
 
         def write_points(points):
             if tr is not None and len(points):
+                t0 = time.perf_counter()
                 tr.write_points(np.stack([np.asarray(pt) for pt in points]) if isinstance(points, list) else points)
+                host["transcript"] += (time.perf_counter() - t0) * 1e3
 
         if tr is not None:
-            for name in FIXED:
-                tr.common_points(self.fixed[name].commits)
+            tr.common_scalar(self.vk_digest())
         usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
         fx = self.fixed
         T = {} if timings is None else timings
 
         def stage(name, fn):
+            # device time per stage only when asked for: the timer waits for the device, and an untimed proof lets the host's
+            # transcript work run beside whatever the device still has queued
+            if timings is None:
+                return fn()
             api.timer_start()
             r = fn()
             T[name] = T.get(name, 0.0) + api.timer_stop()
@@ -427,7 +468,8 @@ class ProverRounds:
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
         resident = hp.ext_cols >= n_cols + 1       # every advice coset stays in HBM; otherwise they are recomputed block by block below
-        adv_commits = hp.step(T, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident).copy()
+        # (the transforms of the advice columns are still running when step returns: the commitments are absorbed meanwhile)
+        adv_commits = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False).copy()
         if instances is None:
             instances = [hp.d_stream.download((4,), offset=cell * 32) for cell in self.instance_cells]
         instances = [np.ascontiguousarray(v, dtype=np.uint64) for v in instances]
@@ -513,19 +555,23 @@ class ProverRounds:
         stage("products", products)
         self._blind(d_zp, n_sets, usable + 1, next(seeds))
         self._blind(d_zl, n_lk, usable + 1, next(seeds))
+        def derived_forms(names):
+            for name in names:
+                q = polys[name]
+                check(lib.vdb_lagrange_to_coeff_dev(q.lag.ptr, _sz(q.n_cols), k))      # in place: the Lagrange form is not needed again
+                q.coeff, q.lag = q.lag, None
+        # The host absorbs one batch of commitments while the device works on the next thing that needs no challenge: the lookup
+        # products' MSM beside the permutation products' commitments, the coefficient forms (needed by the quotient, independent of y)
+        # beside the lookup products' commitments.
         polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
-        polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit(d_zl, n_lk, 1)))
+        stage("commit_products", lambda: self._commit_begin(d_zl, n_lk, 1))
         write_points(polys["zp"].commits)
+        polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit_end(n_lk)))
+        stage("derived_ntt", lambda: derived_forms(("pa", "ps", "zp", "zl")))
         write_points(polys["zl"].commits)
         squeeze("y")
 
         # round 4 (y): the quotient
-        def derived_forms():
-            for name in ("pa", "ps", "zp", "zl"):
-                q = polys[name]
-                check(lib.vdb_lagrange_to_coeff_dev(q.lag.ptr, _sz(q.n_cols), k))      # in place: the Lagrange form is not needed again
-                q.coeff, q.lag = q.lag, None
-        stage("derived_ntt", derived_forms)
         d_h = self.d_h
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
         zp = polys["zp"]
@@ -539,10 +585,14 @@ class ProverRounds:
             # the lookup argument (five per lookup column).  Each group is folded into an accumulator of its own (acc <- acc y +
             # term, from zero) while ONE sweep over blocks of columns produces every coset once — the advice / lookup / constants
             # cosets (unless resident), selectors, sigma, product and lookup-argument cosets — and the groups are joined at the end:
-            # h = ((A1 y^n2 + A2) y^n3 + A3) y^n4 + A4.
-            a1, a2, a3, a4 = d_h, self.d_h2, self.d_h3, self.d_h4
+            # h = (((Ag y^ni + A1) y^n2 + A2) y^n3 + A3) y^n4 + A4.
+            # The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on the
+            # coset of 2 n points inside the 4 n (every second point of the advice cosets; the selector cosets are made for 2 n
+            # points only: half the transform), divided and brought back to coefficients there, and joined in coefficient form.
+            ag, a1, a2, a3, a4 = self.d_hg, d_h, self.d_h2, self.d_h3, self.d_h4
             for a in (a1, a2, a3, a4):
                 check(lib.vdb_memset_dev(a.ptr, 0, _sz(ne * B)))
+            check(lib.vdb_memset_dev(ag.ptr, 0, _sz((rows << GATE_EXT_K) * B)))
             perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
             # l0 (1 - z_0), l_last (z_last^2 - z_last): the first two terms of group 2
             to_ext(zp.coeff.ptr, d_zf.ptr, 1)
@@ -554,8 +604,8 @@ class ProverRounds:
                 base, col0 = adv_ext_block(c0, nb)
                 g1 = min(c0 + nb, n_adv)
                 if c0 < g1:                                            # gates of the block's advice columns
-                    to_ext(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, g1 - c0)
-                    check(lib.vdb_gate_eval_dev(col_ptr(base, col0, c0), d_eb.ptr, _sz(g1 - c0), k, EXT_K, p["y"], a1.ptr))
+                    check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, _sz(g1 - c0), k, GATE_EXT_K))
+                    check(lib.vdb_gate_eval_sub_dev(col_ptr(base, col0, c0), EXT_K, d_eb.ptr, _sz(g1 - c0), k, GATE_EXT_K, p["y"], ag.ptr))
                 # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
                 set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
                 z0 = max(set_lo - 1, 0)
@@ -575,21 +625,25 @@ class ProverRounds:
                     to_ext(polys["zl"].coeff.at(j0 * rows * B), d_eb.at(2 * third * ne * B), m)
                     check(lib.vdb_lookup_eval_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
                                                   _sz(m), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
-            # public inputs close group 1: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
+            # public inputs, group 1: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
             for i, (col, _row) in enumerate(self.instance_pos):
                 l_ext = fx["inst"].ext.at(i * ne * B)
                 base, col0 = adv_ext_block(col, 1)
                 check(lib.vdb_const_eval_dev(col_ptr(base, col0, col), l_ext, _sz(1), k, EXT_K, p["y"], a1.ptr))
                 check(lib.vdb_poly_axpy_dev(a1.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
-            # join the groups (acc_next += y^(terms of the next group) * acc)
+            # join the groups that live on the 4 n points (acc_next += y^(terms of the next group) * acc), divide, back to coefficients
             y_int = _fr_to_int(ch["y"])
-            n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
+            ni, n2, n3, n4 = len(self.instance_pos), 2 + (n_sets - 1), n_sets, 5 * n_lk
             check(lib.vdb_poly_axpy_dev(a2.ptr, api._p(_fr_from_int(pow(y_int, n2, R_MOD))), a1.ptr, _sz(ne)))
             check(lib.vdb_poly_axpy_dev(a3.ptr, api._p(_fr_from_int(pow(y_int, n3, R_MOD))), a2.ptr, _sz(ne)))
             check(lib.vdb_poly_axpy_dev(a4.ptr, api._p(_fr_from_int(pow(y_int, n4, R_MOD))), a3.ptr, _sz(ne)))
             check(lib.vdb_memcpy_d2d(d_h.ptr, a4.ptr, _sz(ne * B)))
             check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
             check(lib.vdb_extended_to_coeff_dev(d_h.ptr, _sz(1), k, EXT_K))
+            # the gates' share: the same on the 2 n points, then h += y^(every later term) * (its 2 n coefficients)
+            check(lib.vdb_divide_by_vanishing_dev(ag.ptr, k, GATE_EXT_K))
+            check(lib.vdb_extended_to_coeff_dev(ag.ptr, _sz(1), k, GATE_EXT_K))
+            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, ni + n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
         stage("quotient", quotient)
         n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)))
@@ -619,9 +673,11 @@ class ProverRounds:
                     evals[(name, rot)] = out
         stage("evaluations", evaluate)
         if tr is not None:
+            t0 = time.perf_counter()
             for rot, names in opened.items():
                 for name in names:
                     tr.write_scalars(evals[(name, rot)])
+            host["transcript"] += (time.perf_counter() - t0) * 1e3
         d_comb, d_quot = self.d_comb, self.d_quot
         if multiopen == "shplonk":
             openings = self._shplonk(allp, opened, points, evals, p, ch, squeeze, write_points, stage)
@@ -779,7 +835,8 @@ class ProverRounds:
         for q in self.fixed.values():
             q.free()
         self.fixed = {}
-        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_comb", "d_quot"):
+        self._vk_digest = None
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

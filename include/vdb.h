@@ -233,7 +233,9 @@ int vdb_msm_batch_dev(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, 
 /* Deferred form of vdb_msm_batch[_masked]_dev (mask and constant points may both be NULL): _begin queues the whole MSM and
  * returns without waiting; the bucket folding of its last batch — short, latency-bound launches — runs on a second
  * stream, so work queued next (vdb_lagrange_to_coeff_dev / vdb_coeff_to_extended_dev on the same columns: the scalars
- * are no longer read) overlaps it.  _end waits and copies the n_cols commitments out.  One deferred MSM at a time. */
+ * are no longer read) overlaps it.  _end waits FOR THE MSM ONLY and copies the n_cols commitments out: what was queued on the
+ * library's stream after _begin may still be running when it returns (the caller feeds the commitments to its transcript
+ * while the transforms run; vdb_sync() or any blocking call joins).  One deferred MSM at a time. */
 int vdb_msm_batch_masked_dev_begin(const vdb_srs *srs, int basis, const vdb_fr *scalars_dev, size_t n_cols, size_t n, const uint8_t *skip_mask_dev,
                                    const vdb_g1 *const_points_dev);
 /* same for columns described by vdb_colsrc (n rows each, the last n_blind of them blinding rows) */
@@ -366,6 +368,14 @@ int vdb_extended_to_coeff_dev(vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32
  * the extended coset of 2^(k+ext_k) points.  adv_ext_dev, sel_ext_dev: n_cols x 2^(k+ext_k) (vdb_coeff_to_extended_dev of
  * the advice and selector polynomials); acc_dev: 2^(k+ext_k), read and written (zero it before the first call). */
 int vdb_gate_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *y, vdb_fr *acc_dev);
+/* The same on a sub-coset: the gate has degree 3, so its share of the quotient, (sum of the gate terms) / (X^n - 1), has degree
+ * below 2 n and is determined by the coset of 2^(k+ext_k) points that lies inside the 2^(k+adv_ext_k) points the advice cosets were
+ * made for (every 2^(adv_ext_k-ext_k)-th point: halo2's extended domain is sized for the highest-degree term, here the
+ * permutation's, and evaluates every term on all of it).  adv_ext_dev: n_cols x 2^(k+adv_ext_k); sel_ext_dev: n_cols x
+ * 2^(k+ext_k) (vdb_coeff_to_extended_dev with ext_k: half the transform); acc_dev: 2^(k+ext_k).  The caller divides by the
+ * vanishing polynomial on the small coset, returns to coefficients there and adds them to the quotient's. */
+int vdb_gate_eval_sub_dev(const vdb_fr *adv_ext_dev, uint32_t adv_ext_k, const vdb_fr *sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k,
+                          const vdb_fr *y, vdb_fr *acc_dev);
 /* Constant cells as a gate: per advice column the fixed polynomials qc (one on the rows that hold a QuantumCell::Constant) and
  * fc (the constant on those rows, zero elsewhere) with qc(X) a(X) - fc(X) = 0 on the domain.  This call folds the qc part into
  * the accumulator: acc[j] <- Horner over the columns of (acc * y + qc_c[j] * a_c[j]) on the extended coset.  The fc part is linear

@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
 FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")
+
+
+def _vk_digest(api, fixed):
+    """the verifying key enters the transcript as one scalar, as halo2's vk.transcript_repr does: here the squeeze of a sponge of
+    its own over every fixed commitment (a verifier computes it once per key)"""
+    tr0 = api.Transcript()
+    for name in FIXED:
+        for pt in fixed[name]:
+            tr0.common_point(pt)
+    d = tr0.squeeze()
+    tr0.free()
+    return d
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
@@ -198,9 +210,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
         pos += 32 * m
         return pts
     tr = api.Transcript()
-    for name in FIXED:
-        for pt in fixed[name]:
-            tr.common_point(pt)
+    tr.common_scalar(_vk_digest(api, fixed))
     commitments = dict(fixed)
     def absorb(pts):
         for pt in pts:
@@ -391,9 +401,7 @@ def _verify(O, api, proof, vk):
                 pos += 32
                 tr.common_point(pts[-1])
             return np.stack(pts) if pts else np.zeros((0, 8), dtype=np.uint64)
-        for name in FIXED:
-            for pt in vk["fixed"][name]:
-                tr.common_point(pt)
+        tr.common_scalar(_vk_digest(api, vk["fixed"]))
         for value in vk.get("instances", []):
             tr.common_scalar(O.fr_from_ints([value])[0])
         C = dict(vk["fixed"])

@@ -110,3 +110,28 @@ def test_compressed_point_sign_bit_is_selectable():
     with pytest.raises(api.VdbError):
         tr = api.Transcript()
         tr.set_sign_bit(5)
+
+
+def test_both_host_builds_of_the_sponge_agree():
+    """hostperm.cpp is built twice (portable / BMI2 + ADX); the library picks by CPU feature, VDB_HOST_GENERIC=1 forces the
+    portable one: the same absorbed values give the same challenges and the same Horner value in both"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import numpy as np, ctypes\n"
+            "from halo2_vectordb_amd import api, _lib\n"
+            "rng = np.random.default_rng(5)\n"
+            "v = rng.integers(0, 1 << 62, size=(1001, 4), dtype=np.uint64)\n"
+            "tr = api.Transcript()\n"
+            "tr.write_scalars(v)\n"
+            "a = tr.squeeze(); b = tr.squeeze()\n"
+            "acc = np.zeros(4, dtype=np.uint64)\n"
+            "_lib.check(_lib.load().vdb_fr_horner(api._p(v), ctypes.c_size_t(len(v)), api._p(a), api._p(acc)))\n"
+            "print(' '.join(str(int(x)) for x in list(a) + list(b) + list(acc)))\n")
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, VDB_HOST_GENERIC=force, PYTHONPATH=root)
+        outs.append(subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120, cwd=root))
+        assert outs[-1].returncode == 0, outs[-1].stderr
+    assert outs[0].stdout == outs[1].stdout and len(outs[0].stdout.split()) == 12

@@ -35,16 +35,21 @@ t_keygen = time.time() - t0
 rep = pr.keygen_report.as_dict()
 free, total = api.mem_info()
 print(json.dumps({"keygen_s": round(t_keygen, 1), "mock": rep, "hbm_used_gb": round((total - free) / 1e9, 1)}), file=sys.stderr, flush=True)
+# untimed proofs for the wall time (the host's transcript work runs beside whatever the device has queued), then one instrumented
+# proof for the device time per stage (its timers wait for the device after every stage)
 best = None
 for it in range(2):
-    T = {}
     t0 = time.time()
-    out = pr.prove(None, timings=T)
+    out = pr.prove(None)
     wall = (time.time() - t0) * 1e3
-    print(json.dumps({"proof": it, "wall_ms": round(wall, 1)}), file=sys.stderr, flush=True)
+    print(json.dumps({"proof": it, "wall_ms": round(wall, 1), "host_transcript_ms": round(pr.host_ms["transcript"], 1)}), file=sys.stderr, flush=True)
     if best is None or wall < best[0]:
-        best = (wall, T, out)
-wall, T, out = best
+        best = (wall, dict(pr.host_ms), out)
+wall, host_ms, out = best
+T = {}
+t0 = time.time()
+pr.prove(None, timings=T)
+wall_timed = (time.time() - t0) * 1e3
 identity = quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
 if proof_path:
     # the proof (public inputs + proof bytes) and what a verifier holds: the circuit's shape, the fixed commitments, which polynomial
@@ -65,6 +70,7 @@ print(json.dumps({"workload": f"kmeans K=4 I={I} 256x128 k=16 {metric}, whole co
                   "advice_cosets_resident": bool(hp.ext_cols >= hp.n_cols + 1), "mock_report_on_keygen_witness": rep,
                   "quotient_identity_at_x_holds": bool(identity), "proof_bytes": len(out["proof"]),
                   "hot_path_setup_s": round(t_hp, 1), "keygen_s": round(t_keygen, 1), "proof_wall_ms": round(wall, 1),
+                  "proof_wall_ms_with_stage_timers": round(wall_timed, 1), "host_transcript_ms": round(host_ms["transcript"], 1),
                   "device_ms": {k: round(v, 2) for k, v in T.items()}, "device_ms_total": round(sum(T.values()), 1),
                   "constraints_per_s_whole_proof": cells / (wall * 1e-3), "hbm_used_gb": round((total - free) / 1e9, 1)}))
 pr.free()

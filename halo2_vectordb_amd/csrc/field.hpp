@@ -230,8 +230,27 @@ HD u256 mont_mul32(const u256& a, const u256& b) {
 // asm statement with an s_nop, which costs more than the 64-bit add per column the compiler spends on joining the
 // two chains it builds to hide the latency of the reduction digit.)
 HD void mad64(uint64_t& acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+// On the device the three cores below are ONE inline-asm statement each (core29_*.inc, written by gen_core29.py): a single
+// accumulator chain — 162 multiply-adds, 9 x (v_mul_lo_u32, v_and) for the reduction digits, 9 masks, 17 shifts = 206 vector
+// instructions — where the compiler's schedule of the C++ below spends 243 (a second chain per column to hide the digit's latency,
+// a 64-bit add to join the two, register moves).  Every one of these instructions issues at the same rate on gfx950 and the NTT and
+// MSM kernels run at the issue ceiling, so the instruction count is the time: tools/core_probe.hip measures 169 against 148 G
+// products/s, bit-identical.  The host build (and the reader) keeps the C++ form.
+#define VDB_CORE29_OUT(o) "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8])
+#define VDB_CORE29_IN(a) "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8])
+#define VDB_CORE29_MOD(M)                                                                                                                          \
+  "s"(M::P29[0]), "s"(M::P29[1]), "s"(M::P29[2]), "s"(M::P29[3]), "s"(M::P29[4]), "s"(M::P29[5]), "s"(M::P29[6]), "s"(M::P29[7]), "s"(M::P29[8]), \
+      "s"(M::INV29)
+#define VDB_CORE29_CLOBBER "vcc", "v30", "v31"
 template <class M>
 HD void mont_core29(uint32_t out[9], const uint32_t A[9], const uint32_t B[9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(
+#include "core29_mul.inc"
+      : VDB_CORE29_OUT(out)
+      : VDB_CORE29_IN(A), VDB_CORE29_IN(B), VDB_CORE29_MOD(M)
+      : VDB_CORE29_CLOBBER);
+#else
   constexpr uint32_t MASK = 0x1fffffffu;
   uint32_t mq[9];
   uint32_t P[9];
@@ -257,12 +276,20 @@ HD void mont_core29(uint32_t out[9], const uint32_t A[9], const uint32_t B[9]) {
     out[k - 9] = k < 17 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
     acc >>= 29;
   }
+#endif
 }
 
 // Sum of two products under ONE reduction: (A1 * B1 + A2 * B2 + m * p) / 2^261.  Limbs of A1 + A2 together below
 // 6 * 2^29 (column bound as in mont_core29), B1, B2 normalised.  Saves the 81 reduction multiply-adds of the second product.
 template <class M>
 HD void mont_core29_2(uint32_t out[9], const uint32_t A1[9], const uint32_t B1[9], const uint32_t A2[9], const uint32_t B2[9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(
+#include "core29_mul2.inc"
+      : VDB_CORE29_OUT(out)
+      : VDB_CORE29_IN(A1), VDB_CORE29_IN(B1), VDB_CORE29_IN(A2), VDB_CORE29_IN(B2), VDB_CORE29_MOD(M)
+      : VDB_CORE29_CLOBBER);
+#else
   constexpr uint32_t MASK = 0x1fffffffu;
   uint32_t mq[9], P[9];
 #pragma unroll
@@ -293,12 +320,23 @@ HD void mont_core29_2(uint32_t out[9], const uint32_t A1[9], const uint32_t B1[9
     out[k - 9] = k < 17 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
     acc >>= 29;
   }
+#endif
 }
 
 // Squaring variant: the 36 off-diagonal products are taken once against the doubled operand (45 multiply-adds instead
 // of 81 for the product half).  A: limbs below 2^29 + 8 (normalised) so that a doubled column still fits 64 bits.
 template <class M>
 HD void mont_sqr_core29(uint32_t out[9], const uint32_t A[9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t D[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) D[j] = A[j] << 1;
+  asm(
+#include "core29_sqr.inc"
+      : VDB_CORE29_OUT(out)
+      : VDB_CORE29_IN(A), VDB_CORE29_IN(D), VDB_CORE29_MOD(M)
+      : VDB_CORE29_CLOBBER);
+#else
   constexpr uint32_t MASK = 0x1fffffffu;
   uint32_t mq[9], A2[9], P[9];
 #pragma unroll
@@ -328,6 +366,7 @@ HD void mont_sqr_core29(uint32_t out[9], const uint32_t A[9]) {
     out[k - 9] = k < 17 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
     acc >>= 29;
   }
+#endif
 }
 
 // THE Montgomery product of this library: 29-bit limbs (canonical in, canonical out, R = 2^256).

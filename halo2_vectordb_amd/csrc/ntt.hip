@@ -15,6 +15,8 @@
 //   ds_write_b128 both along rows and along columns.
 // Roofline: 64 B/element algorithmic HBM traffic per transform; the kernel is integer-ALU bound
 // (one 254-bit Montgomery product per butterfly), see DESIGN.md.
+#include <type_traits>
+
 #include "common.hpp"
 #include "limb9.hpp"
 
@@ -201,44 +203,58 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     const bool ren = (p.ren_mask >> step) & 1;
     if (s + 1 < S) {
       const uint32_t h2 = h >> 1;
-      for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
-        const uint32_t g = t >> (S - 2), gi = t & ((m >> 2) - 1);
-        const uint32_t r = gi & (h2 - 1), blk = gi >> (logh - 1);
-        const uint32_t j0 = g * row + (blk << (logh + 1)) + r;
-        L9 x0 = lds_get(D, j0), x1 = lds_get(D, j0 + h2), x2 = lds_get(D, j0 + h), x3 = lds_get(D, j0 + h + h2);
-        if (ren) {
-          l9_renorm(x0);
-          l9_renorm(x1);
-          l9_renorm(x2);
-          l9_renorm(x3);
+      // (the body is instantiated per (first step, carry pass) combination: a run-time `if (ren)` inside one body makes the
+      // compiler merge the two register sets with ~30 moves per step on the path that does not renormalise)
+      auto radix4 = [&](auto first_c, auto ren_c) {
+        constexpr bool FIRST = decltype(first_c)::value, REN = decltype(ren_c)::value;
+        for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
+          const uint32_t g = t >> (S - 2), gi = t & ((m >> 2) - 1);
+          const uint32_t r = gi & (h2 - 1), blk = gi >> (logh - 1);
+          const uint32_t j0 = g * row + (blk << (logh + 1)) + r;
+          L9 x0 = lds_get(D, j0), x1 = lds_get(D, j0 + h2), x2 = lds_get(D, j0 + h), x3 = lds_get(D, j0 + h + h2);
+          if (REN) {
+            l9_renorm(x0);
+            l9_renorm(x1);
+            l9_renorm(x2);
+            l9_renorm(x3);
+          }
+          if (FIRST) {
+            // stage 0: every twiddle is 1.  stage 1: block 0 has twiddle 1, block 1 has omega_4.
+            L9 a0 = l9_add(x0, x2), a2 = l9_sub(x0, x2, p.ckp);
+            L9 a1 = l9_add(x1, x3), a3 = l9_sub(x1, x3, p.ckp);
+            l9_carry(a1);  // a1 is subtracted below: its limbs must be below 2^29 again
+            const L9 t3 = l9_mul(a3, lds_get(W, m >> 2));
+            x0 = l9_add(a0, a1);
+            x1 = l9_sub(a0, a1, p.ckp);
+            x2 = l9_add(a2, t3);
+            x3 = l9_sub(a2, t3, p.ckp);
+          } else {
+            const uint32_t e = bitrev_s(blk, s) << logh;
+            const L9 w = lds_get(W, e);
+            const L9 t2 = l9_mul(x2, w), t3 = l9_mul(x3, w);
+            const L9 a0 = l9_add(x0, t2), a2 = l9_sub(x0, t2, p.ckp);
+            const L9 a1 = l9_add(x1, t3), a3 = l9_sub(x1, t3, p.ckp);
+            const L9 u1 = l9_mul(a1, lds_get(W, e >> 1));
+            const L9 u3 = l9_mul(a3, lds_get(W, (e >> 1) + (m >> 2)));
+            x0 = l9_add(a0, u1);
+            x1 = l9_sub(a0, u1, p.ckp);
+            x2 = l9_add(a2, u3);
+            x3 = l9_sub(a2, u3, p.ckp);
+          }
+          lds_put(D, j0, x0);
+          lds_put(D, j0 + h2, x1);
+          lds_put(D, j0 + h, x2);
+          lds_put(D, j0 + h + h2, x3);
         }
-        if (s == 0) {
-          // stage 0: every twiddle is 1.  stage 1: block 0 has twiddle 1, block 1 has omega_4.
-          L9 a0 = l9_add(x0, x2), a2 = l9_sub(x0, x2, p.ckp);
-          L9 a1 = l9_add(x1, x3), a3 = l9_sub(x1, x3, p.ckp);
-          l9_carry(a1);  // a1 is subtracted below: its limbs must be below 2^29 again
-          const L9 t3 = l9_mul(a3, lds_get(W, m >> 2));
-          x0 = l9_add(a0, a1);
-          x1 = l9_sub(a0, a1, p.ckp);
-          x2 = l9_add(a2, t3);
-          x3 = l9_sub(a2, t3, p.ckp);
-        } else {
-          const uint32_t e = bitrev_s(blk, s) << logh;
-          const L9 w = lds_get(W, e);
-          const L9 t2 = l9_mul(x2, w), t3 = l9_mul(x3, w);
-          const L9 a0 = l9_add(x0, t2), a2 = l9_sub(x0, t2, p.ckp);
-          const L9 a1 = l9_add(x1, t3), a3 = l9_sub(x1, t3, p.ckp);
-          const L9 u1 = l9_mul(a1, lds_get(W, e >> 1));
-          const L9 u3 = l9_mul(a3, lds_get(W, (e >> 1) + (m >> 2)));
-          x0 = l9_add(a0, u1);
-          x1 = l9_sub(a0, u1, p.ckp);
-          x2 = l9_add(a2, u3);
-          x3 = l9_sub(a2, u3, p.ckp);
-        }
-        lds_put(D, j0, x0);
-        lds_put(D, j0 + h2, x1);
-        lds_put(D, j0 + h, x2);
-        lds_put(D, j0 + h + h2, x3);
+      };
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      if (s == 0) {
+        if (ren) radix4(T_{}, T_{});
+        else radix4(T_{}, F_{});
+      } else {
+        if (ren) radix4(F_{}, T_{});
+        else radix4(F_{}, F_{});
       }
       s += 2;
     } else {

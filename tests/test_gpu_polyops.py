@@ -558,3 +558,44 @@ def test_prover_round_entry_points_reject_bad_arguments_and_accept_empty_batches
     z = api.permutation_product(cols, cols, 10, 5, one_fr, one_fr)
     assert z.shape[0] == 1
     buf.free()
+
+
+def test_gate_eval_on_the_sub_coset(api, O):
+    """vdb_gate_eval_sub_dev: the gates evaluated on the coset of 2 n points that lies inside the 4 n points the advice cosets were
+    made for, against selector cosets made for 2 n points — the same accumulator, bit for bit, as vdb_gate_eval_dev on cosets
+    that were all made for 2 n points; and divided by X^n - 1 there, the quotient's coefficients equal the ones the 4 n route
+    gives (the gate has degree 3: its quotient share has degree below 2 n) on a witness whose gates hold."""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    rng = np.random.default_rng(77)
+    k = 9
+    n = 1 << k
+    qa, qb = O.quantize(rng.uniform(-3, 3, (2, 5))), O.quantize(rng.uniform(-3, 3, (2, 5)))
+    w = api.wit_distance("manhattan", qa, qb, L=8, selectors=True)
+    bp = api.layout_plan(w["flags"], k)
+    cols, _ = api.layout_columns(w["stream"], bp, k)
+    n_cols = cols.shape[0]
+    y = O.random_fr(rng, 1)[0]
+    q, _, _, _, h4 = _gate_quotient(api, O, cols, w["flags"], len(w["stream"]), bp, k, 2, y)
+    adv_c, sel_c = api.lagrange_to_coeff(cols), api.lagrange_to_coeff(q)
+    adv4, adv2, sel2 = api.coeff_to_extended(adv_c, 2), api.coeff_to_extended(adv_c, 1), api.coeff_to_extended(sel_c, 1)
+    assert np.array_equal(adv4[:, ::2], adv2)            # the small coset is every second point of the large one
+    bufs = [api.DeviceBuffer(a.nbytes) for a in (adv4, adv2, sel2)]
+    for b, a in zip(bufs, (adv4, adv2, sel2)):
+        b.upload(a)
+    d_h1, d_h2 = api.DeviceBuffer(2 * n * 32), api.DeviceBuffer(2 * n * 32)
+    for d in (d_h1, d_h2):
+        check(lib.vdb_memset_dev(d.ptr, 0, 2 * n * 32))
+    check(lib.vdb_gate_eval_sub_dev(bufs[0].ptr, 2, bufs[2].ptr, ctypes.c_size_t(n_cols), k, 1, api._p(y), d_h1.ptr))
+    check(lib.vdb_gate_eval_dev(bufs[1].ptr, bufs[2].ptr, ctypes.c_size_t(n_cols), k, 1, api._p(y), d_h2.ptr))
+    api.sync()
+    assert np.array_equal(d_h1.download((2 * n, 4)), d_h2.download((2 * n, 4)))
+    check(lib.vdb_divide_by_vanishing_dev(d_h1.ptr, k, 1))
+    check(lib.vdb_extended_to_coeff_dev(d_h1.ptr, ctypes.c_size_t(1), k, 1))
+    api.sync()
+    h2 = d_h1.download((2 * n, 4))
+    assert np.array_equal(h2, h4[: 2 * n]) and not h4[2 * n:].any()
+    assert lib.vdb_gate_eval_sub_dev(bufs[0].ptr, 0, bufs[2].ptr, ctypes.c_size_t(n_cols), k, 1, api._p(y), d_h1.ptr) == -3     # VDB_ERR_ARG: adv_ext_k < ext_k
+    for b in bufs + [d_h1, d_h2]:
+        b.free()

@@ -6,6 +6,7 @@
 * `data/*.in` JSON: `{"a": [...], "b": [...]}` / `{"query": [...], "database": [[...], ...]}` style inputs of the
   examples (/root/reference/data, /root/reference/src/scaffold/cmd.rs) load with `json.load` as they are.
 """
+import json
 import struct
 
 import numpy as np
@@ -127,3 +128,40 @@ def read_snark(path):
     if len(data) != pos + m:
         raise ValueError("proof length does not match the file")
     return data[pos:], instances
+
+
+# ---------------------------------------------------------------- verifying key file (the reference writes data/{name}.vk, src/scaffold/mod.rs:276-281)
+VK_FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")
+
+
+def write_verifying_key(path, meta, fixed):
+    """meta: JSON-serialisable description of the circuit's shape (rounds.ProverRounds.save_verifying_key); fixed[name]: (n, 8) uint64
+    commitments.  An .npz without pickled objects (numpy appends the suffix when `path` lacks it; pass a name ending in .npz)."""
+    np.savez(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+             **{"fixed_" + name: np.ascontiguousarray(fixed[name], dtype=np.uint64).reshape(-1, 8) for name in VK_FIXED})
+
+
+def read_verifying_key(path):
+    """-> (meta dict with integers restored, {name: commitments}); raises ValueError on a malformed file"""
+    try:
+        with np.load(path, allow_pickle=False) as doc:
+            meta = json.loads(bytes(doc["meta"]).decode())
+            fixed = {name: np.ascontiguousarray(doc["fixed_" + name], dtype=np.uint64) for name in VK_FIXED}
+    except (KeyError, OSError, json.JSONDecodeError, UnicodeDecodeError) as e:
+        raise ValueError(f"not a verifying key of this build: {e}") from e
+    for name, c in fixed.items():
+        if c.ndim != 2 or c.shape[1] != 8:
+            raise ValueError("verifying key: wrong shape for " + name)
+    try:
+        for key in ("delta", "tau", "vk_digest"):
+            if key in meta:
+                meta[key] = int(meta[key])
+        meta["instance_pos"] = [tuple(int(x) for x in p) for p in meta["instance_pos"]]
+        if "opened" in meta:
+            meta["opened"] = {int(rot): list(names) for rot, names in meta["opened"].items()}
+        shape = (meta["n_adv"], meta["n_cols"] + 1, 1, 1, 3, len(meta["instance_pos"]))
+    except (KeyError, TypeError, ValueError) as e:
+        raise ValueError(f"verifying key: bad description: {e}") from e
+    if tuple(len(fixed[name]) for name in VK_FIXED) != shape:
+        raise ValueError("verifying key: the commitments do not match the described shape")
+    return meta, fixed

@@ -362,6 +362,20 @@ class ProverRounds:
         return self
 
     # ------------------------------------------------------------------ the proving key on disk
+    def save_verifying_key(self, path, opened=None):
+        """What the Keygen arm writes beside the proving key (src/scaffold/mod.rs:276-281: data/{name}.vk) in this build's own
+        container (upstream's is SerdeFormat::RawBytes of halo2's VerifyingKey: parity unpinned): the circuit's shape, the commitments
+        of the fixed polynomials in FIXED order, the transcript digest made of them, the SRS scalar of the deterministic "unsafe"
+        setup the reference's gen_srs uses (a verifier derives [tau]_2 from it; a ceremony SRS would carry the G2 point instead), and
+        — when a proof's `opened` map is given — which polynomial is opened at which rotation.  io.read_verifying_key reads it."""
+        from .io import write_verifying_key
+        meta = dict(rows=self.rows, k=self.k, n_adv=self.n_adv, n_lk=self.n_lk, n_cols=self.n_cols, n_sets=self.n_sets, chunk_len=CHUNK_LEN,
+                    n_blind=N_BLIND, delta=str(_fr_to_int(self.delta)), instance_pos=[list(p) for p in self.instance_pos], tau=str(self.hp.tau),
+                    vk_digest=str(_fr_to_int(self.vk_digest())))
+        if opened is not None:
+            meta["opened"] = {str(rot): list(names) for rot, names in opened.items()}
+        write_verifying_key(path, meta, {name: self.fixed[name].commits for name in FIXED})
+
     def save_proving_key(self, path):
         """What the reference's Keygen arm leaves for the Prove arm (src/scaffold/mod.rs:272-281: pinning + pk), in this
         build's own container: an .npz (numpy.load with allow_pickle=False reads it) holding the circuit's shape, the break

@@ -500,6 +500,12 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
     with tempfile.TemporaryDirectory() as d:
         write_snark(os.path.join(d, "kmeans.snark"), proof, out["instances"])
         proof_f, inst_f = read_snark(os.path.join(d, "kmeans.snark"))
+        # ... and the verifying-key file of the Keygen arm (ProverRounds.save_verifying_key / io.read_verifying_key): the pair of files
+        # is all the stand-alone verifier (tests/verify_file.py) is given
+        pr.save_verifying_key(os.path.join(d, "kmeans.snark.vk.npz"), opened=out["opened"])
+        import verify_file
+        rep = verify_file.main(os.path.join(d, "kmeans.snark"))
+        assert rep["accepted"] and not rep["tampered_byte_accepted"] and rep["columns"] == pr.n_cols
     assert proof_f == proof and _verify(O, api, proof_f, {**vk, "instances": inst_f})
     n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 4
     for where in (5, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 64 + 7, len(proof) - 20):    # a commitment, h, an evaluation, W1, W2

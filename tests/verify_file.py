@@ -15,20 +15,22 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+def _fr_int(O, v):
+    return int(O.fr_to_ints(v.reshape(1, 4))[0])
+
+
 def main(proof_path, vk_path=None):
     from halo2_vectordb_amd import api
-    from halo2_vectordb_amd.io import read_snark
+    from halo2_vectordb_amd.io import read_snark, read_verifying_key
     from oracle import oracle as O
     from oracle import pairing as PR
-    from test_gpu_rounds import FIXED, _verify
+    from test_gpu_rounds import _verify, _vk_digest
     proof, instances = read_snark(proof_path)
-    with np.load(vk_path or proof_path + ".vk.npz", allow_pickle=False) as doc:
-        meta = json.loads(bytes(doc["meta"]).decode())
-        fixed = {name: np.ascontiguousarray(doc["fixed_" + name]) for name in FIXED}
-    meta["delta"] = int(meta["delta"])
-    meta["instance_pos"] = [tuple(p) for p in meta["instance_pos"]]
-    opened = {int(rot): names for rot, names in meta.pop("opened").items()}
-    tau = int(meta.pop("tau"))
+    meta, fixed = read_verifying_key(vk_path or proof_path + ".vk.npz")
+    opened = meta.pop("opened")
+    tau = meta.pop("tau")
+    digest = meta.pop("vk_digest")
+    assert _fr_int(O, _vk_digest(api, fixed)) == digest, "the key's digest is not the digest of its commitments"
     vk = dict(meta=meta, opened=opened, fixed=fixed, tau_h=PR.pt_mul(PR.G2, tau), instances=instances)
     t0 = time.time()
     ok = _verify(O, api, proof, vk)

@@ -54,14 +54,9 @@ identity = quotient_identity_holds(pr, out["challenges"], out["evals"], out["ins
 if proof_path:
     # the proof (public inputs + proof bytes) and what a verifier holds: the circuit's shape, the fixed commitments, which polynomial
     # is opened where (tests/verify_file.py checks the pair on the CPU: transcript replay, quotient identity, pairing equation)
-    import numpy as np
     from halo2_vectordb_amd.io import write_snark
-    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND, _fr_to_int
     write_snark(proof_path, out["proof"], out["instances"])
-    meta = dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=CHUNK_LEN, n_blind=N_BLIND,
-                delta=str(_fr_to_int(pr.delta)), instance_pos=list(pr.instance_pos), tau=str(hp.tau),
-                opened={str(rot): names for rot, names in out["opened"].items()})
-    np.savez(proof_path + ".vk.npz", meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **{"fixed_" + name: q.commits for name, q in pr.fixed.items()})
+    pr.save_verifying_key(proof_path + ".vk.npz", opened=out["opened"])
 cells = hp.n_cells + hp.n_lookup
 free, total = api.mem_info()
 print(json.dumps({"workload": f"kmeans K=4 I={I} 256x128 k=16 {metric}, whole constraint map, transcript, fresh blinds",

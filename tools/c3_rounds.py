@@ -1,22 +1,40 @@
-import sys, time, json, numpy as np
+#!/usr/bin/env python3
+"""BASELINE C3 (merkle_commitment over 1,024 x 128 vectors, 2^15 rows) as a whole proof: the Poseidon trace's constraint map in the
+permutation argument, fresh blinds, Fiat-Shamir transcript; wall time of untimed proofs, device time per stage of an instrumented one."""
+import json
+import sys
+import time
+
+import numpy as np
+
 sys.path.insert(0, ".")
 from halo2_vectordb_amd import api
 from halo2_vectordb_amd.pipeline import MerkleHotPath
 from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+
 api.init(0)
 t0 = time.time()
 hp = MerkleHotPath(n=1024, dim=128, k=15).setup()
 t1 = time.time()
 pr = ProverRounds(hp).keygen()
 t2 = time.time()
-tied = int((pr.copy_of != np.arange(pr.copy_of.size)).sum())
+tied = int((pr.circuit.copy_of != np.arange(pr.circuit.n_cells)).sum())
+pr.prove(None)
+best = None
+for _ in range(2):
+    t3 = time.time()
+    out = pr.prove(None)
+    wall = (time.time() - t3) * 1e3
+    if best is None or wall < best[0]:
+        best = (wall, dict(pr.host_ms), out)
+wall, host_ms, out = best
 T = {}
-out = pr.prove(None, seed=1, timings=T)
-T = {}
-t3 = time.time()
-out = pr.prove(None, seed=1, timings=T)
-wall = (time.time() - t3) * 1e3
+pr.prove(None, timings=T)
 ok = quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
-print(json.dumps({"workload": "merkle_commitment 1024x128 k=15 (BASELINE C3) with its full copy map and the constants gate", "cells": hp.n_cells, "columns": hp.n_cols,
-                  "tied_cells": tied, "setup_s": round(t1 - t0, 1), "keygen_s": round(t2 - t1, 1), "quotient_identity_at_x_holds": bool(ok), "proof_bytes": len(out["proof"]),
-                  "wall_ms": round(wall, 1), "device_ms": {k: round(v, 2) for k, v in T.items()}, "device_ms_total": round(sum(T.values()), 1)}))
+print(json.dumps({"workload": "merkle_commitment 1024x128 k=15 (BASELINE C3), whole constraint map, transcript, fresh blinds", "cells": hp.n_cells, "columns": hp.n_cols,
+                  "copies": tied, "mock_report_on_keygen_witness": pr.keygen_report.as_dict(), "setup_s": round(t1 - t0, 1), "keygen_s": round(t2 - t1, 1),
+                  "quotient_identity_at_x_holds": bool(ok), "proof_bytes": len(out["proof"]), "proof_wall_ms": round(wall, 1),
+                  "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": {k: round(v, 2) for k, v in T.items()},
+                  "device_ms_total": round(sum(T.values()), 1)}))
+pr.free()
+hp.free()

@@ -365,6 +365,26 @@ __global__ __launch_bounds__(256) void k_perm_sigma(const uint64_t* __restrict__
   }
   st256(sigma + i, fr_mul(ld256(dpow + c), ld256(wpow + r)));
 }
+// The same from the packed mapping (c' << k | row' in 32 bits) for a block of columns: what the prover's product round reads per proof
+// — one product per cell instead of a transform per sigma column.
+__global__ __launch_bounds__(256) void k_perm_map_pack(const uint64_t* __restrict__ map, uint64_t cells, uint32_t k, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const uint64_t m = map[i];
+  out[i] = (uint32_t)((m >> 32) << k) | (uint32_t)(m & 0xffffffffull);
+}
+__global__ __launch_bounds__(256) void k_perm_sigma_packed(const uint32_t* __restrict__ map, uint64_t cells, uint64_t n_cols_total, uint32_t k,
+                                                           const u256* __restrict__ wpow, const u256* __restrict__ dpow, u256* __restrict__ sigma,
+                                                           int* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const uint32_t m = map[i], c = m >> k, r = m & ((1u << k) - 1u);
+  if (c >= n_cols_total) {
+    *err = 1;
+    return;
+  }
+  st256(sigma + i, fr_mul(ld256(dpow + c), ld256(wpow + r)));
+}
 // One thread per (row, chunk of columns):  num = prod_c (v_c + delta^c * beta * omega^row + gamma),
 //                                          den = prod_c (v_c + beta * sigma_c[row] + gamma).
 __global__ __launch_bounds__(256) void k_perm_terms(const u256* __restrict__ cols, const u256* __restrict__ sigma, uint64_t n_cols, uint64_t n, uint64_t rows,
@@ -771,6 +791,51 @@ int vdb_permutation_sigma_dev(const uint64_t* mapping_dev, size_t n_cols, uint32
   VDB_HIP(hipStreamSynchronize(cx.stream));
   if (herr) {
     set_error("permutation mapping points outside the columns");
+    return VDB_ERR_ARG;
+  }
+  return VDB_OK;
+}
+
+int vdb_permutation_mapping_pack_dev(const uint64_t* mapping_dev, size_t n_cols, uint32_t k, uint32_t* packed_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(mapping_dev && packed_dev && k <= 28, "bad argument");
+  uint32_t col_bits = 0;
+  while (((uint64_t)1 << col_bits) < n_cols) col_bits++;
+  VDB_ARG(col_bits + k <= 32, "column and row of a cell do not fit 32 bits together");
+  if (n_cols == 0) return VDB_OK;
+  const uint64_t cells = (uint64_t)n_cols << k;
+  hipLaunchKernelGGL(k_perm_map_pack, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx().stream, mapping_dev, cells, k, packed_dev);
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_permutation_sigma_packed_dev(const uint32_t* packed_block_dev, size_t n_block_cols, size_t n_cols_total, uint32_t k, const vdb_fr* delta,
+                                     vdb_fr* sigma_block_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(packed_block_dev && delta && sigma_block_dev && k <= 28 && n_block_cols <= n_cols_total, "bad argument");
+  if (n_block_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  const uint64_t n = 1ull << k;
+  u256 dv;
+  memcpy(&dv, delta, 32);
+  u256* buf = (u256*)scratch_get(5, (n + n_cols_total + 1) * sizeof(u256));
+  if (!buf) return VDB_ERR_OOM;
+  u256 *wpow = buf, *dpow = buf + n;
+  int* derr = (int*)(buf + n + n_cols_total);
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), cx.stream));
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k), mont_one<Fr>(), n, wpow);
+  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((n_cols_total + 255) / 256)), dim3(256), 0, cx.stream, dv, mont_one<Fr>(), (uint64_t)n_cols_total, dpow);
+  const uint64_t cells = (uint64_t)n_block_cols << k;
+  {
+    VDB_PROF("k_perm_sigma");
+    hipLaunchKernelGGL(k_perm_sigma_packed, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, cx.stream, packed_block_dev, cells, (uint64_t)n_cols_total, k, wpow,
+                       dpow, as_u256(sigma_block_dev), derr);
+  }
+  VDB_LAUNCH_CHECK();
+  int herr = 0;
+  VDB_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  if (herr) {
+    set_error("packed permutation mapping points outside the columns");
     return VDB_ERR_ARG;
   }
   return VDB_OK;

@@ -111,6 +111,7 @@ class ProverRounds:
         self.delta = api.fr_delta()
         self.fixed = {}
         self._vk_digest = None
+        self.d_map32 = None
 
     # ------------------------------------------------------------------ helpers on device-resident columns
     def _to_coeff(self, lag_buf, n_cols):
@@ -256,6 +257,13 @@ class ProverRounds:
         self._d_map_for_tests = d_map if getattr(self, "keep_mapping", False) else None
         d_sigma = api.DeviceBuffer(self.n_perm * rows * B)
         _chk(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_perm), k, api._p(self.delta), d_sigma.ptr))
+        # the mapping stays with the key in 32 bits per cell when column and row fit: the product round makes the sigma columns'
+        # Lagrange form from it (one product per cell) instead of transforming their coefficient form back
+        self.d_map32 = None
+        if max(self.n_perm - 1, 1).bit_length() + k <= 32 and getattr(self, "keep_packed_mapping", True):
+            self.d_map32 = api.DeviceBuffer(self.n_perm * rows * 4)
+            _chk(lib.vdb_permutation_mapping_pack_dev(d_map.ptr, _sz(self.n_perm), k, self.d_map32.ptr))
+            api.sync()
         if self._d_map_for_tests is None:
             d_map.free()
         self._fixed_poly("sigma", d_sigma, self.n_perm, keep_lag=False, keep_ext=False)
@@ -559,8 +567,11 @@ class ProverRounds:
             for c0 in range(0, n_perm, blk):
                 nb = min(blk, n_perm - c0)
                 lagrange_block(c0, nb, d_lag_a)
-                check(lib.vdb_memcpy_d2d(d_lag_s.ptr, fx["sigma"].coeff.at(c0 * rows * B), _sz(nb * rows * B)))
-                check(lib.vdb_ntt_batch_dev(d_lag_s.ptr, _sz(nb), k, api._p(omega), 0))
+                if self.d_map32 is not None:
+                    check(lib.vdb_permutation_sigma_packed_dev(self.d_map32.at(c0 * rows * 4), _sz(nb), _sz(n_perm), k, api._p(self.delta), d_lag_s.ptr))
+                else:                                      # a key loaded from a file: back from the coefficient form
+                    check(lib.vdb_memcpy_d2d(d_lag_s.ptr, fx["sigma"].coeff.at(c0 * rows * B), _sz(nb * rows * B)))
+                    check(lib.vdb_ntt_batch_dev(d_lag_s.ptr, _sz(nb), k, api._p(omega), 0))
                 check(lib.vdb_permutation_product_range_dev(d_lag_a.ptr, d_lag_s.ptr, _sz(nb), _sz(c0), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
                                                             api._p(self.delta), d_zp.at(c0 // CHUNK_LEN * rows * B)))
             check(lib.vdb_permutation_chain_dev(d_zp.ptr, _sz(n_sets), k, _sz(usable)))
@@ -850,7 +861,7 @@ class ProverRounds:
             q.free()
         self.fixed = {}
         self._vk_digest = None
-        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot"):
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

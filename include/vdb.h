@@ -297,6 +297,14 @@ int vdb_fr_delta(vdb_fr *out);
  * delta^c' omega^row' for the cell (c', row') that the copy-constraint permutation sends (c, row) to;
  * mapping_dev: n_cols x 2^k words c' << 32 | row' (the identity where a cell is unconstrained). */
 int vdb_permutation_sigma_dev(const uint64_t *mapping_dev, size_t n_cols, uint32_t k, const vdb_fr *delta, vdb_fr *sigma_dev);
+/* The mapping kept with the proving key in 32 bits per cell (c' << k | row'; VDB_ERR_ARG when column and row do not fit), and the
+ * sigma columns of a block of columns in Lagrange form straight from it: halo2's ProvingKey holds the permutation polynomials in
+ * Lagrange, coefficient and coset form (plonk/permutation.rs ProvingKey: permutations, polys, cosets); here the coefficient form
+ * is held, the cosets are made per block in the quotient, and the Lagrange form the product round reads costs one product per
+ * cell from these 4 bytes instead of a forward transform per column.  packed_block_dev: the block's n_block_cols x 2^k words. */
+int vdb_permutation_mapping_pack_dev(const uint64_t *mapping_dev, size_t n_cols, uint32_t k, uint32_t *packed_dev);
+int vdb_permutation_sigma_packed_dev(const uint32_t *packed_block_dev, size_t n_block_cols, size_t n_cols_total, uint32_t k, const vdb_fr *delta,
+                                     vdb_fr *sigma_block_dev);
 /* prover side (plonk/permutation/prover.rs commit): the columns are taken in chunks of chunk_len (= constraint degree - 2);
  * per chunk one product column z with z[i + 1] = z[i] prod_c (v_c[i] + beta delta^c omega^i + gamma) / (v_c[i] + beta
  * sigma_c[i] + gamma) over the chunk's columns c, i < usable_rows; chunk j starts from the value chunk j - 1 ended on

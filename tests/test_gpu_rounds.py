@@ -695,3 +695,35 @@ def test_rounds_on_a_nearest_vector_circuit(O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_sigma_columns_from_the_packed_mapping(circuit, O):
+    """The product round reads the sigma columns in Lagrange form: made from the 32-bit packed mapping kept with the key (one product per
+    cell), they equal the forward transform of the coefficient form the key holds, and a proof made with a key that does not hold the
+    mapping (the file-loaded case: transform route) has the same bytes."""
+    import ctypes
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd._lib import check
+    hp, pr = circuit
+    lib, rows, k, B = pr.lib, pr.rows, pr.k, 32
+    assert pr.d_map32 is not None
+    c0, nb = 1, min(4, pr.n_perm - 1)
+    d_a, d_b = api.DeviceBuffer(nb * rows * B), api.DeviceBuffer(nb * rows * B)
+    check(lib.vdb_permutation_sigma_packed_dev(pr.d_map32.at(c0 * rows * 4), ctypes.c_size_t(nb), ctypes.c_size_t(pr.n_perm), k, api._p(pr.delta), d_a.ptr))
+    check(lib.vdb_memcpy_d2d(d_b.ptr, pr.fixed["sigma"].coeff.at(c0 * rows * B), ctypes.c_size_t(nb * rows * B)))
+    check(lib.vdb_ntt_batch_dev(d_b.ptr, ctypes.c_size_t(nb), k, api._p(api.root_of_unity(k)), 0))
+    api.sync()
+    assert np.array_equal(d_a.download((nb, rows, 4)), d_b.download((nb, rows, 4)))
+    for d in (d_a, d_b):
+        d.free()
+    with_map = pr.prove(None, seed=77)["proof"]
+    held, pr.d_map32 = pr.d_map32, None
+    try:
+        without = pr.prove(None, seed=77)["proof"]
+    finally:
+        pr.d_map32 = held
+    assert with_map == without
+    # a mapping whose columns and rows do not fit 32 bits together is refused
+    d = api.DeviceBuffer(64)
+    assert lib.vdb_permutation_mapping_pack_dev(d.ptr, ctypes.c_size_t(1 << 20), 16, d.ptr) == -3
+    d.free()

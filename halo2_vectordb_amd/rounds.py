@@ -503,7 +503,9 @@ class ProverRounds:
         squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, commits=adv_commits)
         n_perm = self.n_perm
-        polys = {"adv": adv}
+        # the gate columns once more as a group of their own: only they are read at rows 1..3 (halo2 opens a column at the rotations
+        # its queries name — the lookup columns only at the current row)
+        polys = {"adv": adv, "advg": _Poly("advg", n_adv, coeff=hp.d_cols, commits=adv_commits[:n_adv])}
         # Everything below works on blocks of `blk` columns: the Lagrange forms, the sigma columns and every extended coset
         # exist one block at a time (the advice cosets too, unless the hot path keeps them resident); what stays in HBM is the
         # streams, the coefficient forms and the derived columns.
@@ -678,7 +680,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["adv", "zp", "zl"], 2: ["adv"], 3: ["adv"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
@@ -881,7 +883,7 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     delta, n, n_adv = _fr_to_int(pr.delta), pr.rows, pr.n_adv
     ev = lambda name, rot=0: evals.get((name, rot), [])
     acc = 0
-    a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
+    a0, a1, a2, a3, q = ev("adv"), ev("advg", 1), ev("advg", 2), ev("advg", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
     for l_i, (col, _row), value in zip(ev("inst"), pr.instance_pos, instances if instances is not None else []):

@@ -60,7 +60,7 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
     delta, n, n_adv, chunk, n_blind = meta["delta"], meta["rows"], meta["n_adv"], meta["chunk_len"], meta["n_blind"]
     ev = lambda name, rot=0: evals.get((name, rot), [])
     acc = 0
-    a0, a1, a2, a3, q = ev("adv"), ev("adv", 1), ev("adv", 2), ev("adv", 3), ev("sel")
+    a0, a1, a2, a3, q = ev("adv"), ev("advg", 1), ev("advg", 2), ev("advg", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
     assert len(instances) == len(meta["instance_pos"])
@@ -160,7 +160,7 @@ def test_every_opening_verifies_in_the_exponent(circuit, proved, O):
         assert comb == O.fr_to_ints(op["eval"].reshape(1, 4))[0]
     assert check_openings(O, v, out["commitments"], out["evals"], out["openings"])
     bad = dict(out["evals"])
-    bad[("adv", 2)] = [(e + 1) % O.R_MOD for e in bad[("adv", 2)]]
+    bad[("advg", 2)] = [(e + 1) % O.R_MOD for e in bad[("advg", 2)]]
     assert not check_openings(O, v, out["commitments"], bad, out["openings"])
 
 
@@ -196,7 +196,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
@@ -217,6 +217,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
             tr.common_point(pt)
         return pts
     commitments["adv"] = absorb(take_points(counts["adv"]))
+    commitments["advg"] = commitments["adv"][: meta["n_adv"]]          # the gate columns, opened at rows 1..3 as a group of their own
     ch = {"theta": tr.squeeze()}
     pairs = absorb(take_points(2 * meta["n_lk"]))
     commitments["pa"], commitments["ps"] = pairs[0::2], pairs[1::2]
@@ -308,7 +309,7 @@ def test_shplonk_multiopen_verifies_in_the_exponent(circuit, O):
     pts = out["points"]
     sets = op["sets"]
     m = len(sets)
-    assert sorted(len(rots) for rots, _ in sets) == [1, 2, 2, 3, 4]     # fixed & h; pa; zl; zp; advice
+    assert sorted(len(rots) for rots, _ in sets) == [1, 2, 2, 3, 3]     # fixed, h & every advice column at x; pa; zl; zp; the gate columns at rows 1..3
     all_rots = sorted({rot for rots, _ in sets for rot in rots})
     def vanish(rots, x):
         acc = 1
@@ -383,7 +384,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     pos = 0
     tr = api.Transcript()
@@ -406,6 +407,7 @@ def _verify(O, api, proof, vk):
             tr.common_scalar(O.fr_from_ints([value])[0])
         C = dict(vk["fixed"])
         C["adv"] = points(counts["adv"])
+        C["advg"] = C["adv"][: meta["n_adv"]]              # the gate columns, opened at rows 1..3 as a group of their own
         ch = {"theta": tr.squeeze()}
         pairs = points(2 * meta["n_lk"])
         C["pa"], C["ps"] = pairs[0::2], pairs[1::2]

@@ -592,7 +592,11 @@ class ProverRounds:
         # beside the lookup products' commitments.
         polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
         stage("commit_products", lambda: self._commit_begin(d_zl, n_lk, 1))
-        write_points(polys["zp"].commits)
+        try:
+            write_points(polys["zp"].commits)
+        except Exception:
+            lib.vdb_msm_batch_end(None, _sz(0))       # a deferred MSM must always be collected, or every later MSM is refused
+            raise
         polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit_end(n_lk)))
         stage("derived_ntt", lambda: derived_forms(("pa", "ps", "zp", "zl")))
         write_points(polys["zl"].commits)

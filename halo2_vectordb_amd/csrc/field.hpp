@@ -323,6 +323,50 @@ HD void mont_core29_2(uint32_t out[9], const uint32_t A1[9], const uint32_t B1[9
 #endif
 }
 
+// Product with a CONSTANT w (an NTT stage twiddle) whose quotient w' = floor(w 2^261 / p) was computed once: t = w v - q p with
+// q = floor(w' v / 2^261) taken from the columns 7 .. 17 of w' v — at most two below floor(w v / p) (one for w', one for the dropped
+// columns: their sum stays below 2^238 when v's limbs stay below 6.1 * 2^29) — and t from the low nine columns of
+// w v + q (2^261 - p): exact, because 0 <= t < 3 p < 2^261.  143 multiply-adds and no chain of reduction digits against the
+// Montgomery core's 162 + 9; 179 instructions as one asm statement.  V: limbs below 6.1 * 2^29, value below 2^261; W, WQ normalised.
+// The result has exactly normalised limbs and is below 3 p; no factor 2^-261 (w is the plain residue, not a Montgomery form).
+template <class M>
+HD void shoup_core29(uint32_t out[9], const uint32_t V[9], const uint32_t W[9], const uint32_t WQ[9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t q[9];
+  asm(
+#include "core29_shoup.inc"
+      : VDB_CORE29_OUT(out), VDB_CORE29_OUT(q)
+      : VDB_CORE29_IN(V), VDB_CORE29_IN(W), VDB_CORE29_IN(WQ), "s"((0x20000000u) - M::P29[0]), "s"(0x1fffffffu - M::P29[1]), "s"(0x1fffffffu - M::P29[2]),
+        "s"(0x1fffffffu - M::P29[3]), "s"(0x1fffffffu - M::P29[4]), "s"(0x1fffffffu - M::P29[5]), "s"(0x1fffffffu - M::P29[6]), "s"(0x1fffffffu - M::P29[7]),
+        "s"(0x1fffffffu - M::P29[8])
+      : VDB_CORE29_CLOBBER);
+#else
+  constexpr uint32_t MASK = 0x1fffffffu;
+  uint32_t q[9], NP[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) NP[k] = (k == 0 ? 0x20000000u : 0x1fffffffu) - M::P29[k];  // limbs of 2^261 - p (P29[0] != 0)
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 7; k < 18; k++) {
+#pragma unroll
+    for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) mad64(acc, WQ[i], V[k - i]);
+    if (k >= 9) q[k - 9] = k < 17 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
+    acc >>= 29;
+  }
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      mad64(acc, W[i], V[k - i]);
+      mad64(acc, q[i], NP[k - i]);
+    }
+    out[k] = (uint32_t)acc & MASK;
+    acc >>= 29;
+  }
+#endif
+}
+
 // Squaring variant: the 36 off-diagonal products are taken once against the doubled operand (45 multiply-adds instead
 // of 81 for the product half).  A: limbs below 2^29 + 8 (normalised) so that a doubled column still fits 64 bits.
 template <class M>

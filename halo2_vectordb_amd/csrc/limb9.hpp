@@ -103,6 +103,13 @@ HD L9 l9_mul(const L9& a, const L9& b) {
   mont_core29<M>(r.l, a.l, b.l);
   return r;
 }
+// w * v mod p (below 3 p, exactly normalised limbs) for a constant w given as its plain residue with wq = floor(w 2^261 / p)
+template <class M>
+HD L9 l9_mul_shoup(const L9& v, const L9& w, const L9& wq) {
+  L9 r;
+  shoup_core29<M>(r.l, v.l, w.l, wq.l);
+  return r;
+}
 // (a1 * b1 + a2 * b2) / 2^261 (+ less than p) with one reduction; limbs of a1 and a2 together below 6 * 2^29
 template <class M>
 HD L9 l9_mul2(const L9& a1, const L9& b1, const L9& a2, const L9& b2) {

@@ -16,6 +16,7 @@
 // Roofline: 64 B/element algorithmic HBM traffic per transform; the kernel is integer-ALU bound
 // (one 254-bit Montgomery product per butterfly), see DESIGN.md.
 #include <type_traits>
+#include <vector>
 
 #include "common.hpp"
 #include "limb9.hpp"
@@ -47,6 +48,11 @@ struct NttPass {
                                   // twiddles and stage twiddles are L2 hits for every column after the first on an XCD
   u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery (zeta^-1 = zeta^2: the same two serve coset_out)
   uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
+  // Shoup products for the stage twiddles (shoup_core29, field.hpp): per twiddle index e that is a multiple of 2^sh_res_log the
+  // plain residue of omega_m^e and its quotient floor(omega_m^e 2^261 / r), 2 x 9 limbs; null: every product is a Montgomery product
+  const uint32_t* sh_tab;
+  uint32_t sh_res_log, sh_ns;     // resolution and number of entries (m / 2 >> sh_res_log)
+  int32_t sh_max_s;               // radix-4 steps starting at stage s <= sh_max_s find both their stages' twiddles in the table
 };
 
 __device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -113,8 +119,16 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   D.b = D.a + NE;
   W.a = D.b + NE;
   W.b = W.a + NW;
-  D.c = reinterpret_cast<uint32_t*>(W.b + NW);
+  const uint32_t NS = p.sh_tab ? p.sh_ns : 0;
+  L9Planes WS, WQ;
+  WS.a = W.b + NW;
+  WS.b = WS.a + NS;
+  WQ.a = WS.b + NS;
+  WQ.b = WQ.a + NS;
+  D.c = reinterpret_cast<uint32_t*>(WQ.b + NS);
   W.c = D.c + NE;
+  WS.c = W.c + NW;
+  WQ.c = WS.c + NS;
   const uint32_t tid = threadIdx.x;
   uint32_t col, tile;
   if (p.col_group == 0) {
@@ -162,6 +176,16 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
 
   // stage twiddles 32 * omega_m^e = tw[e * n/m], as limbs
   for (uint32_t e = tid; e < m / 2; e += NTT_THREADS) lds_put(W, e, l9_split(ld256(tw + ((size_t)e << (p.log_n - S)))));
+  for (uint32_t e = tid; e < NS; e += NTT_THREADS) {
+    L9 ws, wq;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      ws.l[k] = p.sh_tab[18 * e + k];
+      wq.l[k] = p.sh_tab[18 * e + 9 + k];
+    }
+    lds_put(WS, e, ws);
+    lds_put(WQ, e, wq);
+  }
   // load tile.  With s0 == 2 only the first quarter of every row is data; the two skipped stages would just copy
   // it into the other three quarters.
   const uint32_t mload = m >> p.s0, Tload = mload * G;
@@ -205,8 +229,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       const uint32_t h2 = h >> 1;
       // (the body is instantiated per (first step, carry pass) combination: a run-time `if (ren)` inside one body makes the
       // compiler merge the two register sets with ~30 moves per step on the path that does not renormalise)
-      auto radix4 = [&](auto first_c, auto ren_c) {
-        constexpr bool FIRST = decltype(first_c)::value, REN = decltype(ren_c)::value;
+      auto radix4 = [&](auto first_c, auto ren_c, auto shoup_c) {
+        constexpr bool FIRST = decltype(first_c)::value, REN = decltype(ren_c)::value, SHOUP = decltype(shoup_c)::value;
         for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
           const uint32_t g = t >> (S - 2), gi = t & ((m >> 2) - 1);
           const uint32_t r = gi & (h2 - 1), blk = gi >> (logh - 1);
@@ -228,6 +252,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
             x1 = l9_sub(a0, a1, p.ckp);
             x2 = l9_add(a2, t3);
             x3 = l9_sub(a2, t3, p.ckp);
+          } else if (SHOUP) {
+            // both stages' twiddles lie in the quarter- (or full-) resolution table of plain residues and quotients: the products
+            // come out below 3 r with normalised limbs, which is all the sums and differences below ask of them
+            const uint32_t e = bitrev_s(blk, s) << logh, rl = p.sh_res_log;
+            const uint32_t i0 = e >> rl, i1 = (e >> 1) >> rl, i2 = ((e >> 1) + (m >> 2)) >> rl;
+            const L9 ws = lds_get(WS, i0), wq = lds_get(WQ, i0);
+            const L9 t2 = l9_mul_shoup<Fr>(x2, ws, wq), t3 = l9_mul_shoup<Fr>(x3, ws, wq);
+            const L9 a0 = l9_add(x0, t2), a2 = l9_sub(x0, t2, p.ckp);
+            const L9 a1 = l9_add(x1, t3), a3 = l9_sub(x1, t3, p.ckp);
+            const L9 u1 = l9_mul_shoup<Fr>(a1, lds_get(WS, i1), lds_get(WQ, i1));
+            const L9 u3 = l9_mul_shoup<Fr>(a3, lds_get(WS, i2), lds_get(WQ, i2));
+            x0 = l9_add(a0, u1);
+            x1 = l9_sub(a0, u1, p.ckp);
+            x2 = l9_add(a2, u3);
+            x3 = l9_sub(a2, u3, p.ckp);
           } else {
             const uint32_t e = bitrev_s(blk, s) << logh;
             const L9 w = lds_get(W, e);
@@ -250,11 +289,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       using T_ = std::true_type;
       using F_ = std::false_type;
       if (s == 0) {
-        if (ren) radix4(T_{}, T_{});
-        else radix4(T_{}, F_{});
+        if (ren) radix4(T_{}, T_{}, F_{});
+        else radix4(T_{}, F_{}, F_{});
+      } else if (p.sh_tab && (int32_t)s <= p.sh_max_s) {
+        if (ren) radix4(F_{}, T_{}, T_{});
+        else radix4(F_{}, F_{}, T_{});
       } else {
-        if (ren) radix4(F_{}, T_{});
-        else radix4(F_{}, F_{});
+        if (ren) radix4(F_{}, T_{}, F_{});
+        else radix4(F_{}, F_{}, F_{});
       }
       s += 2;
     } else {
@@ -382,6 +424,62 @@ static const u256* get_twiddles(uint32_t log_n, const u256& omega, const u256& f
   return tw;
 }
 
+// Shoup table of one pass size (see NttPass::sh_tab): entry j holds, for e = j << res_log, the plain residue of
+// omega_m^e = omega^(e n / m) and floor(that * 2^261 / r), nine 29-bit limbs each.  Built on the host (a few hundred entries, a
+// 261-step long division each), cached per device beside the twiddle tables.
+static void limbs29(const u256& a, uint32_t extra_top /* bits 256.. */, uint32_t out[9]) {
+  for (int k = 0; k < 9; k++) {
+    const int bit = 29 * k, wd = bit >> 5, sh = bit & 31;
+    uint64_t v = wd < 8 ? (uint64_t)a.w[wd] >> sh : 0;
+    if (sh && wd + 1 < 8) v |= (uint64_t)a.w[wd + 1] << (32 - sh);
+    if (wd + 1 == 8 && sh) v |= (uint64_t)extra_top << (32 - sh);
+    if (wd == 8) v = extra_top >> sh;
+    out[k] = (uint32_t)v & 0x1fffffffu;
+  }
+}
+static const uint32_t* get_shoup_table(uint32_t log_n, const u256& omega, uint32_t S, uint32_t res_log, int* err) {
+  Context& c = ctx();
+  Context::TwKey key{log_n | (S << 8) | (res_log << 16) | 0x40000000u, omega};
+  auto it = c.twiddles.find(key);
+  if (it != c.twiddles.end()) return reinterpret_cast<const uint32_t*>(it->second);
+  const uint32_t m = 1u << S, ns = (m / 2) >> res_log;
+  std::vector<uint32_t> tab((size_t)ns * 18);
+  const u256 p = mod_p<Fr>();
+  const u256 step = mont_pow<Fr>(omega, u256_from_u64(((uint64_t)1 << (log_n - S)) << res_log));  // omega_m^(2^res_log)
+  u256 cur = mont_one<Fr>();
+  for (uint32_t j = 0; j < ns; j++) {
+    const u256 w = from_mont<Fr>(cur);
+    limbs29(w, 0, &tab[18 * (size_t)j]);
+    // q = floor(w 2^261 / p): r starts at w (< p) and takes 261 doubling steps; r stays below 2 p < 2^255 before each reduction
+    u256 r = w;
+    uint32_t q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 260; b >= 0; b--) {
+      u256 d;
+      u256_add(d, r, r);
+      u256 t;
+      const uint32_t borrow = u256_sub(t, d, p);
+      r = borrow ? d : t;
+      if (!borrow) q[b / 29] |= 1u << (b % 29);
+    }
+    for (int k = 0; k < 9; k++) tab[18 * (size_t)j + 9 + k] = q[k];
+    cur = fr_mul(cur, step);
+  }
+  uint32_t* d = nullptr;
+  hipError_t e = hipMalloc(&d, tab.size() * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    *err = hip_fail(e, "hipMalloc(shoup table)", __FILE__, __LINE__);
+    return nullptr;
+  }
+  e = hipMemcpy(d, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    *err = hip_fail(e, "hipMemcpy(shoup table)", __FILE__, __LINE__);
+    (void)hipFree(d);
+    return nullptr;
+  }
+  c.twiddles[key] = reinterpret_cast<u256*>(d);
+  return d;
+}
+
 // Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
 // result goes to out (stride n) or back into data when out == nullptr.
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
@@ -432,6 +530,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
   z1 = fr_mul(z1, m32);
   z2 = fr_mul(z2, m32);
+  static const bool shoup_on = !(getenv("VDB_NTT_SHOUP") && getenv("VDB_NTT_SHOUP")[0] == '0');
   // 14 r with limbs that dominate a normalised subtrahend (l9_sub)
   uint32_t ckp[9];
   const double cmax = l9_offset_limbs<FrParams>(14, ckp);
@@ -536,6 +635,25 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       uint32_t G = 1u << p.logG;
       uint32_t tiles = (uint32_t)(n / ((uint64_t)m * G));
       size_t lds = (size_t)(G * (m + 1) + (m / 2 ? m / 2 : 1)) * (2 * sizeof(uint4) + sizeof(uint32_t));
+      // Shoup table in what is left of a third of the CU's LDS (three workgroups per CU stay resident): full resolution for the
+      // 256-point passes, a quarter for the 512-point ones; passes too small to have a general radix-4 step do without
+      p.sh_tab = nullptr;
+      p.sh_res_log = p.sh_ns = 0;
+      p.sh_max_s = -1;
+      if (shoup_on && S[l] >= 4) {
+        const size_t room = (160 * 1024) / 3;
+        uint32_t rl = 0;
+        while (rl + 2 < S[l] && lds + (size_t)((m / 2) >> rl) * 72 > room) rl++;
+        const int32_t max_s = (int32_t)S[l] - 2 - (int32_t)rl;
+        if (lds + (size_t)((m / 2) >> rl) * 72 <= room && max_s >= 1) {
+          p.sh_tab = get_shoup_table(log_n, omega, S[l], rl, &err);
+          if (!p.sh_tab) return err;
+          p.sh_res_log = rl;
+          p.sh_ns = (m / 2) >> rl;
+          p.sh_max_s = max_s;
+          lds += (size_t)p.sh_ns * 72;
+        }
+      }
       dim3 grid((unsigned)(nc * tiles));
       if (lds > 64 * 1024) {
         bool& raised = c.ntt_lds_raised;  // per device: the attribute belongs to the device's code object

@@ -10,7 +10,7 @@ import sys
 tag = sys.argv[1]
 suffix = sys.argv[2] if len(sys.argv) > 2 else ""
 src = f"gpurun_out/prof_{tag}{suffix}"
-stats = glob.glob(f"{src}_stats/*/*_kernel_stats.csv")
+stats = glob.glob(f"{src}_stats/*/*_kernel_stats.csv") + glob.glob(f"{src}_stats/*kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}{suffix}_kernel_stats.csv")
 else:
@@ -26,7 +26,7 @@ else:
             w.writerow([r[0], r[1], r[2], round(r[3], 3), round(100 * r[2] / tot, 2), r[4], r[5]])
 rows = []
 for kind in ("fetch", "write"):
-    files = glob.glob(f"{src}_{kind}/*/*_counter_collection.csv")
+    files = glob.glob(f"{src}_{kind}/*/*_counter_collection.csv") + glob.glob(f"{src}_{kind}/*counter_collection.csv")
     if not files:
         continue
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
@@ -38,7 +38,7 @@ for kind in ("fetch", "write"):
     for k, (n, v, ms) in agg.items():
         rows.append((kind, k, n, v, ms))
 with open(f"profiles/{tag}{suffix}_pmc_summary.csv", "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-proof (tools/profile_round.sh)\n")
     f.write("# Counter_Value is in KiB as reported; gfx950 correction (MI355X_MICROARCH.md §HBM): HBM read bytes = 2 * FETCH_SIZE * 1024\n")
     f.write("# for wide coalesced 16 B/lane streams, HBM write bytes = WRITE_SIZE * 1024.\n")
     f.write("counter,kernel,launches,sum_counter_KiB,per_launch_KiB,sum_ms\n")

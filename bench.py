@@ -172,14 +172,16 @@ def main():
         # RCCL ("nccl") on a multi-GPU node; VDB_DIST_BACKEND=gloo lets the N>1 path be rehearsed with ranks sharing one GPU
         backend = os.environ.get("VDB_DIST_BACKEND", "nccl")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # one rank per GPU; a launcher that narrows every rank's view to its own card (HIP_VISIBLE_DEVICES) leaves one device, index 0
+            local_dev = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_dev)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
         else:
             dist.init_process_group(backend=backend)
 
     from halo2_vectordb_amd import api
     from halo2_vectordb_amd.pipeline import KmeansHotPath
-    api.init(local_rank if os.environ.get("VDB_DIST_BACKEND", "nccl") == "nccl" else 0)
+    api.init(local_rank % max(1, api.device_count()) if os.environ.get("VDB_DIST_BACKEND", "nccl") == "nccl" else 0)
 
     cfg = dict(n=256, dim=128, K=4, I=8, k=16, P=48, L=15)
     if args.small:

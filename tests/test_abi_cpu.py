@@ -60,3 +60,11 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle under /oracle is test infrastructure", ""), (dp, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/vdb.h is what a C / Rust-bindgen / cgo caller includes: it must compile as C99 on its own, warnings as errors"""
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "vdb.h"\nint main(void) { return vdb_device_count() < 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "h.o")])

@@ -510,10 +510,47 @@ template <class M>
 HD u256 to_mont(const u256& canonical) {
   return mont_mul<M>(canonical, mont_r2<M>());
 }
+// a / R: on the device the reduction half of the core alone ((a << 5) + m p) / 2^261 — the product core in its asm form cannot
+// drop the 72 multiply-adds by the zero limbs of the factor 1, which the compiler used to fold away (the MSM's sort converts every
+// non-zero scalar of a column this way)
 template <class M>
 HD u256 from_mont(const u256& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr uint32_t MASK = 0x1fffffffu;
+  uint32_t A[9], L[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int pos = 29 * k - 5;        // limb k of (a << 5), as in mont_mul
+    if (pos < 0) {
+      A[k] = (a.w[0] << 5) & MASK;
+    } else {
+      int w = pos >> 5, o = pos & 31;
+      uint32_t lo = w < 8 ? a.w[w < 8 ? w : 0] : 0u;
+      uint32_t hi = w + 1 < 8 ? a.w[w + 1 < 8 ? w + 1 : 0] : 0u;
+      A[k] = (o ? ((lo >> o) | (hi << (32 - o))) : lo) & MASK;
+    }
+  }
+  asm(
+#include "core29_redc.inc"
+      : VDB_CORE29_OUT(L)
+      : VDB_CORE29_IN(A), VDB_CORE29_MOD(M)
+      : VDB_CORE29_CLOBBER);
+  u256 r;
+  r.w[0] = L[0] | (L[1] << 29);
+  r.w[1] = (L[1] >> 3) | (L[2] << 26);
+  r.w[2] = (L[2] >> 6) | (L[3] << 23);
+  r.w[3] = (L[3] >> 9) | (L[4] << 20);
+  r.w[4] = (L[4] >> 12) | (L[5] << 17);
+  r.w[5] = (L[5] >> 15) | (L[6] << 14);
+  r.w[6] = (L[6] >> 18) | (L[7] << 11);
+  r.w[7] = (L[7] >> 21) | (L[8] << 8);
+  u256 s, p = mod_p<M>();
+  uint32_t borrow = u256_sub(s, r, p);
+  return borrow ? r : s;
+#else
   u256 one = u256_from_u64(1);
   return mont_mul<M>(a, one);
+#endif
 }
 // a^e (e canonical integer), left-to-right; not constant time (nothing here is secret-dependent
 // beyond what the reference's own vartime code does)

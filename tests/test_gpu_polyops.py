@@ -597,5 +597,9 @@ def test_gate_eval_on_the_sub_coset(api, O):
     h2 = d_h1.download((2 * n, 4))
     assert np.array_equal(h2, h4[: 2 * n]) and not h4[2 * n:].any()
     assert lib.vdb_gate_eval_sub_dev(bufs[0].ptr, 0, bufs[2].ptr, ctypes.c_size_t(n_cols), k, 1, api._p(y), d_h1.ptr) == -3     # VDB_ERR_ARG: adv_ext_k < ext_k
+    before = d_h2.download((2 * n, 4))
+    check(lib.vdb_gate_eval_sub_dev(bufs[0].ptr, 2, bufs[2].ptr, ctypes.c_size_t(0), k, 1, api._p(y), d_h2.ptr))                  # no columns: nothing happens
+    api.sync()
+    assert np.array_equal(d_h2.download((2 * n, 4)), before)
     for b in bufs + [d_h1, d_h2]:
         b.free()

@@ -14,6 +14,9 @@
 // Parity unpinned: the parameters and encodings above are recalled, the reference holds no proof bytes.
 // The sponge is cross-checked against an independent Python restatement (tests/test_transcript_cpu.py), and at T = 3
 // against the chip's optimised schedule.
+#include <chrono>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -28,6 +31,8 @@ struct vdb_transcript {
   PoseidonOpt opt;  // the permutation's optimised schedule (sparse partial rounds), poseidon.hip
   uint8_t sign_mask = 0x40;  // where a compressed point carries "y is odd" (vdb_transcript_set_sign_bit)
   std::vector<uint8_t> bytes;
+  void* ifma = nullptr;      // lane tables of the AVX-512 IFMA permutation (hostperm_ifma.cpp), when the CPU and the width allow
+  ~vdb_transcript() { host_ifma_free(ifma); }
 };
 
 namespace {
@@ -52,12 +57,62 @@ const HostKernels& host_kernels() {
   return k;
 }
 
-void permute(vdb_transcript* tr) {
+HostPermView perm_view(const vdb_transcript* tr) {
   const PoseidonOpt& o = tr->opt;
   static_assert(sizeof(u256) == 32, "field elements are 32 bytes");
   auto w = [](const std::vector<u256>& v) { return reinterpret_cast<const uint64_t*>(v.data()); };
-  const HostPermView view = {o.t, o.half, o.rp, w(o.start), w(o.partial), w(o.end), w(o.mds), w(o.pre_sparse), w(o.sparse_row), w(o.sparse_col)};
-  host_kernels().permute(view, reinterpret_cast<uint64_t*>(tr->state.data()));
+  return HostPermView{o.t, o.half, o.rp, w(o.start), w(o.partial), w(o.end), w(o.mds), w(o.pre_sparse), w(o.sparse_row), w(o.sparse_col)};
+}
+// VDB_HOST_GENERIC: 1 = the portable build, 2 = at most the mulx / adx build (no AVX-512 IFMA); unset: the best the CPU has
+bool ifma_allowed() {
+  static const bool ok = [] {
+    const char* force = getenv("VDB_HOST_GENERIC");
+    if (force && (force[0] == '1' || force[0] == '2')) return false;
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl") != 0;
+#else
+    return false;
+#endif
+  }();
+  return ok;
+}
+// Which build of the permutation is faster on this CPU is measured once per process and width (a few hundred microseconds): the
+// vector build wins on cores with full-width 512-bit units (EPYC 9005, Xeon), the mulx build where they are double-pumped.  Both
+// compute the same function, so the choice never shows in a result.
+bool ifma_is_faster(vdb_transcript* tr) {
+  static std::map<int, bool> decided;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = decided.find(tr->t);
+  if (it != decided.end()) return it->second;
+  const HostPermView view = perm_view(tr);
+  std::vector<u256> scratch(tr->state);
+  uint64_t* st = reinterpret_cast<uint64_t*>(scratch.data());
+  auto time_of = [&](bool ifma) {
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 24; i++) {
+        if (ifma) host_permute_ifma(tr->ifma, st);
+        else host_kernels().permute(view, st);
+      }
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt < best) best = dt;
+    }
+    return best;
+  };
+  time_of(true);   // warm both
+  time_of(false);
+  const bool faster = time_of(true) < time_of(false);
+  decided[tr->t] = faster;
+  return faster;
+}
+void permute(vdb_transcript* tr) {
+  if (tr->ifma) {
+    host_permute_ifma(tr->ifma, reinterpret_cast<uint64_t*>(tr->state.data()));
+    return;
+  }
+  host_kernels().permute(perm_view(tr), reinterpret_cast<uint64_t*>(tr->state.data()));
 }
 
 void absorb_chunk(vdb_transcript* tr, const u256* in, int n_in) {
@@ -107,6 +162,13 @@ int vdb_transcript_new(uint32_t t, uint32_t r_f, uint32_t r_p, vdb_transcript** 
   try {
     poseidon_build_opt(tr->t, tr->r_f, tr->r_p, &tr->opt);
     tr->state.assign(t, u256_zero());
+    if (ifma_allowed()) {
+      tr->ifma = host_ifma_prepare(perm_view(tr));     // null (width above 8, no memory): the scalar builds serve
+      if (tr->ifma && !ifma_is_faster(tr)) {            // e.g. a core that double-pumps 512-bit operations
+        host_ifma_free(tr->ifma);
+        tr->ifma = nullptr;
+      }
+    }
   } catch (...) {
     delete tr;
     return VDB_ERR_OOM;

@@ -112,9 +112,10 @@ def test_compressed_point_sign_bit_is_selectable():
         tr.set_sign_bit(5)
 
 
-def test_both_host_builds_of_the_sponge_agree():
-    """hostperm.cpp is built twice (portable / BMI2 + ADX); the library picks by CPU feature, VDB_HOST_GENERIC=1 forces the
-    portable one: the same absorbed values give the same challenges and the same Horner value in both"""
+def test_the_host_builds_of_the_sponge_agree():
+    """The sponge's permutation exists in three host builds (portable, BMI2 + ADX, AVX-512 IFMA); the library picks by CPU feature,
+    VDB_HOST_GENERIC=1 forces the portable one, 2 allows at most the mulx build: the same absorbed values give the same challenges
+    and the same Horner value in all (on a CPU without a feature the runs coincide trivially)"""
     import os
     import subprocess
     import sys
@@ -130,8 +131,8 @@ def test_both_host_builds_of_the_sponge_agree():
             "_lib.check(_lib.load().vdb_fr_horner(api._p(v), ctypes.c_size_t(len(v)), api._p(a), api._p(acc)))\n"
             "print(' '.join(str(int(x)) for x in list(a) + list(b) + list(acc)))\n")
     outs = []
-    for force in ("0", "1"):
+    for force in ("0", "1", "2"):
         env = dict(os.environ, VDB_HOST_GENERIC=force, PYTHONPATH=root)
         outs.append(subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120, cwd=root))
         assert outs[-1].returncode == 0, outs[-1].stderr
-    assert outs[0].stdout == outs[1].stdout and len(outs[0].stdout.split()) == 12
+    assert outs[0].stdout == outs[1].stdout == outs[2].stdout and len(outs[0].stdout.split()) == 12

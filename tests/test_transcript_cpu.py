@@ -113,9 +113,10 @@ def test_compressed_point_sign_bit_is_selectable():
 
 
 def test_the_host_builds_of_the_sponge_agree():
-    """The sponge's permutation exists in three host builds (portable, BMI2 + ADX, AVX-512 IFMA); the library picks by CPU feature,
-    VDB_HOST_GENERIC=1 forces the portable one, 2 allows at most the mulx build: the same absorbed values give the same challenges
-    and the same Horner value in all (on a CPU without a feature the runs coincide trivially)"""
+    """The sponge's permutation exists in three host builds (portable, BMI2 + ADX, AVX-512 IFMA); the library picks by CPU feature and a
+    one-time measurement, VDB_HOST_GENERIC=1 forces the portable one, 2 allows at most the mulx build, 3 takes the IFMA build whenever
+    the CPU has it: the same absorbed values give the same challenges and the same Horner value in all, at widths that fit the vector
+    build (3, 5, 8) and one that does not (9: the scalar builds serve).  On a CPU without a feature the runs coincide trivially."""
     import os
     import subprocess
     import sys
@@ -124,15 +125,18 @@ def test_the_host_builds_of_the_sponge_agree():
             "from halo2_vectordb_amd import api, _lib\n"
             "rng = np.random.default_rng(5)\n"
             "v = rng.integers(0, 1 << 62, size=(1001, 4), dtype=np.uint64)\n"
-            "tr = api.Transcript()\n"
-            "tr.write_scalars(v)\n"
-            "a = tr.squeeze(); b = tr.squeeze()\n"
+            "out = []\n"
+            "for t, rp in ((5, 60), (3, 57), (8, 22), (9, 22)):\n"
+            "    tr = api.Transcript(t, 8, rp)\n"
+            "    tr.write_scalars(v)\n"
+            "    a = tr.squeeze(); b = tr.squeeze()\n"
+            "    out += list(a) + list(b)\n"
             "acc = np.zeros(4, dtype=np.uint64)\n"
             "_lib.check(_lib.load().vdb_fr_horner(api._p(v), ctypes.c_size_t(len(v)), api._p(a), api._p(acc)))\n"
-            "print(' '.join(str(int(x)) for x in list(a) + list(b) + list(acc)))\n")
+            "print(' '.join(str(int(x)) for x in out + list(acc)))\n")
     outs = []
-    for force in ("0", "1", "2"):
+    for force in ("0", "1", "2", "3"):
         env = dict(os.environ, VDB_HOST_GENERIC=force, PYTHONPATH=root)
-        outs.append(subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120, cwd=root))
+        outs.append(subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300, cwd=root))
         assert outs[-1].returncode == 0, outs[-1].stderr
-    assert outs[0].stdout == outs[1].stdout == outs[2].stdout and len(outs[0].stdout.split()) == 12
+    assert outs[0].stdout == outs[1].stdout == outs[2].stdout == outs[3].stdout and len(outs[0].stdout.split()) == 4 * 8 + 4

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "vdb_msm_batch_masked_dev_begin": [_P, _I, _P, _SZ, _SZ, _P, _P], "vdb_msm_batch_end": [_P, _SZ],
     "vdb_grand_product_dev": [_P, _P, _SZ, _SZ, _P], "vdb_eval_polys_dev": [_P, _SZ, _SZ, _P, _P], "vdb_extended_to_coeff_dev": [_P, _SZ, _U32, _U32],
     "vdb_gate_eval_dev": [_P, _P, _SZ, _U32, _U32, _P, _P], "vdb_permutation_mapping_pack_dev": [_P, _SZ, _U32, _P], "vdb_permutation_sigma_packed_dev": [_P, _SZ, _SZ, _U32, _P, _P],
+    "vdb_eval_polys_dev_out": [_P, _SZ, _SZ, _P, _P], "vdb_transcript_flush": [_P],
     "vdb_gate_eval_sub_dev": [_P, _U32, _P, _SZ, _U32, _U32, _P, _P], "vdb_const_eval_dev": [_P, _P, _SZ, _U32, _U32, _P, _P], "vdb_divide_by_vanishing_dev": [_P, _U32, _U32],
     "vdb_layout_selectors_dev": [_P, _U64, _P, _U64, _U32, _P],
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],

@@ -659,6 +659,10 @@ class Transcript:
         pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 8)
         check(self.L.vdb_transcript_common_points(self.h, _p(pts), _sz(pts.shape[0])))
 
+    def flush(self):
+        """absorb the complete chunks written so far now (vdb_transcript_flush): host work beside queued device work"""
+        check(self.L.vdb_transcript_flush(self.h))
+
     def squeeze(self):
         out = np.zeros(4, dtype=np.uint64)
         check(self.L.vdb_transcript_squeeze(self.h, _p(out)))

@@ -655,26 +655,39 @@ int vdb_grand_product_dev(const vdb_fr* num_dev, const vdb_fr* den_dev, size_t n
   return VDB_OK;
 }
 
-int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, vdb_fr* out_host) {
-  VDB_REQUIRE_INIT();
-  VDB_ARG(coeff_dev && x && out_host && n >= 1, "bad argument");
-  if (n_cols == 0) return VDB_OK;
+// queues the evaluation kernel: out_dev receives n_cols values
+static int eval_polys_launch(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, u256* dout) {
   Context& cx = ctx();
   u256 xv;
   memcpy(&xv, x, 32);
   u256 y = xv;
   for (int i = 0; i < 8; i++) y = fr_mul(y, y);  // x^256
   y = fr_mul(y, host_fr_from_u64(32));             // pre-scaled for the nine-limb product
-  u256* dout = (u256*)scratch_get(5, n_cols * sizeof(u256));
-  if (!dout) return VDB_ERR_OOM;
   {
     VDB_PROF("k_eval_polys");
     hipLaunchKernelGGL(k_eval_polys, dim3((unsigned)n_cols), dim3(EV_THREADS), 0, cx.stream, as_u256(coeff_dev), (uint64_t)n, xv, y, dout);
   }
   VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+int vdb_eval_polys_dev(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, vdb_fr* out_host) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && x && out_host && n >= 1, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& cx = ctx();
+  u256* dout = (u256*)scratch_get(5, n_cols * sizeof(u256));
+  if (!dout) return VDB_ERR_OOM;
+  int rc = eval_polys_launch(coeff_dev, n_cols, n, x, dout);
+  if (rc) return rc;
   VDB_HIP(hipMemcpyAsync(out_host, dout, n_cols * sizeof(u256), hipMemcpyDeviceToHost, cx.stream));
   VDB_HIP(hipStreamSynchronize(cx.stream));
   return VDB_OK;
+}
+int vdb_eval_polys_dev_out(const vdb_fr* coeff_dev, size_t n_cols, size_t n, const vdb_fr* x, vdb_fr* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && x && out_dev && n >= 1, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  return eval_polys_launch(coeff_dev, n_cols, n, x, as_u256(out_dev));
 }
 
 int vdb_gate_eval_sub_dev(const vdb_fr* adv_ext_dev, uint32_t adv_ext_k, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y,

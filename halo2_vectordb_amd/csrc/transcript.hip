@@ -281,6 +281,17 @@ int vdb_transcript_squeeze(vdb_transcript* tr, vdb_fr* out) {
   return VDB_OK;
 }
 
+// Absorbs the complete RATE-sized chunks of what has been written so far (the sponge takes its input in order, so absorbing them
+// now or at the next squeeze gives the same state: what is left, fewer than RATE values or nothing, is framed by the squeeze as
+// before).  A caller interleaves host absorption with device work this way.
+int vdb_transcript_flush(vdb_transcript* tr) {
+  VDB_ARG(tr, "null pointer");
+  const size_t n = tr->buf.size(), full = n - n % (size_t)tr->rate;
+  for (size_t i = 0; i < full; i += tr->rate) absorb_chunk(tr, tr->buf.data() + i, tr->rate);
+  tr->buf.erase(tr->buf.begin(), tr->buf.begin() + (std::ptrdiff_t)full);
+  return VDB_OK;
+}
+
 int vdb_transcript_proof_len(const vdb_transcript* tr, size_t* len) {
   VDB_ARG(tr && len, "null pointer");
   *len = tr->bytes.size();

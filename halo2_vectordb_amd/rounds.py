@@ -16,6 +16,7 @@ from the returned evaluations, and every opening against its commitments in the 
 import ctypes
 from collections.abc import Mapping
 
+import os
 import time
 
 import numpy as np
@@ -692,23 +693,56 @@ class ProverRounds:
         w_int = _fr_to_int(api.root_of_unity(k))
         evals, points = {}, {}
 
+        groups = [(rot, name) for rot, names in opened.items() for name in names]
+        for rot in opened:
+            points[rot] = x_int * pow(w_int, rot % rows, R_MOD) % R_MOD
+
         def evaluate():
-            for rot, names in opened.items():
-                pt = x_int * pow(w_int, rot % rows, R_MOD) % R_MOD
-                points[rot] = pt
-                ptm = _fr_from_int(pt)
-                for name in names:
-                    q = allp[name]
-                    out = np.zeros((q.n_cols, 4), dtype=np.uint64)
-                    check(lib.vdb_eval_polys_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(ptm), api._p(out)))
+            for rot, name in groups:
+                q = allp[name]
+                out = np.zeros((q.n_cols, 4), dtype=np.uint64)
+                check(lib.vdb_eval_polys_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(_fr_from_int(points[rot])), api._p(out)))
+                evals[(name, rot)] = out
+
+        def evaluate_and_absorb():
+            # the device evaluates group i + 1 while the host absorbs the evaluations of group i (the sponge's host work — ~6 us per four
+            # values — is longer than the evaluation itself: only the first group's kernel is not hidden)
+            total = sum(allp[name].n_cols for _rot, name in groups)
+            d_ev = api.DeviceBuffer(max(total, 1) * B)
+            offs, o = [], 0
+            for _rot, name in groups:
+                offs.append(o)
+                o += allp[name].n_cols * B
+
+            def launch(i):
+                rot, name = groups[i]
+                q = allp[name]
+                check(lib.vdb_eval_polys_dev_out(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(_fr_from_int(points[rot])), d_ev.at(offs[i])))
+            try:
+                if groups:
+                    launch(0)
+                for i, (rot, name) in enumerate(groups):
+                    out = d_ev.download((allp[name].n_cols, 4), offset=offs[i])       # waits for group i's kernel only
+                    if i + 1 < len(groups):
+                        launch(i + 1)
                     evals[(name, rot)] = out
-        stage("evaluations", evaluate)
-        if tr is not None:
-            t0 = time.perf_counter()
-            for rot, names in opened.items():
-                for name in names:
+                    t0 = time.perf_counter()
+                    tr.write_scalars(out)
+                    tr.flush()
+                    host["transcript"] += (time.perf_counter() - t0) * 1e3
+            finally:
+                api.sync()
+                d_ev.free()
+
+        if tr is not None and timings is None and os.environ.get("VDB_EVAL_PIPELINE", "1") != "0":
+            evaluate_and_absorb()
+        else:
+            stage("evaluations", evaluate)
+            if tr is not None:
+                t0 = time.perf_counter()
+                for rot, name in groups:
                     tr.write_scalars(evals[(name, rot)])
-            host["transcript"] += (time.perf_counter() - t0) * 1e3
+                host["transcript"] += (time.perf_counter() - t0) * 1e3
         d_comb, d_quot = self.d_comb, self.d_quot
         if multiopen == "shplonk":
             openings = self._shplonk(allp, opened, points, evals, p, ch, squeeze, write_points, stage)

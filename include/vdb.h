@@ -276,6 +276,9 @@ int vdb_grand_product_dev(const vdb_fr *num_dev, const vdb_fr *den_dev, size_t n
 /* out[c] = sum_i coeff[c][i] * x^i for n_cols coefficient-form polynomials of n coefficients (halo2 eval_polynomial, the
  * opening evaluations of the advice polynomials).  coeff_dev: device; x: one field element on the host; out_host: host. */
 int vdb_eval_polys_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *out_host);
+/* the same queued only: the n_cols values go to out_dev, nothing is waited for (the caller reads them with vdb_memcpy_d2h, which is
+ * ordered behind the kernel, and may queue the next evaluation before it turns to the host side of the previous one) */
+int vdb_eval_polys_dev_out(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *out_dev);
 /* Lookup argument, permuted columns (halo2 plonk/lookup/prover.rs permute_expression_pair) for range-table lookups: per
  * input column, over rows [0, usable_rows): permuted_input = the input values in ascending canonical order;
  * permuted_table = at the first row of every run of equal values that value, elsewhere the table's left-over values in
@@ -419,6 +422,9 @@ int vdb_transcript_write_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
 int vdb_transcript_write_scalars(vdb_transcript *tr, const vdb_fr *s, size_t n);
 int vdb_transcript_common_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
 int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
+/* absorbs the complete RATE-sized chunks written so far (same state as leaving them to the next squeeze): lets a caller run the
+ * sponge's host work beside device work that is already queued */
+int vdb_transcript_flush(vdb_transcript *tr);
 int vdb_transcript_proof_len(const vdb_transcript *tr, size_t *len);
 int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t cap);
 

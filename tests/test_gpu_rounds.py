@@ -727,6 +727,9 @@ def test_sigma_columns_from_the_packed_mapping(circuit, O):
     assert with_map == without
     check(lib.vdb_permutation_sigma_packed_dev(pr.d_map32.ptr, ctypes.c_size_t(0), ctypes.c_size_t(pr.n_perm), k, api._p(pr.delta), pr.d_map32.ptr))   # empty block
     assert lib.vdb_permutation_sigma_packed_dev(pr.d_map32.ptr, ctypes.c_size_t(pr.n_perm + 1), ctypes.c_size_t(pr.n_perm), k, api._p(pr.delta), pr.d_map32.ptr) == -3
+    # the untimed proof evaluates and absorbs group by group (device evaluation beside host absorption), the instrumented one evaluates
+    # everything first: the same bytes
+    assert pr.prove(None, seed=77, timings={})["proof"] == with_map
     # a mapping whose columns and rows do not fit 32 bits together is refused
     d = api.DeviceBuffer(64)
     assert lib.vdb_permutation_mapping_pack_dev(d.ptr, ctypes.c_size_t(1 << 20), 16, d.ptr) == -3

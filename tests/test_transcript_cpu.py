@@ -140,3 +140,26 @@ def test_the_host_builds_of_the_sponge_agree():
         outs.append(subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300, cwd=root))
         assert outs[-1].returncode == 0, outs[-1].stderr
     assert outs[0].stdout == outs[1].stdout == outs[2].stdout == outs[3].stdout and len(outs[0].stdout.split()) == 4 * 8 + 4
+
+
+def test_flush_absorbs_early_without_changing_the_sponge():
+    """vdb_transcript_flush takes the complete chunks now: challenges equal those of a transcript that leaves everything to the squeeze,
+    whatever the lengths written between flushes (multiples of the rate, remainders, nothing)"""
+    from halo2_vectordb_amd import api
+    rng = np.random.default_rng(9)
+    v = rng.integers(0, 1 << 62, size=(41, 4), dtype=np.uint64)
+    a, b = api.Transcript(), api.Transcript()
+    got_a, got_b = [], []
+    pos = 0
+    for m in (0, 3, 4, 1, 8, 5, 0, 9, 11):
+        a.write_scalars(v[pos: pos + m])
+        b.write_scalars(v[pos: pos + m])
+        b.flush()
+        b.flush()
+        pos += m
+        if m in (4, 5, 0, 11):
+            got_a.append(a.squeeze().tolist())
+            got_b.append(b.squeeze().tolist())
+    assert got_a == got_b and a.proof() == b.proof()
+    a.free()
+    b.free()

@@ -142,6 +142,7 @@ def whole_proof(api):
            "proof_ms": wall, "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
            "constraints_per_s": (hp.n_cells + hp.n_lookup) / (wall * 1e-3), "proof_bytes": len(out["proof"]),
            "keygen_and_setup_s": round(keygen_s, 1),
+           "n_instances": len(out["instances"]),        # the public statement: the K x dim centroid words, tied to the instance column
            "mock_prover_violations": rep.violations(),
            "quotient_identity_at_x_holds": bool(quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"]))}
     pr.free()

@@ -79,17 +79,18 @@ _SIGNATURES = {
     "vdb_grand_product_dev": [_P, _P, _SZ, _SZ, _P], "vdb_eval_polys_dev": [_P, _SZ, _SZ, _P, _P], "vdb_extended_to_coeff_dev": [_P, _SZ, _U32, _U32],
     "vdb_gate_eval_dev": [_P, _P, _SZ, _U32, _U32, _P, _P], "vdb_permutation_mapping_pack_dev": [_P, _SZ, _U32, _P], "vdb_permutation_sigma_packed_dev": [_P, _SZ, _SZ, _U32, _P, _P],
     "vdb_eval_polys_dev_out": [_P, _SZ, _SZ, _P, _P], "vdb_transcript_flush": [_P],
-    "vdb_gate_eval_sub_dev": [_P, _U32, _P, _SZ, _U32, _U32, _P, _P], "vdb_const_eval_dev": [_P, _P, _SZ, _U32, _U32, _P, _P], "vdb_divide_by_vanishing_dev": [_P, _U32, _U32],
+    "vdb_gate_eval_sub_dev": [_P, _U32, _P, _SZ, _U32, _U32, _P, _P], "vdb_divide_by_vanishing_dev": [_P, _U32, _U32],
     "vdb_layout_selectors_dev": [_P, _U64, _P, _U64, _U32, _P],
     "vdb_lookup_permute_dev": [_P, _P, _SZ, _SZ, _SZ, _U32, _P, _P],
     "vdb_lookup_product_dev": [_P, _P, _P, _P, _SZ, _SZ, _SZ, _P, _P, _P], "vdb_fr_delta": [_P],
     "vdb_permutation_sigma_dev": [_P, _SZ, _U32, _P, _P],
     "vdb_transcript_new": [_U32, _U32, _U32, _P], "vdb_transcript_free": [_P], "vdb_transcript_set_sign_bit": [_P, _U32], "vdb_transcript_common_scalar": [_P, _P], "vdb_transcript_common_point": [_P, _P],
-    "vdb_transcript_write_points": [_P, _P, _SZ], "vdb_transcript_write_scalars": [_P, _P, _SZ], "vdb_transcript_common_points": [_P, _P, _SZ],
+    "vdb_transcript_write_points": [_P, _P, _SZ], "vdb_transcript_write_scalars": [_P, _P, _SZ], "vdb_transcript_common_points": [_P, _P, _SZ], "vdb_transcript_common_scalars": [_P, _P, _SZ],
     "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
     "vdb_scratch_release": [], "vdb_mem_info": [_P, _P],
-    "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P],
+    "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P, _U64, _P],
+    "vdb_gather_fr_dev": [_P, _P, _SZ, _P], "vdb_mock_check_instances_dev": [_P, _U64, _P, _P, _U64, _P],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_axpy_dev": [_P, _P, _P, _SZ],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],

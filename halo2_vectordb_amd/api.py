@@ -423,10 +423,11 @@ class MockReport(ctypes.Structure):
     """vdb_mock_report (include/vdb.h)"""
     _fields_ = [(n, ctypes.c_uint64) for n in ("gate_rows_violated", "first_gate_row", "lookup_cells_out_of_table", "first_lookup_cell",
                                                "copies_unequal", "first_copy", "lookup_copies_unequal", "first_lookup_copy",
-                                               "constants_changed", "first_constant")]
+                                               "constants_changed", "first_constant", "instances_unequal", "first_instance")]
 
     def violations(self):
-        return int(self.gate_rows_violated + self.lookup_cells_out_of_table + self.copies_unequal + self.lookup_copies_unequal + self.constants_changed)
+        return int(self.gate_rows_violated + self.lookup_cells_out_of_table + self.copies_unequal + self.lookup_copies_unequal + self.constants_changed
+                   + self.instances_unequal)
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -439,6 +440,13 @@ def mock_check_dev(stream_ptr, n_cells, flags_ptr, lookup_ptr, n_lookup, lookup_
     check(_lib.init().vdb_mock_check_dev(stream_ptr, ctypes.c_uint64(n_cells), flags_ptr, lookup_ptr, ctypes.c_uint64(n_lookup), ctypes.c_uint32(lookup_bits),
                                          copy_of_ptr, lookup_src_ptr, const_stream_ptr, const_idx_ptr, const_table_ptr, ctypes.c_uint64(n_consts),
                                          ctypes.byref(rep)))
+    return rep
+
+
+def mock_check_instances_dev(rep, stream_ptr, n_cells, cells_ptr, values_ptr, n_instances):
+    """the `instances` argument of MockProver::run on a device-resident witness (vdb_mock_check_instances_dev): stream cell cells[i]
+    must hold values[i]; fills rep.instances_unequal / first_instance"""
+    check(_lib.init().vdb_mock_check_instances_dev(stream_ptr, ctypes.c_uint64(n_cells), cells_ptr, values_ptr, ctypes.c_uint64(n_instances), ctypes.byref(rep)))
     return rep
 
 
@@ -658,6 +666,10 @@ class Transcript:
     def common_points(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 8)
         check(self.L.vdb_transcript_common_points(self.h, _p(pts), _sz(pts.shape[0])))
+
+    def common_scalars(self, ss):
+        ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
+        check(self.L.vdb_transcript_common_scalars(self.h, _p(ss), _sz(ss.shape[0])))
 
     def flush(self):
         """absorb the complete chunks written so far now (vdb_transcript_flush): host work beside queued device work"""

@@ -216,7 +216,7 @@ def lookup_sources(flags, n_lookup):
     return src
 
 
-def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, lookup_rows=None, const_idx=None, n_consts=0):
+def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, lookup_rows=None, const_idx=None, n_consts=0, instance_cells=None):
     """Permutation over a grid of columns x rows (words col << 32 | row, the identity where nothing is tied) from a copy map
     over the stream cells that fill the first len(break_points) + 1 columns: every set of cells that copy one another
     (directly or through other copies) becomes one cycle, and the overlap cell that ends column c is the cell that starts
@@ -224,7 +224,9 @@ def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, l
     n_adv + j // lookup_rows, joins the cycle of the advice cell lookup_src[j].
     `const_idx` (with `n_consts`): cell i with const_idx[i] = r >= 0 is tied to row r of ONE MORE column, number n_cols, the
     fixed column that holds the circuit's constants — how halo2-base pins `QuantumCell::Constant` cells and
-    `assert_is_const` — and the grid gets n_cols + 1 columns."""
+    `assert_is_const` — and the grid gets n_cols + 1 columns.
+    `instance_cells` (a list, possibly empty; requires `const_idx`): the grid gets column n_cols + 1 as well, the instance
+    column, whose row i joins the cycle of stream cell instance_cells[i] (RangeWithInstanceCircuitBuilder's constrain_instance)."""
     copy_of = np.asarray(copy_of, dtype=np.int64)
     n_cells = copy_of.size
     bp = np.asarray(break_points, dtype=np.int64)
@@ -264,6 +266,16 @@ def mapping_from_copy_of(copy_of, break_points, n_cols, rows, lookup_src=None, l
         pos_col.append(np.full(n_consts, n_cols, dtype=np.int64))
         pos_row.append(np.arange(n_consts, dtype=np.int64))
         pos_root.append(root[n_cells:])
+    if instance_cells is not None:
+        if not with_consts:
+            raise ValueError("the instance column follows the constants' column")
+        inst = np.asarray(instance_cells, dtype=np.int64).reshape(-1)
+        if inst.size > rows:
+            raise ValueError("more public cells than rows in the instance column")
+        total_cols += 1
+        pos_col.append(np.full(inst.size, n_cols + 1, dtype=np.int64))
+        pos_row.append(np.arange(inst.size, dtype=np.int64))
+        pos_root.append(root[inst])
     pos_col, pos_row, pos_root = np.concatenate(pos_col), np.concatenate(pos_row), np.concatenate(pos_root)
     if int(root.size) * total_cols * rows < (1 << 62):           # one combined key sorts several times faster than three
         order = np.argsort(pos_root * (total_cols * rows) + pos_col * rows + pos_row, kind="stable")

@@ -57,6 +57,8 @@ struct Context {
 Context& ctx();
 // makes that device the calling thread's current HIP device (HIP's current device is per thread)
 int bind_thread();
+// physical HIP device of a logical one (identical unless the test-only VDB_TEST_ALIAS_DEVICES is set)
+int phys_of(int logical);
 bool context_ready(int device);
 void witness_release(Context& c);   // witness.hip
 void poseidon_release(Context& c);  // poseidon.hip

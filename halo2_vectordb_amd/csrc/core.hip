@@ -12,8 +12,13 @@ static thread_local char g_err[512] = "";
 
 Context& ctx() { return g_ctxs[t_cur >= 0 ? t_cur : g_default]; }
 bool context_ready(int device) { return device >= 0 && device < VDB_MAX_DEVICES && g_ctxs[device].ready; }
+// Test-only switch VDB_TEST_ALIAS_DEVICES=n: the library offers n logical devices where fewer are visible, logical device d
+// living on physical device d % visible — separate contexts (streams, work space, tables, srs handles) on one card, so that the
+// several-GPUs-in-one-process code runs with n > 1 on a one-GPU box.  Unset (the default): logical = physical.
+static int g_phys_count = 0;
+int phys_of(int logical) { return g_phys_count > 0 ? logical % g_phys_count : logical; }
 int bind_thread() {
-  const int d = ctx().device;
+  const int d = phys_of(ctx().device);
   if (t_hip_dev != d) {
     VDB_HIP(hipSetDevice(d));
     t_hip_dev = d;
@@ -193,15 +198,15 @@ const char* vdb_last_error(void) { return g_err; }
 static int init_context(int device) {
   Context& c = g_ctxs[device];
   if (c.ready) return VDB_OK;
-  VDB_HIP(hipSetDevice(device));
-  t_hip_dev = device;
+  VDB_HIP(hipSetDevice(phys_of(device)));
+  t_hip_dev = phys_of(device);
   VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   VDB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
   VDB_HIP(hipEventCreateWithFlags(&c.ev_tail, hipEventDisableTiming));
   VDB_HIP(hipEventCreate(&c.ev0));
   VDB_HIP(hipEventCreate(&c.ev1));
   hipDeviceProp_t prop;
-  VDB_HIP(hipGetDeviceProperties(&prop, device));
+  VDB_HIP(hipGetDeviceProperties(&prop, phys_of(device)));
   c.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c.device = device;
   c.ready = true;
@@ -210,7 +215,7 @@ static int init_context(int device) {
 static void shutdown_context(int device) {
   Context& c = g_ctxs[device];
   if (!c.ready) return;
-  if (hipSetDevice(device) == hipSuccess) t_hip_dev = device;
+  if (hipSetDevice(phys_of(device)) == hipSuccess) t_hip_dev = phys_of(device);
   (void)hipStreamSynchronize(c.stream);
   (void)hipStreamSynchronize(c.aux);
   c.msm_pending = false;
@@ -246,6 +251,11 @@ static int visible_devices(int* n) {
     return VDB_ERR_NO_DEVICE;
   }
   if (*n > VDB_MAX_DEVICES) *n = VDB_MAX_DEVICES;
+  g_phys_count = *n;
+  if (const char* e2 = getenv("VDB_TEST_ALIAS_DEVICES")) {
+    const int want = atoi(e2);
+    if (want > *n && want <= VDB_MAX_DEVICES) *n = want;
+  }
   return VDB_OK;
 }
 

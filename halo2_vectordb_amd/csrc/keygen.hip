@@ -6,7 +6,9 @@
 //   1. pointer jumping over the copy forest (every cell points at an earlier cell, at itself, or at a cell of the constants'
 //      fixed column) until every cell holds the root of its class;
 //   2. one (root, position) record per grid position a class occupies — a stream cell's (column, row), the duplicate of the
-//      overlap cell at the end of each column, a lookup cell's position in the lookup columns, the fixed cells;
+//      overlap cell at the end of each column, a lookup cell's position in the lookup columns, the fixed cells, and the rows of
+//      the instance column the circuit's public cells are tied to (halo2-base's RangeWithInstanceCircuitBuilder:
+//      layouter.constrain_instance(cell, instance_column, i), /root/reference/src/scaffold/mod.rs:400);
 //   3. a radix sort of the records by root (rocPRIM device radix sort: the sort is HBM-bound, 4 passes over 16 B records);
 //   4. every record points at the next one of its class, the last at the first: the cycles.  Positions in no class keep the
 //      identity.
@@ -40,14 +42,14 @@ __global__ __launch_bounds__(256) void k_pm_identity(uint64_t* __restrict__ mapp
   if (i < n_cols * rows) mapping[i] = ((i / rows) << 32) | (i % rows);
 }
 struct PmShape {
-  uint64_t n_cells, n_dup, n_lookup, n_consts;  // records: stream cells, overlap duplicates, lookup cells, fixed cells
-  uint64_t n_adv, lookup_rows, fixed_col;
+  uint64_t n_cells, n_dup, n_lookup, n_consts, n_inst;  // records: stream cells, overlap duplicates, lookup cells, fixed cells, instance rows
+  uint64_t n_adv, lookup_rows, fixed_col;               // the instance column is column fixed_col + 1
 };
 // record t -> (root, col << 32 | row); starts[c] = stream offset of row 0 of advice column c (n_adv + 1 entries, the last = n_cells)
 __global__ __launch_bounds__(256) void k_pm_records(PmShape s, const int64_t* __restrict__ root, const uint64_t* __restrict__ starts,
-                                                   const uint64_t* __restrict__ bp, const int64_t* __restrict__ lookup_src, uint64_t* __restrict__ keys,
-                                                   uint64_t* __restrict__ vals) {
-  const uint64_t total = s.n_cells + s.n_dup + s.n_lookup + s.n_consts;
+                                                   const uint64_t* __restrict__ bp, const int64_t* __restrict__ lookup_src,
+                                                   const int64_t* __restrict__ inst_cells, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+  const uint64_t total = s.n_cells + s.n_dup + s.n_lookup + s.n_consts + s.n_inst;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     uint64_t key, col, row;
@@ -71,11 +73,16 @@ __global__ __launch_bounds__(256) void k_pm_records(PmShape s, const int64_t* __
       col = s.n_adv + j / s.lookup_rows;
       row = j % s.lookup_rows;
       key = (uint64_t)root[lookup_src[j]];
-    } else {
+    } else if (t < s.n_cells + s.n_dup + s.n_lookup + s.n_consts) {
       const uint64_t r = t - s.n_cells - s.n_dup - s.n_lookup;
       col = s.fixed_col;
       row = r;
       key = s.n_cells + r;
+    } else {  // row i of the instance column joins the class of the cell that was made public i-th
+      const uint64_t r = t - s.n_cells - s.n_dup - s.n_lookup - s.n_consts;
+      col = s.fixed_col + 1;
+      row = r;
+      key = (uint64_t)root[inst_cells[r]];
     }
     keys[t] = key;
     vals[t] = (col << 32) | row;
@@ -107,12 +114,14 @@ __global__ __launch_bounds__(256) void k_pm_link(const uint64_t* __restrict__ ke
 using namespace vdb;
 
 extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t* break_points, uint64_t n_bp, uint32_t k,
-                                           const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols, uint64_t* mapping_dev) {
+                                           const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
+                                           const int64_t* instance_cells_dev, uint64_t n_instances, uint64_t* mapping_dev) {
   VDB_REQUIRE_INIT();
   VDB_ARG(parent_dev && mapping_dev && (break_points || n_bp == 0) && k <= 28 && n_cells >= 1, "bad argument");
   const uint64_t rows = 1ull << k, n_adv = n_bp + 1;
   VDB_ARG(n_cols >= n_adv && n_consts <= rows && (n_lookup == 0 || (lookup_src_dev && lookup_rows >= 1 && lookup_rows <= rows)), "bad shape");
   VDB_ARG(n_lookup == 0 || n_adv + (n_lookup + lookup_rows - 1) / lookup_rows <= n_cols, "lookup cells do not fit the lookup columns");
+  VDB_ARG(n_instances <= rows && (n_instances == 0 || instance_cells_dev), "more public cells than rows of the instance column");
   Context& cx = ctx();
   // starts (n_adv + 1) and break points on the device
   std::vector<uint64_t> h(2 * n_adv + 1);
@@ -159,8 +168,8 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
     }
   }
   // 2. records
-  PmShape s{n_cells, n_bp, n_lookup, n_consts, n_adv, lookup_rows ? lookup_rows : 1, n_cols};
-  const uint64_t total = n_cells + n_bp + n_lookup + n_consts;
+  PmShape s{n_cells, n_bp, n_lookup, n_consts, n_instances, n_adv, lookup_rows ? lookup_rows : 1, n_cols};
+  const uint64_t total = n_cells + n_bp + n_lookup + n_consts + n_instances;
   uint64_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
   for (uint64_t** q : {&keys, &vals, &keys2, &vals2}) {
     hipError_t e = hipMalloc(q, total * sizeof(uint64_t));
@@ -169,7 +178,7 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   }
   {
     VDB_PROF("k_pm_records");
-    hipLaunchKernelGGL(k_pm_records, dim3(grid), dim3(256), 0, cx.stream, s, parent_dev, d_starts, d_bp, lookup_src_dev, keys, vals);
+    hipLaunchKernelGGL(k_pm_records, dim3(grid), dim3(256), 0, cx.stream, s, parent_dev, d_starts, d_bp, lookup_src_dev, instance_cells_dev, keys, vals);
   }
   VDB_LAUNCH_CHECK();
   // 3. sort by root
@@ -189,8 +198,8 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   keys2 = dk.current();
   vals2 = dv.current();
   // 4. cycles
-  const uint64_t n_grid = (n_cols + 1) * rows;
-  hipLaunchKernelGGL(k_pm_identity, dim3((unsigned)((n_grid + 255) / 256)), dim3(256), 0, cx.stream, mapping_dev, n_cols + 1, rows);
+  const uint64_t n_grid = (n_cols + 2) * rows;  // [advice | lookup | constants | instance]
+  hipLaunchKernelGGL(k_pm_identity, dim3((unsigned)((n_grid + 255) / 256)), dim3(256), 0, cx.stream, mapping_dev, n_cols + 2, rows);
   {
     VDB_PROF("k_pm_link");
     hipLaunchKernelGGL(k_pm_link, dim3(grid), dim3(256), 0, cx.stream, keys2, vals2, total, rows, mapping_dev);

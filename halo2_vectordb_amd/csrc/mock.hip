@@ -64,6 +64,17 @@ __global__ __launch_bounds__(256) void k_mock_lookups(const u256* __restrict__ l
   }
 }
 
+__global__ __launch_bounds__(256) void k_mock_instances(const u256* __restrict__ a, uint64_t n_cells, const int64_t* __restrict__ cells,
+                                                       const u256* __restrict__ values, uint64_t n, unsigned long long* __restrict__ out /* count, first */) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = cells[i];
+  if (c < 0 || (uint64_t)c >= n_cells || !u256_eq(ld256(a + c), ld256(values + i))) {
+    atomicAdd(&out[0], 1ull);
+    atomicMin(&out[1], (unsigned long long)i);
+  }
+}
+
 }  // namespace vdb
 
 using namespace vdb;
@@ -100,5 +111,30 @@ extern "C" int vdb_mock_check_dev(const vdb_fr* stream_dev, uint64_t n_cells, co
   out->copies_unequal = h.n[2], out->first_copy = h.first[2];
   out->lookup_copies_unequal = h.n[3], out->first_lookup_copy = h.first[3];
   out->constants_changed = h.n[4], out->first_constant = h.first[4];
+  out->instances_unequal = 0, out->first_instance = ~0ull;
+  return VDB_OK;
+}
+
+extern "C" int vdb_mock_check_instances_dev(const vdb_fr* stream_dev, uint64_t n_cells, const int64_t* instance_cells_dev, const vdb_fr* instances_dev,
+                                            uint64_t n_instances, vdb_mock_report* out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(out && (n_instances == 0 || (stream_dev && instance_cells_dev && instances_dev)), "bad argument");
+  out->instances_unequal = 0, out->first_instance = ~0ull;
+  if (n_instances == 0) return VDB_OK;
+  Context& c = ctx();
+  unsigned long long* d = (unsigned long long*)scratch_get(5, 2 * sizeof(unsigned long long));
+  if (!d) return VDB_ERR_OOM;
+  unsigned long long h[2] = {0ull, ~0ull};
+  VDB_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, c.stream));
+  VDB_HIP(hipStreamSynchronize(c.stream));  // `h` is on the stack
+  {
+    VDB_PROF("k_mock_instances");
+    hipLaunchKernelGGL(k_mock_instances, dim3((unsigned)((n_instances + 255) / 256)), dim3(256), 0, c.stream, as_u256(stream_dev), n_cells, instance_cells_dev,
+                       as_u256(instances_dev), n_instances, d);
+  }
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  VDB_HIP(hipStreamSynchronize(c.stream));
+  out->instances_unequal = h[0], out->first_instance = h[1];
   return VDB_OK;
 }

@@ -929,7 +929,7 @@ int vdb_g1_sum(const vdb_g1* parts, size_t m, size_t n, vdb_g1* out) {
 void vdb_srs_free(vdb_srs* s) {
   if (!s) return;
   int cur = -1;
-  const bool hop = hipGetDevice(&cur) == hipSuccess && cur != s->device && hipSetDevice(s->device) == hipSuccess;
+  const bool hop = hipGetDevice(&cur) == hipSuccess && cur != vdb::phys_of(s->device) && hipSetDevice(vdb::phys_of(s->device)) == hipSuccess;
   for (int b = 0; b < 2; b++)
     if (s->table[b]) (void)hipFree(s->table[b]);
   if (hop) (void)hipSetDevice(cur);

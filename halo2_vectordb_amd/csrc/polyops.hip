@@ -315,24 +315,6 @@ __global__ __launch_bounds__(256) void k_gate_eval(const u256* __restrict__ adv,
   }
   st256(acc + j, l9_canon<Fr>(h));
 }
-// Constant cells as a gate of their own: per advice column, qc (one where the cell is a QuantumCell::Constant) and fc (the
-// constant there, zero elsewhere) are fixed polynomials and qc(X) a(X) - fc(X) vanishes on the domain.  Folded into the same
-// accumulator after the gates as h = h y + qc a per column; the fc part, sum_c y^(n-1-c) fc_c, is linear in the fixed
-// polynomials, so the caller combines their COEFFICIENTS with the same powers of y (vdb_poly_lincomb_dev), extends that one
-// polynomial and subtracts it (vdb_poly_axpy_dev): only the qc cosets are ever needed per column.  Nine-limb form as
-// k_gate_eval: one two-product reduction per cell.
-__global__ __launch_bounds__(256) void k_const_eval(const u256* __restrict__ adv, const u256* __restrict__ qc, uint64_t n_cols, uint32_t log_ne,
-                                                    u256 y32 /* 32 y */, u256* __restrict__ acc) {
-  const uint64_t ne = 1ull << log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ne) return;
-  const L9 Y = l9_split(y32);
-  L9 h = l9_split(ld256(acc + j));
-  for (uint64_t c = 0; c < n_cols; c++) {
-    const uint64_t o = c * ne + j;
-    h = l9_mul2<Fr>(h, Y, l9_split(ld256(adv + o)), l9_split32(ld256(qc + o)));     // h y + a qc, normalised and below 2 r
-  }
-  st256(acc + j, l9_canon<Fr>(h));
-}
 // h[j] *= t[j mod 2^e],  t[m] = 1 / (zeta^n * w_{2^e}^m - 1): division by the vanishing polynomial X^n - 1 on the coset
 __global__ __launch_bounds__(256) void k_mul_periodic(u256* __restrict__ h, uint64_t ne, const u256* __restrict__ t, uint32_t period_mask) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -630,6 +612,11 @@ __global__ __launch_bounds__(256) void k_fill_rows(u256* __restrict__ cols, uint
   st256(cols + c * n + from + r, ld256(src + i));
 }
 // acc += a * x, coefficient by coefficient (the scaled sums of SHPLONK's linearisation polynomial)
+// out[i] = src[idx[i]]: the cells a circuit makes public, read out of the witness stream in instance order
+__global__ __launch_bounds__(256) void k_gather_fr(const u256* __restrict__ src, const int64_t* __restrict__ idx, uint64_t n, u256* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st256(out + i, ld256(src + idx[i]));
+}
 __global__ __launch_bounds__(256) void k_poly_axpy(u256* __restrict__ acc, u256 a, const u256* __restrict__ x, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -710,21 +697,6 @@ int vdb_gate_eval_sub_dev(const vdb_fr* adv_ext_dev, uint32_t adv_ext_k, const v
 }
 int vdb_gate_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
   return vdb_gate_eval_sub_dev(adv_ext_dev, ext_k, sel_ext_dev, n_cols, k, ext_k, y, acc_dev);
-}
-int vdb_const_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* qc_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* y, vdb_fr* acc_dev) {
-  VDB_REQUIRE_INIT();
-  VDB_ARG(adv_ext_dev && qc_ext_dev && y && acc_dev && k + ext_k <= 28, "bad argument");
-  if (n_cols == 0) return VDB_OK;
-  u256 yv;
-  memcpy(&yv, y, 32);
-  const uint64_t ne = 1ull << (k + ext_k);
-  {
-    VDB_PROF("k_const_eval");
-    hipLaunchKernelGGL(k_const_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(adv_ext_dev), as_u256(qc_ext_dev), (uint64_t)n_cols,
-                       k + ext_k, fr_mul(yv, host_fr_from_u64(32)), as_u256(acc_dev));
-  }
-  VDB_LAUNCH_CHECK();
-  return VDB_OK;
 }
 int vdb_divide_by_vanishing_dev(vdb_fr* h_ext_dev, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();
@@ -1092,6 +1064,17 @@ int vdb_fill_rows_dev(vdb_fr* cols_dev, size_t n_cols, size_t n, size_t from_row
   return VDB_OK;
 }
 
+int vdb_gather_fr_dev(const vdb_fr* src_dev, const int64_t* idx_dev, size_t n, vdb_fr* out_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(n == 0 || (src_dev && idx_dev && out_dev), "bad argument");
+  if (n == 0) return VDB_OK;
+  {
+    VDB_PROF("k_gather_fr");
+    hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(src_dev), idx_dev, (uint64_t)n, as_u256(out_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
 int vdb_poly_axpy_dev(vdb_fr* acc_dev, const vdb_fr* a, const vdb_fr* x_dev, size_t n) {
   VDB_REQUIRE_INIT();
   VDB_ARG(acc_dev && a && x_dev, "null pointer");

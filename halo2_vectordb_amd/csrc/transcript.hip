@@ -271,6 +271,15 @@ int vdb_transcript_common_points(vdb_transcript* tr, const vdb_g1* p, size_t n) 
   return VDB_OK;
 }
 
+int vdb_transcript_common_scalars(vdb_transcript* tr, const vdb_fr* s, size_t n) {
+  VDB_ARG(tr && (s || n == 0), "null pointer");
+  for (size_t i = 0; i < n; i++) {
+    int rc = vdb_transcript_common_scalar(tr, s + i);
+    if (rc) return rc;
+  }
+  return VDB_OK;
+}
+
 int vdb_transcript_squeeze(vdb_transcript* tr, vdb_fr* out) {
   VDB_ARG(tr && out, "null pointer");
   const size_t n = tr->buf.size();

@@ -131,7 +131,7 @@ def read_snark(path):
 
 
 # ---------------------------------------------------------------- verifying key file (the reference writes data/{name}.vk, src/scaffold/mod.rs:276-281)
-VK_FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")
+VK_FIXED = ("sel", "sigma", "cst", "table", "lag")
 
 
 def write_verifying_key(path, meta, fixed):
@@ -156,10 +156,10 @@ def read_verifying_key(path):
         for key in ("delta", "tau", "vk_digest"):
             if key in meta:
                 meta[key] = int(meta[key])
-        meta["instance_pos"] = [tuple(int(x) for x in p) for p in meta["instance_pos"]]
+        meta["n_instances"] = int(meta["n_instances"])
         if "opened" in meta:
             meta["opened"] = {int(rot): list(names) for rot, names in meta["opened"].items()}
-        shape = (meta["n_adv"], meta["n_cols"] + 1, 1, 1, 3, len(meta["instance_pos"]))
+        shape = (meta["n_adv"], meta["n_cols"] + 2, 1, 1, 3)     # sigma: advice, lookup, the constants' column, the instance column
     except (KeyError, TypeError, ValueError) as e:
         raise ValueError(f"verifying key: bad description: {e}") from e
     if tuple(len(fixed[name]) for name in VK_FIXED) != shape:

@@ -301,11 +301,12 @@ class KmeansHotPath:
         # The extended cosets, last: all of them when they fit beside everything above and leave the MSM its work space (C4:
         # 68 GB), otherwise the largest block of columns that does — the cosets are then produced block after block into the
         # same buffer (a circuit larger than HBM streams through: C4' cosine, 20.3 k columns = 170 GB of cosets; C5's Merkle).
-        # One column more than this rank holds: the prover rounds keep the coset of the constants' fixed column behind the
-        # advice cosets, so that the permutation argument reads its columns from one contiguous block (rounds.py).
+        # Two columns more than this rank holds: the prover rounds keep the cosets of the constants' fixed column and of the
+        # instance column behind the advice cosets, so that the permutation argument reads its columns from one contiguous
+        # block (rounds.py).
         check(lib.vdb_scratch_release())
         per_col = self.rows * 4 * B
-        want = max(self.my_cols, 1) + 1
+        want = max(self.my_cols, 1) + 2
         if self.ext_block_cols is None:
             free, _ = api.mem_info()
             fit = (free - self.ext_reserve_bytes) // per_col
@@ -390,11 +391,12 @@ class KmeansHotPath:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
     # ------------------------------------------------------------------ one pass of the hot path
-    def step(self, timings=None, blind_seed=None, with_ext=True, sync=True):
+    def step(self, timings=None, blind_seed=None, with_ext=True, sync=True, after_witness=None):
         """`with_ext`: False leaves coeff_to_extended out (a caller that streams the cosets itself, block by block: rounds.py on
         circuits whose cosets do not fit HBM).  `sync`: False returns as soon as the commitments are on the host, the transforms
         still running on the library's stream (the caller absorbs the commitments into its transcript meanwhile; everything it
-        queues next is ordered behind them)."""
+        queues next is ordered behind them).  `after_witness`: called once the witness kernels are queued and before the
+        commitments are (the prover rounds read the public cells out of the stream there)."""
         lib, B = self.lib, 32
         self.refresh_blinds(blind_seed)
 
@@ -406,6 +408,8 @@ class KmeansHotPath:
                 timings[name] = timings.get(name, 0.0) + api.timer_stop()
 
         stage("witness", self._witness)
+        if after_witness is not None:
+            after_witness()
 
         virt = self.virtual_layout and self.k > 10
         if not virt:

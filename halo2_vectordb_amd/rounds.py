@@ -3,10 +3,15 @@ k-means hot path leaves resident: lookup permutation -> products -> quotient -> 
 step on the GPU, nothing but commitments, evaluations and challenges crossing the C ABI.
 
 The circuit proved is the reference's circuit: the vertical gate on every gate row, every lookup cell in the range table,
-and the permutation argument over the advice columns, the lookup columns and ONE fixed column of constants, with every copy
-halo2-base records while the closure runs — `Existing` cells, `Constant` cells (tied to the fixed column), constrain_equal /
-assert_is_const, the lookup cells (copies of advice cells), the overlap cell the column layout duplicates — taken from the
-circuit's symbolic map (circuit_sym.py for the fixed-point gadgets, copymap.py for the Merkle circuit).
+and the permutation argument over the advice columns, the lookup columns, ONE fixed column of constants and ONE instance
+column, with every copy halo2-base records while the closure runs — `Existing` cells, `Constant` cells (tied to the fixed
+column), constrain_equal / assert_is_const, the lookup cells (copies of advice cells), the overlap cell the column layout
+duplicates — taken from the circuit's symbolic map (circuit_sym.py for the fixed-point gadgets, copymap.py for the Merkle
+circuit), and every cell the closure pushes into `make_public` tied to its row of the instance column
+(RangeWithInstanceCircuitBuilder, /root/reference/src/scaffold/mod.rs:400; the values are circuit.instances(), :265): the
+centroids for k-means (examples/kmeans.rs:51-56), the result vector for nearest_vector (examples/query.rs:58), the root for
+the Merkle circuit (examples/merkle.rs:47).  The instance polynomial is not committed: prover and verifier both make it from
+the public values, which enter the transcript first (halo2's KZG provers: QUERY_INSTANCE = false, [UPSTREAM-RECALL]).
 What this is not: halo2's exact proof layout (the order of terms and challenges is recalled, [UPSTREAM-RECALL]; the
 Fiat–Shamir transcript is the library's own, vdb_transcript_*; the multi-open is SHPLONK, or one quotient per rotation point
 with multiopen="gwc"); the order of the quotient's terms follows plonk/evaluation.rs as recalled ([UPSTREAM-RECALL]; parity
@@ -26,7 +31,7 @@ from ._lib import check
 from .pipeline import N_BLIND
 
 B = 32
-FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")     # the fixed polynomials, in the order the transcript absorbs their commitments
+FIXED = ("sel", "sigma", "cst", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
 GATE_EXT_K = 1   # the vertical gate q (a + b c - d) has degree 3: its share of the quotient is determined on the coset of 2 n points
@@ -107,7 +112,7 @@ class ProverRounds:
         self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
         self.usable = hp.rows - N_BLIND
         self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
-        self.n_perm = self.n_cols + 1                # the permutation argument's columns: advice, lookup, and the constants' fixed column
+        self.n_perm = self.n_cols + 2                # the permutation argument's columns: advice, lookup, the constants' fixed column, the instance column
         self.n_sets = -(-self.n_perm // CHUNK_LEN)
         self.delta = api.fr_delta()
         self.fixed = {}
@@ -196,21 +201,24 @@ class ProverRounds:
                 c = api.fr_to_canonical(hp.d_stream.download((hi - lo, 4), offset=lo * B))
                 return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in c]
             cm, self.root_cell = merkle_circuit_map(hp.n, hp.dim, flags, fetch)
+            self.public_cells = [int(self.root_cell)]                               # examples/merkle.rs:47 make_public.push(root)
             return cm
         from . import circuit_sym as CS
         if isinstance(hp, NearestHotPath):
-            cm, _ = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L)
+            cm, (_ind, res) = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L)
+            self.public_cells = [int(c) for c in res]                               # examples/query.rs:58 make_public.extend(result)
         else:
-            cm, _ = CS.build_kmeans(hp.metric_name, hp.n, hp.dim, hp.K, hp.I, hp.P, hp.L)
+            cm, (cent, _ind) = CS.build_kmeans(hp.metric_name, hp.n, hp.dim, hp.K, hp.I, hp.P, hp.L)
+            self.public_cells = [int(c) for c in np.asarray(cent).reshape(-1)]      # examples/kmeans.rs:51-56: every centroid, word by word
         return cm
 
     def keygen(self, circuit=None, instance_cells=None, check=True):
         """The Keygen arm's work for the rounds (src/scaffold/mod.rs:267-283 -> keygen_vk / keygen_pk): gate selectors, the
         permutation (sigma columns) from the circuit's constraint map, the constants' fixed column, the range table.
         `circuit`: a circuit_sym.CopyMap over the stream cells; None = the map of the gadget this hot path runs (circuit_map).
-        `instance_cells`: stream cells whose values are public inputs of the statement (for the Merkle circuit: the root
-        cell).  Each gets a fixed Lagrange polynomial L of its (column, row) and the term L (a - value) in the quotient — the
-        value enters the transcript and the verifier's identity; halo2 would tie the cell to an instance column instead.
+        `instance_cells`: the stream cells the closure makes public, in `make_public` order; cell i is tied to row i of the
+        instance column by a copy constraint (src/scaffold/mod.rs:400).  None = what the reference's example of this gadget
+        exposes (circuit_map: centroids / result vector / root) when the map is the gadget's own, nothing for a map handed in.
         `check`: run the device-side MockProver on the keygen witness with the whole map (vdb_mock_check_dev); the report is
         kept in self.keygen_report (a circuit the witness does not satisfy can still be set up — the proof will not verify)."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
@@ -220,7 +228,13 @@ class ProverRounds:
         # gate selectors from a flag-recording witness run
         d_flags = hp.keygen_flags()
         from ._lib import check as _chk     # (`check` is this method's flag)
+        self.public_cells = []
         cm = circuit if circuit is not None else self.circuit_map(d_flags)
+        if instance_cells is None:
+            instance_cells = self.public_cells
+        self.instance_cells = [int(c) for c in instance_cells]
+        if len(self.instance_cells) > self.usable or any(not 0 <= c < hp.n_cells for c in self.instance_cells):
+            raise ValueError("public cells outside the stream, or more of them than usable rows of the instance column")
         if cm.n_cells != hp.n_cells or (cm.lookup_src is not None and len(cm.lookup_src) != hp.n_lookup):
             raise ValueError("the constraint map does not describe this circuit (cell counts differ)")
         self.circuit = cm
@@ -229,7 +243,7 @@ class ProverRounds:
             raise ValueError("more distinct constants than usable rows of the fixed column")
         if check:
             self.keygen_report = self.mock_check(d_flags)
-        # sigma columns over [advice | lookup | constants]: the cycles of the copy classes, built on the device
+        # sigma columns over [advice | lookup | constants | instance]: the cycles of the copy classes, built on the device
         # (vdb_permutation_mapping_dev: pointer jumping, one radix sort; copymap.mapping_from_copy_of is the host restatement
         # the tests compare it with).  A map without lookup sources leaves the lookup columns untied: only the tests' negative
         # cases want that.
@@ -249,9 +263,11 @@ class ProverRounds:
             d_lsrc.upload(np.ascontiguousarray(cm.lookup_src, dtype=np.int64))
         d_map = api.DeviceBuffer(self.n_perm * rows * 8)
         bp64 = np.ascontiguousarray(hp.bp, dtype=np.uint64)
+        self._upload_instance_cells()
         _chk(lib.vdb_permutation_mapping_dev(d_parent.ptr, ctypes.c_uint64(hp.n_cells), ctypes.c_uint64(len(self.consts)), api._p(bp64), ctypes.c_uint64(len(bp64)), k,
                                              d_lsrc.ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
-                                             ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols), d_map.ptr))
+                                             ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols),
+                                             self.d_inst_cells.ptr, ctypes.c_uint64(len(self.instance_cells)), d_map.ptr))
         d_parent.free()
         if d_lsrc is not None:
             d_lsrc.free()
@@ -261,7 +277,7 @@ class ProverRounds:
         # the mapping stays with the key in 32 bits per cell when column and row fit: the product round makes the sigma columns'
         # Lagrange form from it (one product per cell) instead of transforming their coefficient form back
         self.d_map32 = None
-        if max(self.n_perm - 1, 1).bit_length() + k <= 32 and getattr(self, "keep_packed_mapping", True):
+        if (self.n_perm - 1).bit_length() + k <= 32 and getattr(self, "keep_packed_mapping", True):
             self.d_map32 = api.DeviceBuffer(self.n_perm * rows * 4)
             _chk(lib.vdb_permutation_mapping_pack_dev(d_map.ptr, _sz(self.n_perm), k, self.d_map32.ptr))
             api.sync()
@@ -281,8 +297,9 @@ class ProverRounds:
         d_cst = api.DeviceBuffer(rows * B)
         d_cst.upload(cst)
         self._fixed_poly("cst", d_cst, 1)
-        # its coset sits behind the advice cosets (the permutation term of the quotient reads one contiguous block of columns)
-        if hp.ext_cols >= self.n_cols + 1:
+        # its coset sits behind the advice cosets, the instance column's behind it (the permutation term of the quotient reads one
+        # contiguous block of columns)
+        if hp.ext_cols >= self.n_cols + 2:
             _chk(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
@@ -296,25 +313,20 @@ class ProverRounds:
         d_l = api.DeviceBuffer(lag.nbytes)
         d_l.upload(lag)
         self._fixed_poly("lag", d_l, 3)
-        if instance_cells is None:
-            instance_cells = [self.root_cell] if getattr(self, "root_cell", None) is not None else []
-        starts = np.concatenate([[0], np.cumsum(np.asarray(hp.bp, dtype=np.int64))])
-        self.instance_cells = [int(c) for c in instance_cells]
-        self.instance_pos = []
-        inst = np.zeros((max(len(self.instance_cells), 1), rows, 4), dtype=np.uint64)
-        for i, cell in enumerate(self.instance_cells):
-            col = int(np.searchsorted(starts, cell, side="right") - 1)
-            self.instance_pos.append((col, cell - int(starts[col])))
-            inst[i, cell - int(starts[col])] = one
-        d_i = api.DeviceBuffer(inst.nbytes)
-        d_i.upload(inst)
-        self._fixed_poly("inst", d_i, len(self.instance_cells))
         api.sync()
         return self._alloc_working_set()
 
-    def mock_check(self, d_flags=None):
+    def _upload_instance_cells(self):
+        cells = np.asarray(self.instance_cells, dtype=np.int64)
+        self.d_inst_cells = api.DeviceBuffer(max(cells.nbytes, 32))
+        if cells.nbytes:
+            self.d_inst_cells.upload(cells)
+
+    def mock_check(self, d_flags=None, instances=None):
         """The Mock stage on the witness in HBM with this circuit's whole constraint map (vdb_mock_check_dev): gate rows, the
-        range table, every copy, every lookup source, every constant and asserted constant.  api.MockReport."""
+        range table, every copy, every lookup source, every constant and asserted constant — and, with `instances` (canonical
+        integers, one per public cell: MockProver::run's third argument), every public cell against the value claimed for it.
+        api.MockReport."""
         hp = self.hp
         cm = self.circuit
         own = d_flags is None
@@ -338,8 +350,16 @@ class ProverRounds:
             if len(cm.consts):
                 tab[: len(cm.consts)] = api.fr_from_canonical(np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in cm.consts], dtype=np.uint64))
             d_tab = dev(tab, np.uint64)
-            return api.mock_check_dev(hp.d_stream.ptr, hp.n_cells, d_flags.ptr, hp.d_lookup.ptr, hp.n_lookup, hp.L, d_copy.ptr,
-                                      None if d_lsrc is None else d_lsrc.ptr, None, d_cidx.ptr, d_tab.ptr, len(cm.consts))
+            rep = api.mock_check_dev(hp.d_stream.ptr, hp.n_cells, d_flags.ptr, hp.d_lookup.ptr, hp.n_lookup, hp.L, d_copy.ptr,
+                                     None if d_lsrc is None else d_lsrc.ptr, None, d_cidx.ptr, d_tab.ptr, len(cm.consts))
+            if instances is not None:
+                if len(instances) != len(self.instance_cells):
+                    raise ValueError("one value per public cell")
+                vals = np.zeros((max(len(instances), 1), 4), dtype=np.uint64)
+                if len(instances):
+                    vals[: len(instances)] = np.stack([_fr_from_int(int(v)) for v in instances])
+                api.mock_check_instances_dev(rep, hp.d_stream.ptr, hp.n_cells, dev(self.instance_cells, np.int64).ptr, dev(vals, np.uint64).ptr, len(instances))
+            return rep
         finally:
             for b in bufs:
                 b.free()
@@ -366,6 +386,10 @@ class ProverRounds:
         self.d_h, self.d_h2, self.d_h3, self.d_h4 = (api.DeviceBuffer(self.ne * B) for _ in range(4))
         self.d_hg = api.DeviceBuffer((rows << GATE_EXT_K) * B)      # the gates' accumulator, on the coset of 2 n points
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
+        # the instance column: Lagrange form (the public values in rows 0 .. n_instances - 1, zero below), coefficients, coset —
+        # made anew for every proof from the values of the statement
+        self.d_inst_lag, self.d_inst_coeff, self.d_inst_ext = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B), api.DeviceBuffer(self.ne * B)
+        check(lib.vdb_memset_dev(self.d_inst_lag.ptr, 0, _sz(rows * B)))
         self._vk_digest = None
         self.vk_digest()            # part of the key, made here so that no proof pays for it
         return self
@@ -379,7 +403,7 @@ class ProverRounds:
         — when a proof's `opened` map is given — which polynomial is opened at which rotation.  io.read_verifying_key reads it."""
         from .io import write_verifying_key
         meta = dict(rows=self.rows, k=self.k, n_adv=self.n_adv, n_lk=self.n_lk, n_cols=self.n_cols, n_sets=self.n_sets, chunk_len=CHUNK_LEN,
-                    n_blind=N_BLIND, delta=str(_fr_to_int(self.delta)), instance_pos=[list(p) for p in self.instance_pos], tau=str(self.hp.tau),
+                    n_blind=N_BLIND, delta=str(_fr_to_int(self.delta)), n_instances=len(self.instance_cells), tau=str(self.hp.tau),
                     vk_digest=str(_fr_to_int(self.vk_digest())))
         if opened is not None:
             meta["opened"] = {str(rot): list(names) for rot, names in opened.items()}
@@ -393,7 +417,6 @@ class ProverRounds:
         api.sync()
         doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, CHUNK_LEN, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
         doc["instance_cells"] = np.asarray(self.instance_cells, dtype=np.int64)
-        doc["instance_pos"] = np.asarray(self.instance_pos, dtype=np.int64).reshape(-1, 2)
         for name, q in self.fixed.items():
             doc[name + "_coeff"] = q.coeff.download((max(q.n_cols, 1), self.rows, 4))
             doc[name + "_commits"] = q.commits
@@ -412,13 +435,8 @@ class ProverRounds:
             self.srs_few = api.Srs(k, hp.g_monomial, None)
             omega = api.root_of_unity(k)
             for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("sigma", self.n_perm, False, False), ("cst", 1, True, True),
-                                                     ("table", 1, True, True), ("lag", 3, False, True), ("inst", None, False, True)):
+                                                     ("table", 1, True, True), ("lag", 3, False, True)):
                 coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
-                if n_cols is None:                      # instance cells: their number and positions come with the key
-                    self.instance_cells = [int(c) for c in doc["instance_cells"]]
-                    self.instance_pos = [(int(c), int(r)) for c, r in doc["instance_pos"]]
-                    n_cols = len(self.instance_cells)
-                    coeff_h = coeff_h[:n_cols]
                 if coeff_h.shape != (n_cols, rows, 4):
                     raise ValueError("proving key: wrong shape for " + name)
                 coeff = api.DeviceBuffer(max(coeff_h.nbytes, 32))
@@ -431,7 +449,9 @@ class ProverRounds:
                     check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
                 self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None,
                                          commits=np.ascontiguousarray(doc[name + "_commits"]))
-        if hp.ext_cols >= self.n_cols + 1:
+            self.instance_cells = [int(c) for c in doc["instance_cells"]]      # the public cells come with the key
+        self._upload_instance_cells()
+        if hp.ext_cols >= self.n_cols + 2:
             check(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         api.sync()
         return self._alloc_working_set()
@@ -445,8 +465,9 @@ class ProverRounds:
         pieces -> x; all evaluations, rotation by rotation -> then the multi-open: "gwc": v, one quotient per rotation
         point; "shplonk" (what the reference's gen_snark_shplonk runs, [UPSTREAM-RECALL] for the order of its challenges):
         yo, v; the quotient f of all rotation sets; u; the quotient of the linearisation polynomial.
-        `instances`: the public values of keygen's instance cells (Montgomery field elements); None = read from the witness
-        this proof commits to (the honest prover's statement).
+        `instances`: the public values, one per public cell of keygen (Montgomery field elements); None = read from the witness
+        this proof commits to (the honest prover's statement: circuit.instances(), src/scaffold/mod.rs:265).  They fill rows
+        0 .. of the instance column, which the permutation argument ties to the public cells.
         Returns dict(commitments, evals, openings, points, proof, instances): commitments[name] (n, 8); evals[(name, rotation)] list
         of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W).
         `seed`: None = every blinding scalar of this proof (advice, lookup and product columns) comes fresh from the
@@ -490,16 +511,37 @@ class ProverRounds:
             return r
 
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
-        resident = hp.ext_cols >= n_cols + 1       # every advice coset stays in HBM; otherwise they are recomputed block by block below
+        resident = hp.ext_cols >= n_cols + 2       # every advice coset stays in HBM; otherwise they are recomputed block by block below
+        ni = len(self.instance_cells)
+        given = None if instances is None else np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.uint64) for v in instances]).reshape(-1, 4) if ni else np.zeros((0, 4), np.uint64))
+        assert given is None or len(given) == ni, "one value per public cell"
+        inst_host = np.zeros((max(ni, 1), 4), dtype=np.uint64)
+
+        def public_values():
+            # rows 0 .. ni - 1 of the instance column <- the public cells of the witness just generated (or the values of the
+            # statement handed in); the values are needed on the host before the advice commitments enter the transcript, so they
+            # are read here, behind the witness kernels only, and not behind the transforms queued next
+            if not ni:
+                return
+            if given is None:
+                check(lib.vdb_gather_fr_dev(hp.d_stream.ptr, self.d_inst_cells.ptr, _sz(ni), self.d_inst_lag.ptr))
+                check(lib.vdb_memcpy_d2h(api._p(inst_host), self.d_inst_lag.ptr, _sz(ni * B)))
+            else:
+                inst_host[:ni] = given
+                check(lib.vdb_memcpy_h2d(self.d_inst_lag.ptr, api._p(inst_host), _sz(ni * B)))
         # (the transforms of the advice columns are still running when step returns: the commitments are absorbed meanwhile)
-        adv_commits = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False).copy()
-        if instances is None:
-            instances = [hp.d_stream.download((4,), offset=cell * 32) for cell in self.instance_cells]
-        instances = [np.ascontiguousarray(v, dtype=np.uint64) for v in instances]
-        assert len(instances) == len(self.instance_cells)
-        if tr is not None:
-            for v in instances:
-                tr.common_scalar(v)
+        adv_commits = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False, after_witness=public_values).copy()
+        instances = [inst_host[i].copy() for i in range(ni)]
+        # the instance polynomial in the forms the rounds read (one column: queued behind the advice transforms)
+        check(lib.vdb_memcpy_d2d(self.d_inst_coeff.ptr, self.d_inst_lag.ptr, _sz(rows * B)))
+        check(lib.vdb_lagrange_to_coeff_dev(self.d_inst_coeff.ptr, _sz(1), k))
+        check(lib.vdb_coeff_to_extended_dev(self.d_inst_coeff.ptr, self.d_inst_ext.ptr, _sz(1), k, EXT_K))
+        if resident:
+            check(lib.vdb_memcpy_d2d(hp.d_ext.at((n_cols + 1) * ne * B), self.d_inst_ext.ptr, _sz(ne * B)))
+        if tr is not None and ni:
+            t0 = time.perf_counter()
+            tr.common_scalars(inst_host[:ni])
+            host["transcript"] += (time.perf_counter() - t0) * 1e3
         write_points(adv_commits)
         squeeze("theta")
         adv = _Poly("adv", n_cols, coeff=hp.d_cols, commits=adv_commits)
@@ -519,15 +561,16 @@ class ProverRounds:
         lk_blind = hp.d_blind.at(hp.n_adv_cols * N_BLIND * B)
 
         def lagrange_block(c0, nb, dest):
-            """the permutation's columns c0 .. c0 + nb in Lagrange form: advice from the stream, lookup from their laid-out copy, constants"""
+            """the permutation's columns c0 .. c0 + nb in Lagrange form: advice from the stream, lookup from their laid-out copy, constants, instances"""
             a1, l0_, l1_ = min(c0 + nb, n_adv), max(c0, n_adv), min(c0 + nb, n_cols)
             if c0 < a1:
                 check(lib.vdb_layout_columns_range_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), bp_p, n_bp, k, ctypes.c_uint64(c0), ctypes.c_uint64(a1),
                                                        dest.ptr, hp.d_blind.ptr, N_BLIND))
             if l0_ < l1_:
                 check(lib.vdb_memcpy_d2d(dest.at((l0_ - c0) * rows * B), d_lklag.at((l0_ - n_adv) * rows * B), _sz((l1_ - l0_) * rows * B)))
-            if c0 + nb > n_cols:
-                check(lib.vdb_memcpy_d2d(dest.at((n_cols - c0) * rows * B), fx["cst"].lag.ptr, _sz(rows * B)))
+            for col, src in ((n_cols, fx["cst"].lag), (n_cols + 1, self.d_inst_lag)):
+                if c0 <= col < c0 + nb:
+                    check(lib.vdb_memcpy_d2d(dest.at((col - c0) * rows * B), src.ptr, _sz(rows * B)))
 
         def adv_ext_block(c0, nb):
             """(pointer, first column) of a buffer that holds the cosets of the permutation's columns c0 .. c0 + nb"""
@@ -536,8 +579,9 @@ class ProverRounds:
             n_real = max(0, min(c0 + nb, n_cols) - c0)
             if n_real:
                 check(lib.vdb_coeff_to_extended_dev(hp.d_cols.at(c0 * rows * B), d_ea.ptr, _sz(n_real), k, EXT_K))
-            if c0 + nb > n_cols:
-                check(lib.vdb_memcpy_d2d(d_ea.at(n_real * ne * B), fx["cst"].ext.ptr, _sz(ne * B)))
+            for col, src in ((n_cols, fx["cst"].ext), (n_cols + 1, self.d_inst_ext)):
+                if c0 <= col < c0 + nb:
+                    check(lib.vdb_memcpy_d2d(d_ea.at((col - c0) * ne * B), src.ptr, _sz(ne * B)))
             return d_ea.ptr, c0
 
         def col_ptr(base, col0, c):
@@ -612,17 +656,18 @@ class ProverRounds:
             check(lib.vdb_coeff_to_extended_dev(coeff_ptr, dest_ptr, _sz(m), k, EXT_K))
 
         def quotient():
-            # The numerator is sum_i term_i y^(N-1-i) over the terms in halo2's order: gates (one per advice column), public inputs,
+            # The numerator is sum_i term_i y^(N-1-i) over the terms in halo2's order: gates (one per advice column),
             # the permutation argument (two terms of the product columns alone, the chaining of the sets, one product term per set),
             # the lookup argument (five per lookup column).  Each group is folded into an accumulator of its own (acc <- acc y +
             # term, from zero) while ONE sweep over blocks of columns produces every coset once — the advice / lookup / constants
             # cosets (unless resident), selectors, sigma, product and lookup-argument cosets — and the groups are joined at the end:
-            # h = (((Ag y^ni + A1) y^n2 + A2) y^n3 + A3) y^n4 + A4.
+            # h = ((Ag y^n2 + A2) y^n3 + A3) y^n4 + A4.  (The public inputs have no term of their own: the instance column is one
+            # of the permutation's columns.)
             # The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on the
             # coset of 2 n points inside the 4 n (every second point of the advice cosets; the selector cosets are made for 2 n
             # points only: half the transform), divided and brought back to coefficients there, and joined in coefficient form.
-            ag, a1, a2, a3, a4 = self.d_hg, d_h, self.d_h2, self.d_h3, self.d_h4
-            for a in (a1, a2, a3, a4):
+            ag, a2, a3, a4 = self.d_hg, self.d_h2, self.d_h3, self.d_h4
+            for a in (a2, a3, a4):
                 check(lib.vdb_memset_dev(a.ptr, 0, _sz(ne * B)))
             check(lib.vdb_memset_dev(ag.ptr, 0, _sz((rows << GATE_EXT_K) * B)))
             perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
@@ -657,16 +702,9 @@ class ProverRounds:
                     to_ext(polys["zl"].coeff.at(j0 * rows * B), d_eb.at(2 * third * ne * B), m)
                     check(lib.vdb_lookup_eval_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
                                                   _sz(m), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
-            # public inputs, group 1: h = h y + L (a_col - value) per instance cell, with the bricks at hand: (h y + L a) - value L
-            for i, (col, _row) in enumerate(self.instance_pos):
-                l_ext = fx["inst"].ext.at(i * ne * B)
-                base, col0 = adv_ext_block(col, 1)
-                check(lib.vdb_const_eval_dev(col_ptr(base, col0, col), l_ext, _sz(1), k, EXT_K, p["y"], a1.ptr))
-                check(lib.vdb_poly_axpy_dev(a1.ptr, api._p(_fr_from_int(-_fr_to_int(instances[i]))), l_ext, _sz(ne)))
             # join the groups that live on the 4 n points (acc_next += y^(terms of the next group) * acc), divide, back to coefficients
             y_int = _fr_to_int(ch["y"])
-            ni, n2, n3, n4 = len(self.instance_pos), 2 + (n_sets - 1), n_sets, 5 * n_lk
-            check(lib.vdb_poly_axpy_dev(a2.ptr, api._p(_fr_from_int(pow(y_int, n2, R_MOD))), a1.ptr, _sz(ne)))
+            n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
             check(lib.vdb_poly_axpy_dev(a3.ptr, api._p(_fr_from_int(pow(y_int, n3, R_MOD))), a2.ptr, _sz(ne)))
             check(lib.vdb_poly_axpy_dev(a4.ptr, api._p(_fr_from_int(pow(y_int, n4, R_MOD))), a3.ptr, _sz(ne)))
             check(lib.vdb_memcpy_d2d(d_h.ptr, a4.ptr, _sz(ne * B)))
@@ -675,7 +713,7 @@ class ProverRounds:
             # the gates' share: the same on the 2 n points, then h += y^(every later term) * (its 2 n coefficients)
             check(lib.vdb_divide_by_vanishing_dev(ag.ptr, k, GATE_EXT_K))
             check(lib.vdb_extended_to_coeff_dev(ag.ptr, _sz(1), k, GATE_EXT_K))
-            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, ni + n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
+            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
         stage("quotient", quotient)
         n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)))
@@ -685,7 +723,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "inst", "pa", "ps", "zp", "zl", "h"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
@@ -753,7 +791,7 @@ class ProverRounds:
             api.sync()
             return dict(commitments={name: q.commits for name, q in allp.items()}, evals=openings.pop("evals_int"), openings=openings, points=points,
                         proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened,
-                        instances=[_fr_to_int(v) for v in instances], instance_pos=list(self.instance_pos))
+                        instances=[_fr_to_int(v) for v in instances])
         squeeze("v")
 
         # round 6 (v): one opening per rotation point: combine with powers of v, divide by (X - point), commit
@@ -780,7 +818,7 @@ class ProverRounds:
         commitments = {name: q.commits for name, q in allp.items()}
         return dict(commitments=commitments, evals=_Evals(evals), openings=openings, points=points,
                     proof=proof, challenges={name: v.copy() for name, v in ch.items()}, opened=opened,
-                        instances=[_fr_to_int(v) for v in instances], instance_pos=list(self.instance_pos))
+                        instances=[_fr_to_int(v) for v in instances])
 
     # ------------------------------------------------------------------ SHPLONK multi-open (halo2 poly/kzg/multiopen/shplonk)
     def _shplonk(self, allp, opened, points, evals, p, ch, squeeze, write_points, stage):
@@ -901,7 +939,7 @@ class ProverRounds:
             q.free()
         self.fixed = {}
         self._vk_digest = None
-        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32"):
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32", "d_inst_lag", "d_inst_coeff", "d_inst_ext", "d_inst_cells"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()
@@ -910,6 +948,32 @@ class ProverRounds:
             if getattr(self, name, None) is not None:
                 getattr(self, name).free()
                 setattr(self, name, None)
+
+
+def instance_eval(instances, x, k):
+    """The instance polynomial at x from the public values alone (what a verifier does instead of reading an evaluation from the
+    proof): sum_i v_i L_i(x), L_i(x) = w^i (x^n - 1) / (n (x - w^i)) over the domain of 2^k rows.  Canonical integers."""
+    n = 1 << k
+    w = _fr_to_int(api.root_of_unity(k))
+    if not instances:
+        return 0
+    xn1 = (pow(x, n, R_MOD) - 1) % R_MOD
+    acc, wi = 0, 1
+    dens = []
+    for _ in instances:
+        dens.append((x - wi) % R_MOD)
+        wi = wi * w % R_MOD
+    # one inversion for all denominators
+    pref = [1]
+    for d in dens:
+        pref.append(pref[-1] * d % R_MOD)
+    inv = pow(pref[-1], -1, R_MOD)
+    wi_list = [pow(w, i, R_MOD) for i in range(len(instances))]
+    for i in range(len(instances) - 1, -1, -1):
+        di = inv * pref[i] % R_MOD
+        inv = inv * dens[i] % R_MOD
+        acc = (acc + int(instances[i]) * wi_list[i] % R_MOD * di) % R_MOD
+    return acc * xn1 % R_MOD * pow(n, -1, R_MOD) % R_MOD
 
 
 def quotient_identity_holds(pr, challenges, evals, instances=None):
@@ -924,11 +988,10 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     a0, a1, a2, a3, q = ev("adv"), ev("advg", 1), ev("advg", 2), ev("advg", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
-    for l_i, (col, _row), value in zip(ev("inst"), pr.instance_pos, instances if instances is not None else []):
-        acc = (acc * yv + l_i * (a0[col] - value)) % R
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
-    pcols = list(a0) + list(ev("cst"))                  # the permutation's columns: advice, lookup, the constants' fixed column
+    # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (evaluated from the public values)
+    pcols = list(a0) + list(ev("cst")) + [instance_eval(list(instances) if instances is not None else [], x, pr.k)]
     n_cols, n_sets = len(pcols), len(z0)
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R

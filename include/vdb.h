@@ -16,8 +16,9 @@
  *  - Every function returns 0 on success or a negative VDB_ERR_*; nothing aborts or throws across
  *    the ABI.  vdb_last_error() returns a thread-local message for the last failure.
  *  - Host pointers unless the name ends in _dev (then: device pointers in HBM of the bound GPU).
- *  - One process binds one GPU (vdb_init(device)); calls are not re-entrant per process, matching the
- *    reference's single prover thread.  Entry points with host outputs block until the result is there;
+ *  - A process binds one GPU (vdb_init(device): one process per GPU) or several (vdb_init_devices(n): one context per
+ *    device, the calling thread's device chosen with vdb_set_device).  Calls are not re-entrant per device context,
+ *    matching the reference's single prover thread.  Entry points with host outputs block until the result is there;
  *    _dev entry points only queue work on the library's stream (in order), and the vdb_msm_batch_*_begin /
  *    vdb_msm_batch_end pair is explicitly asynchronous (see there).  vdb_sync() waits for everything queued.
  */
@@ -387,14 +388,6 @@ int vdb_gate_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sel_ext_dev, size
  * vanishing polynomial on the small coset, returns to coefficients there and adds them to the quotient's. */
 int vdb_gate_eval_sub_dev(const vdb_fr *adv_ext_dev, uint32_t adv_ext_k, const vdb_fr *sel_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k,
                           const vdb_fr *y, vdb_fr *acc_dev);
-/* Constant cells as a gate: per advice column the fixed polynomials qc (one on the rows that hold a QuantumCell::Constant) and
- * fc (the constant on those rows, zero elsewhere) with qc(X) a(X) - fc(X) = 0 on the domain.  This call folds the qc part into
- * the accumulator: acc[j] <- Horner over the columns of (acc * y + qc_c[j] * a_c[j]) on the extended coset.  The fc part is linear
- * in the fixed polynomials: the caller combines the fc coefficients with the same powers of y (vdb_poly_lincomb_dev), extends
- * that one polynomial (vdb_coeff_to_extended_dev) and subtracts it (vdb_poly_axpy_dev with -1) right after the last block.
- * (halo2-base ties constants to a fixed column through the permutation argument instead; this build states the same fact —
- * the cell holds that constant — as a degree-2 gate.) */
-int vdb_const_eval_dev(const vdb_fr *adv_ext_dev, const vdb_fr *qc_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *y, vdb_fr *acc_dev);
 /* EvaluationDomain::divide_by_vanishing_poly: h[j] /= (X^n - 1) at the j-th point of the extended coset, in place. */
 int vdb_divide_by_vanishing_dev(vdb_fr *h_ext_dev, uint32_t k, uint32_t ext_k);
 /* column-layout image of the gate selectors as field elements (keygen side; flags as for vdb_layout_const_mask_dev, bit 0):
@@ -421,6 +414,8 @@ int vdb_transcript_write_point(vdb_transcript *tr, const vdb_g1 *p);
 int vdb_transcript_write_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
 int vdb_transcript_write_scalars(vdb_transcript *tr, const vdb_fr *s, size_t n);
 int vdb_transcript_common_points(vdb_transcript *tr, const vdb_g1 *p, size_t n);
+/* the public inputs of a proof: halo2's create_proof absorbs every instance value with common_scalar before anything else */
+int vdb_transcript_common_scalars(vdb_transcript *tr, const vdb_fr *s, size_t n);
 int vdb_transcript_squeeze(vdb_transcript *tr, vdb_fr *out);
 /* absorbs the complete RATE-sized chunks written so far (same state as leaving them to the next squeeze): lets a caller run the
  * sponge's host work beside device work that is already queued */
@@ -434,10 +429,16 @@ int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t ca
  *      n_cells + r: row r of the constants' fixed column (QuantumCell::Constant, assert_is_const); OVERWRITTEN with the roots.
  *      break_points (host): rows per advice column as vdb_layout_plan gives them; lookup_src_dev[j]: the advice cell lookup cell
  *      j copies (lookup cell j sits at row j % lookup_rows of column n_adv + j / lookup_rows).  n_cols = advice + lookup
- *      columns; the fixed column is column n_cols.  mapping_dev: (n_cols + 1) x 2^k words col << 32 | row, the input of
- *      vdb_permutation_sigma_dev. ------------------------------------------------------------------------------------ */
+ *      columns; the fixed column is column n_cols, the INSTANCE column is column n_cols + 1: instance_cells_dev[i] is the
+ *      stream cell the circuit makes public i-th (the closure's make_public vector, src/scaffold/mod.rs:378-400:
+ *      RangeWithInstanceCircuitBuilder ties assigned_instances[i] to row i of its one instance column), n_instances <= 2^k.
+ *      mapping_dev: (n_cols + 2) x 2^k words col << 32 | row, the input of vdb_permutation_sigma_dev. ------------------ */
 int vdb_permutation_mapping_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
-                                const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols, uint64_t *mapping_dev);
+                                const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
+                                const int64_t *instance_cells_dev, uint64_t n_instances, uint64_t *mapping_dev);
+/* out_dev[i] = src_dev[idx_dev[i]]: the public cells read out of the witness stream in instance order (what
+ * circuit.instances() returns, src/scaffold/mod.rs:265) without leaving HBM */
+int vdb_gather_fr_dev(const vdb_fr *src_dev, const int64_t *idx_dev, size_t n, vdb_fr *out_dev);
 
 /* ---- Mock stage: replaces MockProver::run(k, &circuit, instances).assert_satisfied() of the reference's Mock arm
  *      (src/scaffold/mod.rs:263-266): every gate row a + b c = d, every lookup cell against the range table, every copy
@@ -454,10 +455,15 @@ typedef struct {
   uint64_t copies_unequal, first_copy;
   uint64_t lookup_copies_unequal, first_lookup_copy;
   uint64_t constants_changed, first_constant;
+  uint64_t instances_unequal, first_instance; /* filled by vdb_mock_check_instances_dev only */
 } vdb_mock_report;
 int vdb_mock_check_dev(const vdb_fr *stream_dev, uint64_t n_cells, const uint8_t *flags_dev, const vdb_fr *lookup_dev, uint64_t n_lookup,
                        uint32_t lookup_bits, const int64_t *copy_of_dev, const int64_t *lookup_src_dev, const vdb_fr *const_stream_dev,
                        const int64_t *const_idx_dev, const vdb_fr *const_table_dev, uint64_t n_consts, vdb_mock_report *out);
+/* The `instances` argument of MockProver::run: stream cell instance_cells_dev[i] must hold instances_dev[i] (the copy between
+ * the cell and row i of the instance column).  Sets out->instances_unequal / first_instance and leaves the other fields alone. */
+int vdb_mock_check_instances_dev(const vdb_fr *stream_dev, uint64_t n_cells, const int64_t *instance_cells_dev, const vdb_fr *instances_dev,
+                                 uint64_t n_instances, vdb_mock_report *out);
 
 /* ---- b6 Poseidon: replaces poseidon::PoseidonChip<F,3,2> value semantics (T=3, RATE=2, R_F=8,
  *      R_P=57 as examples/merkle.rs:15-18; call sites src/gadget/vectordb.rs:180-182, 213-215) --- */

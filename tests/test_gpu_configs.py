@@ -279,7 +279,7 @@ def test_extended_cosets_in_column_blocks(api, O):
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     cfg = dict(n=14, dim=6, K=3, I=2, k=11, P=48, L=9, seed=11, blind_seed=8)
     full = KmeansHotPath(**cfg).setup()
-    assert full.ext_cols == full.n_cols + 1                      # everything fits: resident
+    assert full.ext_cols == full.n_cols + 2                      # everything fits: resident
     com = full.step().copy()
     ext_all = full.d_ext.download((full.n_cols, 4 * full.rows, 4))
     coeff = full.d_cols.download((full.n_cols, full.rows, 4))

@@ -157,6 +157,57 @@ def test_c2_nearest_64x128_proves_with_the_whole_map(api, O):
         bad = bytearray(out["proof"])
         bad[40] ^= 1
         assert not _verify(O, api, bytes(bad), vk)
+        # the statement: the nearest vector's 128 words are public (examples/query.rs:58), tied to the instance column
+        _ind, res = hp.results()
+        assert out["instances"] == O.fr_to_ints(res) and len(out["instances"]) == 128
+        other = list(out["instances"])
+        other[77] = (other[77] + 1) % O.R_MOD
+        assert not _verify(O, api, out["proof"], {**vk, "instances": other})
+    finally:
+        pr.free()
+        hp.free()
+
+
+def test_public_instances_bind_the_statement(api, O):
+    """What RangeWithInstanceCircuitBuilder adds to the reference's circuits (src/scaffold/mod.rs:400, :265): the cells the closure
+    pushes into make_public — the K x dim centroid words of examples/kmeans.rs:51-56 — are tied to an instance column.  An honest
+    proof verifies against the centroids the witness holds and against nothing else; the device MockProver takes the instances
+    (MockProver::run's third argument); a prover that claims other centroids than its witness computes cannot prove them."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    hp = KmeansHotPath(n=8, dim=4, K=2, I=2, k=12, L=11, metric="cosine", tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert len(pr.instance_cells) == 2 * 4 and pr.n_perm == pr.n_cols + 2
+        out = pr.prove(None, seed=21)
+        cent, _ind = hp.results()
+        want = O.fr_to_ints(cent.reshape(-1, 4))
+        assert out["instances"] == want                                   # row-major: every centroid, word by word
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert "inst" not in vk["fixed"] and all(name != "inst" for names in out["opened"].values() for name in names)
+        assert _verify(O, api, out["proof"], {**vk, "instances": want})
+        for i in (0, 5, 7):                                               # a changed centroid word: rejected
+            other = list(want)
+            other[i] = (other[i] + 1) % O.R_MOD
+            assert not _verify(O, api, out["proof"], {**vk, "instances": other})
+        assert not _verify(O, api, out["proof"], {**vk, "instances": want[:-1]})
+        assert not _verify(O, api, out["proof"], {**vk, "instances": want[1:] + want[:1]})      # the order is part of the statement
+        # the Mock stage with instances
+        assert pr.mock_check(instances=want).violations() == 0
+        other = list(want)
+        other[5] = (other[5] + 3) % O.R_MOD
+        rep = pr.mock_check(instances=other)
+        assert rep.instances_unequal == 1 and rep.first_instance == 5 and rep.violations() == 1
+        # a prover that states centroids its witness does not compute: the instance column no longer equals the public cells
+        lie = pr.prove(None, seed=22, instances=[O.fr_from_ints([v])[0] for v in other])
+        assert lie["instances"] == other
+        assert not quotient_identity_holds(pr, lie["challenges"], lie["evals"], other)
+        assert not _verify(O, api, lie["proof"], {**vk, "opened": lie["opened"], "instances": other})
+        assert not _verify(O, api, lie["proof"], {**vk, "opened": lie["opened"], "instances": want})
+        # and an honest proof again (the lie left nothing behind in the instance column)
+        again = pr.prove(None, seed=23)
+        assert _verify(O, api, again["proof"], {**vk, "opened": again["opened"], "instances": want})
     finally:
         pr.free()
         hp.free()
@@ -164,7 +215,8 @@ def test_c2_nearest_64x128_proves_with_the_whole_map(api, O):
 
 def test_device_permutation_mapping_has_the_cycles_of_the_host_construction(api, O):
     """vdb_permutation_mapping_dev (pointer jumping + radix sort on the device) against copymap.mapping_from_copy_of (numpy): both
-    are permutations of the (n_cols + 1) x rows grid with exactly the same classes — the order inside a cycle is free"""
+    are permutations of the (n_cols + 2) x rows grid ([advice | lookup | constants | instance]) with exactly the same classes —
+    the order inside a cycle is free; the rows of the instance column sit in the classes of the public cells"""
     from halo2_vectordb_amd.copymap import mapping_from_copy_of
     from halo2_vectordb_amd.pipeline import MINIMUM_ROWS, KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds
@@ -175,7 +227,9 @@ def test_device_permutation_mapping_has_the_cycles_of_the_host_construction(api,
     try:
         cm, rows, n_perm = pr.circuit, pr.rows, pr.n_perm
         dev = pr._d_map_for_tests.download((n_perm, rows), dtype=np.uint64)
-        host = mapping_from_copy_of(cm.copy_of, hp.bp, pr.n_cols, rows, cm.lookup_src, rows - MINIMUM_ROWS, const_idx=cm.const_idx, n_consts=len(cm.consts))
+        host = mapping_from_copy_of(cm.copy_of, hp.bp, pr.n_cols, rows, cm.lookup_src, rows - MINIMUM_ROWS, const_idx=cm.const_idx, n_consts=len(cm.consts),
+                                    instance_cells=pr.instance_cells)
+        assert len(pr.instance_cells) == 2 * 3 and dev.shape == host.shape
 
         def classes(mapping):
             nxt = ((mapping >> np.uint64(32)).astype(np.int64) * rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)).reshape(-1)
@@ -188,6 +242,12 @@ def test_device_permutation_mapping_has_the_cycles_of_the_host_construction(api,
                     return label
                 label = new
         assert np.array_equal(classes(dev), classes(host))
+        # row i of the instance column and the i-th public cell's grid position are in one class
+        starts = np.concatenate([[0], np.cumsum(np.asarray(hp.bp, dtype=np.int64))])
+        lab = classes(dev)
+        for i, cell in enumerate(pr.instance_cells):
+            col = int(np.searchsorted(starts, cell, side="right") - 1)
+            assert lab[(pr.n_cols + 1) * rows + i] == lab[col * rows + cell - int(starts[col])]
         assert (classes(dev) != np.arange(n_perm * rows)).mean() > 0.3
     finally:
         pr._d_map_for_tests.free()
@@ -210,7 +270,7 @@ def test_streamed_rounds_give_the_resident_proof(api, O):
         hp.setup()
         pr = ProverRounds(hp, block_cols=block_cols).keygen()
         try:
-            assert (hp.ext_cols >= hp.n_cols + 1) == (label == "resident") and pr.n_perm > 5 * 12
+            assert (hp.ext_cols >= hp.n_cols + 2) == (label == "resident") and pr.n_perm > 5 * 12
             out = pr.prove(None, seed=9)
             vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU),
                       instances=out["instances"])

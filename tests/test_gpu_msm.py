@@ -250,3 +250,88 @@ def test_multi_device_lifecycle_and_batches(api, O):
     finally:
         api.shutdown()
         api.init(0)
+
+
+def test_two_device_contexts_in_one_process(api, O):
+    """The n > 1 branch of the several-GPUs-in-one-process code (csrc/multi.hip for_each_device, per-device contexts and handles)
+    on a one-GPU box: the test-only switch VDB_TEST_ALIAS_DEVICES=2 binds the card as two logical devices with separate contexts —
+    streams, work space, twiddle tables, srs handles.  vdb_srs_load_all gives one handle per context; the *_multi entry points cut
+    the batch into two blocks driven by two host threads; a handle used on the other context is refused with VDB_ERR_ARG; two host
+    threads running the _dev pipeline (upload, commit, lagrange_to_coeff) concurrently on their own contexts give the
+    single-context result."""
+    import ctypes
+    import os
+    import threading
+    from halo2_vectordb_amd._lib import check
+    rng = np.random.default_rng(78)
+    k, n = 10, 1024
+    g, gl = O.srs_from_tau(k, 0x51DF)
+    cols = O.random_fr(rng, 7 * n).reshape(7, n, 4)
+    cols[2] = witness_like(O, rng, n)
+    want = O.msm_batch(cols, gl, threads=4)
+    lib = api._lib.init()
+    os.environ["VDB_TEST_ALIAS_DEVICES"] = "2"
+    try:
+        api.init_devices(2)
+        assert api.devices_bound() == 2 and api.current_device() == 0
+        with pytest.raises(api.VdbError):
+            api.set_device(2)                      # not bound
+        srs = api.SrsAll(k, g, gl)
+        assert srs.devices() == [0, 1]
+        assert np.array_equal(srs.msm_batch(cols), want)                               # blocks [0, 3) and [3, 7) on two contexts
+        assert np.array_equal(api.ntt_batch_multi(cols, api.root_of_unity(k)), O.ntt_batch(cols, O.root_of_unity(k), threads=2))
+        # a handle belongs to its context
+        out1 = np.zeros((1, 8), dtype=np.uint64)
+        ptrs = (ctypes.c_void_p * 1)(cols[0].ctypes.data)
+        api.set_device(1)
+        assert lib.vdb_msm_batch(srs.handles[0], 1, ptrs, ctypes.c_size_t(1), ctypes.c_size_t(n), api._p(out1)) == -3      # VDB_ERR_ARG
+        assert b"another device" in lib.vdb_last_error()
+        assert lib.vdb_msm_batch(srs.handles[1], 1, ptrs, ctypes.c_size_t(1), ctypes.c_size_t(n), api._p(out1)) == 0 and np.array_equal(out1[0], want[0])
+        api.set_device(0)
+        # two host threads, each on its own context, the device-resident pipeline concurrently
+        res, errs = {}, []
+
+        def worker(dev, lo, hi):
+            try:
+                api.set_device(dev)
+                m = hi - lo
+                for rep in range(3):
+                    buf = api.DeviceBuffer(m * n * 32)
+                    buf.upload(np.ascontiguousarray(cols[lo:hi]))
+                    com = np.zeros((m, 8), dtype=np.uint64)
+                    check(lib.vdb_msm_batch_dev(srs.handles[dev], 1, buf.ptr, ctypes.c_size_t(m), ctypes.c_size_t(n), api._p(com)))
+                    check(lib.vdb_lagrange_to_coeff_dev(buf.ptr, ctypes.c_size_t(m), ctypes.c_uint32(k)))
+                    res[(dev, rep)] = (com, buf.download((m, n, 4)))
+                    buf.free()
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        threads = [threading.Thread(target=worker, args=(0, 0, 4)), threading.Thread(target=worker, args=(1, 4, 7))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        srs.free()
+        api.shutdown()
+        del os.environ["VDB_TEST_ALIAS_DEVICES"]
+        # the single-context result
+        api.init(0)
+        single = api.Srs(k, g, gl)
+        buf = api.DeviceBuffer(7 * n * 32)
+        buf.upload(cols)
+        com = np.zeros((7, 8), dtype=np.uint64)
+        check(lib.vdb_msm_batch_dev(single.h, 1, buf.ptr, ctypes.c_size_t(7), ctypes.c_size_t(n), api._p(com)))
+        check(lib.vdb_lagrange_to_coeff_dev(buf.ptr, ctypes.c_size_t(7), ctypes.c_uint32(k)))
+        coeff = buf.download((7, n, 4))
+        buf.free()
+        single.free()
+        assert np.array_equal(com, want)
+        for rep in range(3):
+            assert np.array_equal(np.concatenate([res[(0, rep)][0], res[(1, rep)][0]]), com)
+            assert np.array_equal(np.concatenate([res[(0, rep)][1], res[(1, rep)][1]]), coeff)
+        with pytest.raises(api.VdbError):
+            api.init_devices(2)                                                      # without the switch the box has one device
+    finally:
+        os.environ.pop("VDB_TEST_ALIAS_DEVICES", None)
+        api.shutdown()
+        api.init(0)

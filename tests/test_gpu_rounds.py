@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
-FIXED = ("sel", "sigma", "cst", "table", "lag", "inst")
+FIXED = ("sel", "sigma", "cst", "table", "lag")
 
 
 def _vk_digest(api, fixed):
@@ -52,6 +52,18 @@ def proved(circuit, O):
     return ch, out, timings
 
 
+def instance_poly_at(O, instances, x, k):
+    """the instance column at x from the public values alone: sum_i v_i L_i(x), L_i(x) = w^i (x^n - 1) / (n (x - w^i)) — the
+    verifier's side of an uncommitted instance column (halo2: QUERY_INSTANCE = false)"""
+    R, n = O.R_MOD, 1 << k
+    w = O.fr_to_ints(O.root_of_unity(k).reshape(1, 4))[0]
+    acc = 0
+    for i, v in enumerate(instances):
+        wi = pow(w, i, R)
+        acc = (acc + v * wi * pow((x - wi) % R, -1, R)) % R
+    return acc * (pow(x, n, R) - 1) * pow(n, -1, R) % R
+
+
 def check_quotient_identity(O, meta, ch, evals, instances=()):
     """gates + permutation + lookup expressions from the evaluations == h(x) (x^n - 1)"""
     R = O.R_MOD
@@ -63,14 +75,14 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
     a0, a1, a2, a3, q = ev("adv"), ev("advg", 1), ev("advg", 2), ev("advg", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
-    assert len(instances) == len(meta["instance_pos"])
-    for l_i, (col, _row), value in zip(ev("inst"), meta["instance_pos"], instances):        # public inputs: L (a - value)
-        acc = (acc * yv + l_i * (a0[col] - value)) % R
+    if len(instances) != meta["n_instances"]:
+        return False
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
-    pcols = list(a0) + list(ev("cst"))      # the permutation's columns: advice, lookup, the constants' fixed column
+    # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (from the public values)
+    pcols = list(a0) + list(ev("cst")) + [instance_poly_at(O, instances, x, meta["k"])]
     n_cols, n_sets = len(pcols), len(z0)
-    assert n_cols == meta["n_cols"] + 1 and len(sg) == n_cols
+    assert n_cols == meta["n_cols"] + 2 and len(sg) == n_cols
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
     for i in range(1, n_sets):
@@ -120,7 +132,7 @@ def _meta(pr):
     from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND
     import halo2_vectordb_amd.rounds as rounds
     return dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=CHUNK_LEN, n_blind=N_BLIND,
-                delta=rounds._fr_to_int(pr.delta), instance_pos=list(pr.instance_pos))
+                delta=rounds._fr_to_int(pr.delta), n_instances=len(pr.instance_cells))
 
 
 def test_round_outputs_have_the_expected_shape(circuit, proved):
@@ -137,16 +149,21 @@ def test_round_outputs_have_the_expected_shape(circuit, proved):
 def test_quotient_identity_from_the_returned_evaluations(circuit, proved, O):
     from halo2_vectordb_amd.rounds import quotient_identity_holds
     ch, out, _ = proved
-    assert check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"])
-    assert quotient_identity_holds(circuit[1], out["challenges"], out["evals"])      # the library-side helper agrees
+    inst = out["instances"]
+    assert len(inst) == 2 * 4                                                     # the K x dim centroid words (examples/kmeans.rs:51-56)
+    assert check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"], inst)
+    assert quotient_identity_holds(circuit[1], out["challenges"], out["evals"], inst)      # the library-side helper agrees
+    # another centroid word than the one the witness holds: the instance column's value at x changes, the identity breaks
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"], inst[:3] + [(inst[3] + 1) % O.R_MOD] + inst[4:])
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, out["evals"], inst[:-1])
     wrong = dict(out["evals"])
     wrong[("zl", 1)] = [(e + 1) % O.R_MOD for e in wrong[("zl", 1)]]
-    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong, inst)
     # the constants' fixed column is one of the permutation's columns: another evaluation of it breaks the identity
-    assert len(out["evals"][("cst", 0)]) == 1 and len(out["evals"][("sigma", 0)]) == circuit[1].n_cols + 1
+    assert len(out["evals"][("cst", 0)]) == 1 and len(out["evals"][("sigma", 0)]) == circuit[1].n_cols + 2
     wrong = dict(out["evals"])
     wrong[("cst", 0)] = [(e + 1) % O.R_MOD for e in wrong[("cst", 0)]]
-    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong)
+    assert not check_quotient_identity(O, _meta(circuit[1]), ch, wrong, inst)
 
 
 def test_every_opening_verifies_in_the_exponent(circuit, proved, O):
@@ -196,7 +213,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
-    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
@@ -211,6 +228,8 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
         return pts
     tr = api.Transcript()
     tr.common_scalar(_vk_digest(api, fixed))
+    for value in out["instances"]:                  # the statement: the public centroid words
+        tr.common_scalar(O.fr_from_ints([value])[0])
     commitments = dict(fixed)
     def absorb(pts):
         for pt in pts:
@@ -248,7 +267,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     # the challenges the prover used are the ones the proof bytes determine
     for name in ("beta", "gamma", "y", "x", "v"):
         assert np.array_equal(ch[name], out["challenges"][name])
-    assert check_quotient_identity(O, meta, ch, evals)
+    assert check_quotient_identity(O, meta, ch, evals, out["instances"])
     assert check_openings(O, O.fr_to_ints(ch["v"].reshape(1, 4))[0], commitments, evals, openings)
 
 
@@ -302,7 +321,7 @@ def test_shplonk_multiopen_verifies_in_the_exponent(circuit, O):
     out = pr.prove(None, seed=21)            # multiopen="shplonk" is the default
     op, R = out["openings"], O.R_MOD
     assert op["kind"] == "shplonk" and all(r == 0 for r in op["remainders"]) and len(op["remainders"]) >= 2
-    assert quotient_identity_holds(pr, out["challenges"], out["evals"])
+    assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
     assert len(out["proof"]) % 32 == 0
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     yo, v, u = (to_int(out["challenges"][n]) for n in ("yo", "v", "u"))
@@ -384,7 +403,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 1, "cst": 1, "table": 1, "lag": 3, "inst": len(meta["instance_pos"]), "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
     pos = 0
     tr = api.Transcript()
@@ -493,9 +512,10 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
     hp, pr = circuit
     out = pr.prove(None, seed=31)
     vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},
-              tau_h=PR.pt_mul(PR.G2, TAU))
+              tau_h=PR.pt_mul(PR.G2, TAU), instances=out["instances"])
     proof = out["proof"]
     assert _verify(O, api, proof, vk)
+    assert not _verify(O, api, proof, {**vk, "instances": []})       # a proof is a proof of its statement: the public centroids
     # through the proof file the Prove arm leaves behind (io.write_snark / read_snark)
     from halo2_vectordb_amd.io import read_snark, write_snark
     import tempfile, os
@@ -529,7 +549,7 @@ def test_every_proof_draws_fresh_blinding_scalars(circuit, O):
         assert ca.shape == cb.shape and not (ca == cb).all(axis=1).any(), name
     assert a["proof"] != b["proof"]
     for out in (a, b):
-        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU), instances=out["instances"])
         assert _verify(O, api, out["proof"], vk)
     # the hot path alone: two steps, different advice commitments for the same witness; a seed (test hook) pins them
     c1, c2 = hp.step().copy(), hp.step().copy()
@@ -577,10 +597,11 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
             assert np.array_equal(stream[pr.root_cell], api.poseidon_merkle_root(hp.qvec))
             cst = np.flatnonzero(cm.const_idx >= 0)                                         # every constant cell holds its constant
             assert np.array_equal(stream[cst], O.fr_from_ints(cm.consts)[cm.const_idx[cst]])
-        # the permutation built from it is a permutation of [advice | constants]
-        mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows, const_idx=cm.const_idx, n_consts=len(cm.consts))
+        # the permutation built from it is a permutation of [advice | constants | instance]; the root is the one public cell
+        assert pr.instance_cells == [pr.root_cell]
+        mapping = mapping_from_copy_of(copy_of, hp.bp, pr.n_cols, pr.rows, const_idx=cm.const_idx, n_consts=len(cm.consts), instance_cells=pr.instance_cells)
         flat = (mapping >> np.uint64(32)).astype(np.int64) * pr.rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        assert mapping.shape[0] == pr.n_cols + 1 and np.array_equal(np.sort(flat.reshape(-1)), np.arange((pr.n_cols + 1) * pr.rows))
+        assert mapping.shape[0] == pr.n_cols + 2 and np.array_equal(np.sort(flat.reshape(-1)), np.arange((pr.n_cols + 2) * pr.rows))
         out = pr.prove(None, seed=8)
         assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
         assert out["instances"] == [O.fr_to_ints(api.poseidon_merkle_root(hp.qvec).reshape(1, 4))[0]]                # the public input is the root

@@ -107,14 +107,14 @@ def test_verifying_key_file_round_trip(tmp_path):
     from halo2_vectordb_amd.io import VK_FIXED, read_verifying_key, write_verifying_key
     rng = np.random.default_rng(3)
     n_adv, n_cols = 5, 7
-    counts = dict(sel=n_adv, sigma=n_cols + 1, cst=1, table=1, lag=3, inst=2)
+    counts = dict(sel=n_adv, sigma=n_cols + 2, cst=1, table=1, lag=3)
     fixed = {name: rng.integers(0, 1 << 63, size=(counts[name], 8), dtype=np.uint64) for name in VK_FIXED}
-    meta = dict(rows=64, k=6, n_adv=n_adv, n_lk=2, n_cols=n_cols, n_sets=3, chunk_len=3, n_blind=5, delta=str(7 ** 40), instance_pos=[[0, 3], [4, 9]],
+    meta = dict(rows=64, k=6, n_adv=n_adv, n_lk=2, n_cols=n_cols, n_sets=3, chunk_len=3, n_blind=5, delta=str(7 ** 40), n_instances=2,
                 tau=str(2 ** 200 + 5), vk_digest=str(3 ** 150), opened={"0": ["adv", "sel"], "-1": ["pa"]})
     path = str(tmp_path / "c.vk.npz")
     write_verifying_key(path, meta, fixed)
     m, f = read_verifying_key(path)
-    assert m["delta"] == 7 ** 40 and m["tau"] == 2 ** 200 + 5 and m["vk_digest"] == 3 ** 150 and m["instance_pos"] == [(0, 3), (4, 9)]
+    assert m["delta"] == 7 ** 40 and m["tau"] == 2 ** 200 + 5 and m["vk_digest"] == 3 ** 150 and m["n_instances"] == 2
     assert m["opened"] == {0: ["adv", "sel"], -1: ["pa"]} and all(np.array_equal(f[name], fixed[name]) for name in VK_FIXED)
     # a key whose commitments do not fit its description, a file that is something else
     write_verifying_key(path, dict(meta, n_adv=n_adv + 1), fixed)

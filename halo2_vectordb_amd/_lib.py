@@ -92,7 +92,7 @@ _SIGNATURES = {
     "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P, _U64, _P],
     "vdb_gather_fr_dev": [_P, _P, _SZ, _P], "vdb_mock_check_instances_dev": [_P, _U64, _P, _P, _U64, _P],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
-    "vdb_poly_axpy_dev": [_P, _P, _P, _SZ],
+    "vdb_poly_axpy_dev": [_P, _P, _P, _SZ], "vdb_poly_scale_dev": [_P, _P, _SZ],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_eval_range_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _SZ],

@@ -622,6 +622,11 @@ __global__ __launch_bounds__(256) void k_poly_axpy(u256* __restrict__ acc, u256 
   if (i >= n) return;
   st256(acc + i, fr_add(ld256(acc + i), fr_mul(a, ld256(x + i))));
 }
+__global__ __launch_bounds__(256) void k_poly_scale(u256* __restrict__ x, u256 a, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st256(x + i, fr_mul(a, ld256(x + i)));
+}
 
 }  // namespace vdb
 
@@ -1082,6 +1087,17 @@ int vdb_poly_axpy_dev(vdb_fr* acc_dev, const vdb_fr* a, const vdb_fr* x_dev, siz
   u256 av;
   memcpy(&av, a, 32);
   hipLaunchKernelGGL(k_poly_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(acc_dev), av, as_u256(x_dev), (uint64_t)n);
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+
+int vdb_poly_scale_dev(vdb_fr* x_dev, const vdb_fr* a, size_t n) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(x_dev && a, "null pointer");
+  if (n == 0) return VDB_OK;
+  u256 av;
+  memcpy(&av, a, 32);
+  hipLaunchKernelGGL(k_poly_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(x_dev), av, (uint64_t)n);
   VDB_LAUNCH_CHECK();
   return VDB_OK;
 }

@@ -1324,7 +1324,9 @@ int vdb_wit_nearest_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* query_
   int* derr = (int*)scratch_get(1, 64);
   if (!derr) return VDB_ERR_OOM;
   VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
-  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, 0, ~0ull, 0, ~0ull};
+  // the rank window (vdb_wit_set_window): a rank stores the cells of its own columns — the distances, N-way parallel and nearly all of
+  // the cells, exit early outside it — while every rank computes every value (the N distances, the short minimum chain)
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], g_win[2], g_win[3]};
   TRY(wit_nearest_dev(fp, metric, as_u256(query_dev), as_u256(vectors_dev), n, dim, st, 0, 0, as_u256(indicator_dev), as_u256(result_dev)));
   return check_err_flag(derr);
 }

@@ -77,6 +77,34 @@ def balanced_column_shards(var_adv, var_lk, world, msm_share=0.22):
     return list(zip(adv, lk))
 
 
+SET_COLS = 3   # columns per product polynomial of the permutation argument (rounds.CHUNK_LEN): block boundaries fall on sets
+
+
+def align_column_shards(shards, n_adv, n_lk, chunk=SET_COLS):
+    """The same blocks with their inner boundaries moved (by at most chunk - 1 columns) onto the boundaries of the permutation
+    argument's column sets: the permutation runs over [advice | lookup | constants | instance] in sets of `chunk` consecutive
+    columns, so an advice cut a must have a % chunk == 0 and a lookup cut l must have (n_adv + l) % chunk == 0.  Then every
+    product polynomial's columns lie on one rank — except the one set that spans the advice / lookup junction — and the prover
+    rounds shard by the same blocks as the hot path (rounds.ShardMap)."""
+    world = len(shards)
+
+    def snap(cuts, offset, n):
+        out = [0]
+        for c in cuts[1:-1]:
+            down = c - (c + offset) % chunk
+            up = down + chunk
+            c2 = down if (c - down <= up - c or up > n) else up
+            out.append(min(n, max(out[-1], c2, 0)))
+        out.append(n)
+        return out
+    a_cuts = snap([0] + [shards[r][0][1] for r in range(world)], 0, n_adv)
+    l_cuts = snap([0] + [shards[r][1][1] for r in range(world)], n_adv, n_lk)
+    # a lookup cut below the first set that starts inside the lookup columns would split the junction set's columns over three ranks
+    first = (-n_adv) % chunk
+    l_cuts = [0] + [min(n_lk, max(c, first)) if c > 0 else 0 for c in l_cuts[1:-1]] + [n_lk]
+    return [((a_cuts[r], a_cuts[r + 1]), (l_cuts[r], l_cuts[r + 1])) for r in range(world)]
+
+
 def gather_commitments(dist, local, shards, device):
     """The one real exchange step of the path: all_gather of the 64-byte commitments of every rank's column
     shard (RCCL on GPUs, gloo in the CPU test).  `local`: (my_cols, 8) uint64, [advice block | lookup block];
@@ -247,6 +275,8 @@ class KmeansHotPath:
             d_tmpc.free()
             self.msm_entries = (var_adv, var_lk[: self.n_lk_cols])
             self.shards = balanced_column_shards(var_adv, var_lk[: self.n_lk_cols], self.world)
+        if self.world > 1:
+            self.shards = align_column_shards(self.shards, self.n_adv_cols, self.n_lk_cols)
         (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = self.shards[self.rank]
         self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
         self.my_cols = self.my_adv + self.my_lk
@@ -511,6 +541,12 @@ class KmeansHotPath:
         self._layout()
         api.sync()
 
+    def public_values_dev(self):
+        """(device pointer, count) of the values the reference's example of this circuit makes public, in make_public order
+        (examples/kmeans.rs:51-56: every centroid, word by word).  Every rank computes them (value-only walk), whichever rank's
+        columns hold the cells."""
+        return self.d_cent.ptr, self.K * self.dim
+
     def results(self):
         cent = self.d_cent.download((self.K, self.dim, 4))
         ind = self.d_ind.download((self.n, self.K, 4))
@@ -558,6 +594,9 @@ class MerkleHotPath(KmeansHotPath):
             if windowed:
                 check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
 
+    def public_values_dev(self):
+        return self.d_root.ptr, 1                  # examples/merkle.rs:47
+
     def results(self):
         return self.d_root.download((4,))
 
@@ -570,14 +609,14 @@ class MerkleHotPath(KmeansHotPath):
 
 class NearestHotPath(KmeansHotPath):
     """nearest_vector(query, vectors) (src/gadget/vectordb.rs:122-163; tests/vectordb/mod.rs:220-247 assigns the query, then the
-    vectors) through the same hot path.  The running minimum is one chain over all vectors, so every rank emits the whole
-    witness and takes its block of columns."""
+    vectors) through the same hot path.  Sharded: every rank computes the N distances' values and the short minimum
+    chain (value-only walk), and stores the cells of its own block of columns only — the distance blocks, N-way parallel and nearly
+    all of the cells, are skipped outside the rank's window."""
 
     def __init__(self, n=64, dim=128, k=14, P=48, L=13, metric="euclidean", seed=20260002, tau=None, col_shard=(0, 1), vectors=None, blind_seed=None):
         """`vectors`: (n + 1, dim) f64 rows, the query first"""
         super().__init__(n=n, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metric, seed=seed, tau=tau, col_shard=col_shard, vectors=vectors,
                          blind_seed=blind_seed)
-        self.shard_witness = False
 
     def n_input_rows(self):
         return self.n + 1
@@ -599,9 +638,20 @@ class NearestHotPath(KmeansHotPath):
     def _witness(self, sel=None):
         lib = self.lib
         check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
-        check(lib.vdb_wit_nearest_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.d_vec.at(self.dim * 32), self.n, self.dim, self.d_stream.at(self.n_in * 32),
-                                      self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_ind.ptr,
-                                      self.d_res.ptr))
+        windowed = sel is None and self.shard_witness and self.world > 1
+        if windowed:   # in the coordinates of the pointers handed to the call (the gadget's cells start n_in cells into the stream)
+            lo, hi = (max(0, x - self.n_in) for x in self.win_adv)
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(self.win_lk[0]), ctypes.c_uint64(self.win_lk[1])))
+        try:
+            check(lib.vdb_wit_nearest_dev(self.metric, self.P, self.L, self.d_vec.ptr, self.d_vec.at(self.dim * 32), self.n, self.dim, self.d_stream.at(self.n_in * 32),
+                                          self.d_lookup.ptr, ctypes.c_void_p(sel.ptr.value + self.n_in) if sel is not None else None, self.d_ind.ptr,
+                                          self.d_res.ptr))
+        finally:
+            if windowed:
+                check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
+
+    def public_values_dev(self):
+        return self.d_res.ptr, self.dim            # examples/query.rs:58: the nearest vector
 
     def results(self):
         return self.d_ind.download((self.n, 4)), self.d_res.download((self.dim, 4))

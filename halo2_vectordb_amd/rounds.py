@@ -91,10 +91,17 @@ class _Evals(Mapping):
 
 
 class _Poly:
-    """a set of polynomials in the three forms the rounds use; any of them may be absent"""
+    """a set of polynomials in the three forms the rounds use; any of them may be absent.  In a sharded proof the buffers hold
+    this rank's part only: `ranges` = the [lo, hi) stretches of the set's global numbering that lie in the buffers one after the
+    other (n_cols polynomials in all), `n_total` = the size of the whole set; `commits` is always the whole set's (gathered).
+    `replicated`: every rank holds the whole set (the small fixed polynomials, the quotient's pieces)."""
 
-    def __init__(self, name, n_cols, lag=None, coeff=None, ext=None, commits=None):
+    def __init__(self, name, n_cols, lag=None, coeff=None, ext=None, commits=None, ranges=None, n_total=None, replicated=False):
         self.name, self.n_cols, self.lag, self.coeff, self.ext, self.commits = name, n_cols, lag, coeff, ext, commits
+        self.ranges = [(0, n_cols)] if ranges is None else [(int(a), int(b)) for a, b in ranges if b > a]
+        self.n_total = n_cols if n_total is None else int(n_total)
+        self.replicated = replicated
+        assert sum(b - a for a, b in self.ranges) == n_cols
 
     def free(self):
         for b in (self.lag, self.coeff, self.ext):
@@ -104,20 +111,80 @@ class _Poly:
 
 
 class ProverRounds:
-    def __init__(self, hp, block_cols=BLOCK_COLS):
-        assert hp.world == 1, "the prover rounds run on one rank's full column set"
+    """`comm`: the exchange steps of a sharded proof (dist.Comm over torch.distributed: RCCL on a multi-GPU node, gloo in the
+    tests) when the hot path `hp` holds one rank's column blocks (col_shard = (rank, world)); None for a proof on one GPU.
+    Every rank runs the same rounds on its own columns and its own sets of the permutation argument (shardmap.ShardMap) and
+    keeps a transcript of its own: commitments and evaluations are exchanged in the global order before they are absorbed, so
+    every rank derives the same challenges and ends with the same proof bytes — the bytes a single GPU writes with the same
+    blinding scalars."""
+
+    def __init__(self, hp, block_cols=BLOCK_COLS, comm=None):
+        from .dist import LocalComm
+        from .shardmap import ShardMap
         assert block_cols % CHUNK_LEN == 0
         self.block_cols = block_cols
         self.hp, self.lib = hp, hp.lib
+        self.comm = comm if comm is not None else LocalComm()
+        self.rank, self.world = hp.rank, hp.world
+        assert (self.comm.rank, self.comm.world) == (self.rank, self.world), "the hot path's shard and the communicator disagree"
         self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
         self.usable = hp.rows - N_BLIND
         self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
         self.n_perm = self.n_cols + 2                # the permutation argument's columns: advice, lookup, the constants' fixed column, the instance column
         self.n_sets = -(-self.n_perm // CHUNK_LEN)
+        self.map = ShardMap(hp.shards, self.n_adv, self.n_lk, CHUNK_LEN)
+        (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = hp.shards[self.rank]
+        self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
+        self.set_ranges = self.map.set_ranges(self.rank)                       # the sets whose running products this rank computes
+        self.sig_ranges = self.map.set_col_ranges(self.rank)                   # their columns: the sigma columns this rank keeps
+        self.my_sets = sum(hi - lo for lo, hi in self.set_ranges)
+        self.my_sig = sum(hi - lo for lo, hi in self.sig_ranges)
+        self.adv_ranges = [(self.a_lo, self.a_hi), (self.n_adv + self.l_lo, self.n_adv + self.l_hi)]      # my columns among all advice + lookup columns
+        self.foreign = self.map.foreign_cols(self.rank)                        # columns of my sets that another rank holds
+        self.stray = self.map.stray_cols(self.rank)                            # my columns that lie in another rank's set
         self.delta = api.fr_delta()
         self.fixed = {}
         self._vk_digest = None
         self.d_map32 = None
+
+    # ------------------------------------------------------------------ local positions of global things
+    def _set_local(self, i):
+        """position of global set i in this rank's product buffers"""
+        off = 0
+        for lo, hi in self.set_ranges:
+            if lo <= i < hi:
+                return off + i - lo
+            off += hi - lo
+        raise KeyError(i)
+
+    def _sig_local(self, p):
+        """position of permutation column p in this rank's sigma buffers"""
+        off = 0
+        for lo, hi in self.sig_ranges:
+            if lo <= p < hi:
+                return off + p - lo
+            off += hi - lo
+        raise KeyError(p)
+
+    def _col_local(self, p):
+        """position of advice / lookup column p (permutation numbering) in the hot path's column buffer [my advice | my lookup]; None: not mine"""
+        if self.a_lo <= p < self.a_hi:
+            return p - self.a_lo
+        if self.l_lo <= p - self.n_adv < self.l_hi:
+            return self.my_adv + p - self.n_adv - self.l_lo
+        return None
+
+    def _globalize(self, local, ranges, n_total):
+        """rows this rank made, placed at `ranges` of an array of n_total rows; the other ranks' rows come with the exchange"""
+        local = np.ascontiguousarray(local, dtype=np.uint64)
+        if self.world == 1:
+            return local
+        out = np.zeros((n_total,) + local.shape[1:], dtype=np.uint64)
+        off = 0
+        for lo, hi in ranges:
+            out[lo:hi] = local[off: off + hi - lo]
+            off += hi - lo
+        return self.comm.sum_disjoint(out)
 
     # ------------------------------------------------------------------ helpers on device-resident columns
     def _to_coeff(self, lag_buf, n_cols):
@@ -137,7 +204,8 @@ class ProverRounds:
 
     def _commit(self, buf, n_cols, basis, dense=True):
         out = np.zeros((n_cols, 8), dtype=np.uint64)
-        check(self.lib.vdb_msm_batch_dev(self._srs_for(n_cols, basis, dense).h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
+        if n_cols:
+            check(self.lib.vdb_msm_batch_dev(self._srs_for(n_cols, basis, dense).h, basis, buf.ptr, _sz(n_cols), _sz(self.rows), api._p(out)))
         return out
 
     def _commit_begin(self, buf, n_cols, basis, dense=True):
@@ -151,15 +219,26 @@ class ProverRounds:
             check(self.lib.vdb_msm_batch_end(api._p(out), _sz(n_cols)))
         return out
 
-    def _blind(self, buf, n_cols, from_row, seed):
+    def _blind(self, buf, n_cols, from_row, seed, ranges=None, n_total=None):
         """uniform field elements into the rows from `from_row` on of every column (halo2 fills them with Scalar::random(rng)
-        from OsRng): 64 bytes of entropy each, reduced on the device; `seed` = None draws from the operating system"""
+        from OsRng): 64 bytes of entropy each, reduced on the device; `seed` = None draws from the operating system.
+        `ranges` / `n_total`: the n_cols columns are those stretches of a set of n_total columns; a seeded stream (test hook) is
+        then drawn for the whole set and this rank's part taken, so that a sharded proof blinds as the unsharded one does."""
         cnt = self.rows - from_row
         if n_cols * cnt == 0:
             return
-        d = api.DeviceBuffer(n_cols * cnt * B)
-        api.random_scalars_dev(d.ptr, n_cols * cnt, seed=seed)
-        check(self.lib.vdb_fill_rows_dev(buf.ptr, _sz(n_cols), _sz(self.rows), _sz(from_row), d.ptr))
+        if seed is None or ranges is None or n_total == n_cols:
+            d = api.DeviceBuffer(n_cols * cnt * B)
+            api.random_scalars_dev(d.ptr, n_cols * cnt, seed=seed)
+            check(self.lib.vdb_fill_rows_dev(buf.ptr, _sz(n_cols), _sz(self.rows), _sz(from_row), d.ptr))
+        else:
+            d = api.DeviceBuffer(n_total * cnt * B)
+            api.random_scalars_dev(d.ptr, n_total * cnt, seed=seed)
+            off = 0
+            for lo, hi in ranges:
+                if hi > lo:
+                    check(self.lib.vdb_fill_rows_dev(buf.at(off * self.rows * B), _sz(hi - lo), _sz(self.rows), _sz(from_row), d.at(lo * cnt * B)))
+                off += hi - lo
         api.sync()
         d.free()
 
@@ -175,11 +254,17 @@ class ProverRounds:
             tr0.free()
         return self._vk_digest
 
-    def _fixed_poly(self, name, lag_buf, n_cols, keep_lag=True, keep_ext=True):
+    def _fixed_poly(self, name, lag_buf, n_cols, keep_lag=True, keep_ext=True, ranges=None, n_total=None):
         """commitment and coefficient form of a fixed polynomial; its extended coset only when it is small (the selector and
-        sigma cosets — 4x the columns — are produced block by block inside the quotient instead of being held)"""
+        sigma cosets — 4x the columns — are produced block by block inside the quotient instead of being held).  With `ranges`
+        the buffer holds this rank's part of a set of n_total polynomials: every rank commits its part, the commitments of the
+        whole set are exchanged (they make the verifying key's digest); without, every rank holds the (small) whole."""
         coeff = self._to_coeff(lag_buf, n_cols)
-        p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=self._commit(lag_buf, n_cols, 1))
+        commits = self._commit(lag_buf, n_cols, 1)
+        if ranges is not None:
+            commits = self._globalize(commits, ranges, n_total)
+        p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=commits,
+                  ranges=ranges, n_total=n_total, replicated=ranges is None)
         if not keep_lag:
             api.sync()
             lag_buf.free()
@@ -272,23 +357,38 @@ class ProverRounds:
         if d_lsrc is not None:
             d_lsrc.free()
         self._d_map_for_tests = d_map if getattr(self, "keep_mapping", False) else None
-        d_sigma = api.DeviceBuffer(self.n_perm * rows * B)
-        _chk(lib.vdb_permutation_sigma_dev(d_map.ptr, _sz(self.n_perm), k, api._p(self.delta), d_sigma.ptr))
         # the mapping stays with the key in 32 bits per cell when column and row fit: the product round makes the sigma columns'
         # Lagrange form from it (one product per cell) instead of transforming their coefficient form back
         self.d_map32 = None
-        if (self.n_perm - 1).bit_length() + k <= 32 and getattr(self, "keep_packed_mapping", True):
+        if (self.n_perm - 1).bit_length() + k <= 32 and (getattr(self, "keep_packed_mapping", True) or self.world > 1):
             self.d_map32 = api.DeviceBuffer(self.n_perm * rows * 4)
             _chk(lib.vdb_permutation_mapping_pack_dev(d_map.ptr, _sz(self.n_perm), k, self.d_map32.ptr))
             api.sync()
+        if self.world > 1 and self.d_map32 is None:
+            raise ValueError("a sharded key keeps the packed mapping: column and row of a cell must fit 32 bits")
+        # sigma columns: every rank builds the cycles of the whole circuit (the copy classes cross all columns) and keeps the
+        # columns of its own sets
+        d_sigma = api.DeviceBuffer(max(self.my_sig, 1) * rows * B)
+        off = 0
+        for lo, hi in self.sig_ranges:
+            _chk(lib.vdb_permutation_sigma_dev(d_map.at(lo * rows * 8), _sz(hi - lo), k, api._p(self.delta), d_sigma.at(off * rows * B))
+                 if self.world == 1 else
+                 lib.vdb_permutation_sigma_packed_dev(self.d_map32.at(lo * rows * 4), _sz(hi - lo), _sz(self.n_perm), k, api._p(self.delta), d_sigma.at(off * rows * B)))
+            off += hi - lo
         if self._d_map_for_tests is None:
             d_map.free()
-        self._fixed_poly("sigma", d_sigma, self.n_perm, keep_lag=False, keep_ext=False)
-        # gate selectors (after the permutation's work space is gone: both are tens of GB at BASELINE sizes)
+        self._fixed_poly("sigma", d_sigma, self.my_sig, keep_lag=False, keep_ext=False, ranges=self.sig_ranges, n_total=self.n_perm)
+        # gate selectors (after the permutation's work space is gone: both are tens of GB at BASELINE sizes), of my advice columns
         d_q = api.DeviceBuffer(self.n_adv * rows * B)
         _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
         d_flags.free()
-        self._fixed_poly("sel", d_q, self.n_adv, keep_lag=False, keep_ext=False)
+        if self.my_adv != self.n_adv:
+            d_mine = api.DeviceBuffer(max(self.my_adv, 1) * rows * B)
+            _chk(lib.vdb_memcpy_d2d(d_mine.ptr, d_q.at(self.a_lo * rows * B), _sz(self.my_adv * rows * B)))
+            api.sync()
+            d_q.free()
+            d_q = d_mine
+        self._fixed_poly("sel", d_q, self.my_adv, keep_lag=False, keep_ext=False, ranges=[(self.a_lo, self.a_hi)], n_total=self.n_adv)
         # the constants' fixed column: constant r at row r (halo2-base assigns the distinct constants of a circuit to fixed cells
         # and ties every Constant advice cell to its fixed cell through the permutation)
         cst = np.zeros((rows, 4), dtype=np.uint64)
@@ -299,8 +399,8 @@ class ProverRounds:
         self._fixed_poly("cst", d_cst, 1)
         # its coset sits behind the advice cosets, the instance column's behind it (the permutation term of the quotient reads one
         # contiguous block of columns)
-        if hp.ext_cols >= self.n_cols + 2:
-            _chk(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
+        if hp.ext_cols >= self.my_adv + self.my_lk + 2:
+            _chk(lib.vdb_memcpy_d2d(hp.d_ext.at((self.my_adv + self.my_lk) * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         # range table 0 .. 2^L - 1, zero below; Lagrange selectors l0, l_last, l_active
         tab = np.arange(rows, dtype=np.uint64)
         tab[tab >= (1 << hp.L)] = 0
@@ -332,7 +432,11 @@ class ProverRounds:
         own = d_flags is None
         if own:
             d_flags = hp.keygen_flags()
-            hp._witness()
+            shard, hp.shard_witness = hp.shard_witness, False      # the check walks the whole witness, whatever this rank's columns
+            try:
+                hp._witness()
+            finally:
+                hp.shard_witness = shard
         bufs = []
 
         def dev(a, dtype):
@@ -374,11 +478,17 @@ class ProverRounds:
         # cosets, one of product cosets — through which every per-column stage streams.  The library's MSM scratch is released
         # first so that it is re-sized to what is left.
         check(lib.vdb_scratch_release())
-        n_der = 3 * self.n_lk + self.n_sets
-        blk = max(2 * CHUNK_LEN, min(self.block_cols, -(-self.n_perm // (2 * CHUNK_LEN)) * (2 * CHUNK_LEN)) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
+        n_der = 3 * self.my_lk + self.my_sets
+        blk = max(2 * CHUNK_LEN, min(self.block_cols, -(-max(self.my_sig, 1) // (2 * CHUNK_LEN)) * (2 * CHUNK_LEN)) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
         self.blk_alloc = blk
         self.pool_der = api.DeviceBuffer(max(n_der, 1) * rows * B)
-        self.d_lklag = api.DeviceBuffer(max(self.n_lk, 1) * rows * B)
+        self.d_lklag = api.DeviceBuffer(max(self.my_lk, 1) * rows * B)
+        # what a sharded proof receives from other ranks: the columns that complete the set spanning the advice / lookup junction
+        # (Lagrange and coefficient form), one boundary product polynomial per requested set
+        self.z_req = self.map.z_requests(self.rank)
+        self.d_foreign_lag = api.DeviceBuffer(max(len(self.foreign), 1) * rows * B)
+        self.d_foreign_coeff = api.DeviceBuffer(max(len(self.foreign), 1) * rows * B)
+        self.d_zhalo = api.DeviceBuffer(max(len(self.z_req), 1) * rows * B)
         self.d_lag_a, self.d_lag_s = api.DeviceBuffer(blk * rows * B), api.DeviceBuffer(blk * rows * B)
         self.d_ea, self.d_eb = api.DeviceBuffer(blk * self.ne * B), api.DeviceBuffer(blk * self.ne * B)
         self.d_ez = api.DeviceBuffer((blk // CHUNK_LEN + 1) * self.ne * B)
@@ -414,6 +524,8 @@ class ProverRounds:
         build's own container: an .npz (numpy.load with allow_pickle=False reads it) holding the circuit's shape, the break
         points, and per fixed polynomial — gate selectors, sigma columns, range table, Lagrange selectors — its coefficient
         form and its commitments.  Upstream's pk file format (SerdeFormat::RawBytes) is not reproduced: parity unpinned."""
+        if self.world > 1:
+            raise NotImplementedError("the proving-key file holds the whole key: write it from a one-rank run")
         api.sync()
         doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, CHUNK_LEN, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
         doc["instance_cells"] = np.asarray(self.instance_cells, dtype=np.int64)
@@ -427,6 +539,8 @@ class ProverRounds:
         flag-recording witness pass, no permutation construction).  The Lagrange forms the rounds read (sigma, table) are
         recovered with a forward transform; raises ValueError when the file describes another circuit."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
+        if self.world > 1:
+            raise NotImplementedError("the proving-key file holds the whole key: load it in a one-rank run")
         with np.load(path, allow_pickle=False) as doc:
             meta = [int(v) for v in doc["meta"]]
             if meta != [k, self.n_adv, self.n_lk, hp.L, CHUNK_LEN, N_BLIND] or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
@@ -471,8 +585,13 @@ class ProverRounds:
         Returns dict(commitments, evals, openings, points, proof, instances): commitments[name] (n, 8); evals[(name, rotation)] list
         of ints; openings: list of dict(rotation, point, polys=[names in combination order], eval, W).
         `seed`: None = every blinding scalar of this proof (advice, lookup and product columns) comes fresh from the
-        operating system's entropy, as in halo2's create_proof; an integer makes the proof reproducible (tests)."""
+        operating system's entropy, as in halo2's create_proof; an integer makes the proof reproducible (tests).
+        Sharded (world > 1, SHPLONK only): every rank calls prove() with the same arguments; each works on its own columns and
+        sets and all end with the same proof bytes (see the class docstring and shardmap.py)."""
         hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
+        comm, world, rank = self.comm, self.world, self.rank
+        if world > 1 and multiopen != "shplonk":
+            raise ValueError("the sharded rounds open with SHPLONK")
         seeds = iter([None] * 8 if seed is None else [[int(seed), i] for i in range(1, 9)])
         tr = api.Transcript() if challenges is None else None
         ch = {} if challenges is None else {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
@@ -497,6 +616,9 @@ class ProverRounds:
         if tr is not None:
             tr.common_scalar(self.vk_digest())
         usable, n_adv, n_lk, n_cols, n_sets = self.usable, self.n_adv, self.n_lk, self.n_cols, self.n_sets
+        a_lo, a_hi, l_lo, l_hi, my_adv, my_lk, my_sets = self.a_lo, self.a_hi, self.l_lo, self.l_hi, self.my_adv, self.my_lk, self.my_sets
+        my_cols = my_adv + my_lk
+        lk_ranges = [(l_lo, l_hi)]
         fx = self.fixed
         T = {} if timings is None else timings
 
@@ -510,8 +632,31 @@ class ProverRounds:
             T[name] = T.get(name, 0.0) + api.timer_stop()
             return r
 
+        def power(name, e):
+            """challenge^e as a Montgomery element (a fold that skips e terms another rank holds multiplies by it)"""
+            return _fr_from_int(pow(_fr_to_int(ch[name]), int(e), R_MOD))
+
+        class _Fold:
+            """position in a sum  sum_i t_i c^(N-1-i)  that this rank folds its own terms of, in increasing i: `skip_to(i)`
+            before term i is folded in (acc <- acc c + t_i) multiplies the accumulator by c for every term in between that
+            another rank holds; `finish()` for the terms after its last.  On one rank nothing is ever skipped."""
+
+            def __init__(self, acc, n_elems, challenge, n_terms):
+                self.acc, self.n_elems, self.challenge, self.n_terms, self.pos, self.live = acc, n_elems, challenge, n_terms, 0, False
+
+            def skip_to(self, i, count):
+                if self.live and i > self.pos:
+                    check(lib.vdb_poly_scale_dev(self.acc.ptr, api._p(power(self.challenge, i - self.pos)), _sz(self.n_elems)))
+                assert i >= self.pos or not self.live, "terms are folded in increasing order"
+                self.pos, self.live = i + count, True
+
+            def finish(self):
+                if self.live and self.n_terms > self.pos:
+                    check(lib.vdb_poly_scale_dev(self.acc.ptr, api._p(power(self.challenge, self.n_terms - self.pos)), _sz(self.n_elems)))
+                self.pos = self.n_terms
+
         # round 1: advice columns (the hot path of the bench: witness, commit, lagrange_to_coeff, coeff_to_extended)
-        resident = hp.ext_cols >= n_cols + 2       # every advice coset stays in HBM; otherwise they are recomputed block by block below
+        resident = hp.ext_cols >= my_cols + 2      # every advice coset stays in HBM; otherwise they are recomputed block by block below
         ni = len(self.instance_cells)
         given = None if instances is None else np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.uint64) for v in instances]).reshape(-1, 4) if ni else np.zeros((0, 4), np.uint64))
         assert given is None or len(given) == ni, "one value per public cell"
@@ -524,71 +669,108 @@ class ProverRounds:
             if not ni:
                 return
             if given is None:
-                check(lib.vdb_gather_fr_dev(hp.d_stream.ptr, self.d_inst_cells.ptr, _sz(ni), self.d_inst_lag.ptr))
+                if world == 1:
+                    check(lib.vdb_gather_fr_dev(hp.d_stream.ptr, self.d_inst_cells.ptr, _sz(ni), self.d_inst_lag.ptr))
+                else:
+                    # a rank writes only the cells of its own columns; the values every rank computes are the gadget's results
+                    ptr, cnt = hp.public_values_dev()
+                    if cnt != ni or self.instance_cells != self.public_cells:
+                        raise ValueError("a sharded proof exposes the circuit's default public cells")
+                    check(lib.vdb_memcpy_d2d(self.d_inst_lag.ptr, ptr, _sz(ni * B)))
                 check(lib.vdb_memcpy_d2h(api._p(inst_host), self.d_inst_lag.ptr, _sz(ni * B)))
             else:
                 inst_host[:ni] = given
                 check(lib.vdb_memcpy_h2d(self.d_inst_lag.ptr, api._p(inst_host), _sz(ni * B)))
         # (the transforms of the advice columns are still running when step returns: the commitments are absorbed meanwhile)
-        adv_commits = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False, after_witness=public_values).copy()
+        adv_local = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False, after_witness=public_values).copy()
+        adv_commits = self._globalize(adv_local, self.adv_ranges, n_cols)
         instances = [inst_host[i].copy() for i in range(ni)]
         # the instance polynomial in the forms the rounds read (one column: queued behind the advice transforms)
         check(lib.vdb_memcpy_d2d(self.d_inst_coeff.ptr, self.d_inst_lag.ptr, _sz(rows * B)))
         check(lib.vdb_lagrange_to_coeff_dev(self.d_inst_coeff.ptr, _sz(1), k))
         check(lib.vdb_coeff_to_extended_dev(self.d_inst_coeff.ptr, self.d_inst_ext.ptr, _sz(1), k, EXT_K))
         if resident:
-            check(lib.vdb_memcpy_d2d(hp.d_ext.at((n_cols + 1) * ne * B), self.d_inst_ext.ptr, _sz(ne * B)))
+            check(lib.vdb_memcpy_d2d(hp.d_ext.at((my_cols + 1) * ne * B), self.d_inst_ext.ptr, _sz(ne * B)))
         if tr is not None and ni:
             t0 = time.perf_counter()
             tr.common_scalars(inst_host[:ni])
             host["transcript"] += (time.perf_counter() - t0) * 1e3
         write_points(adv_commits)
         squeeze("theta")
-        adv = _Poly("adv", n_cols, coeff=hp.d_cols, commits=adv_commits)
+        adv = _Poly("adv", my_cols, coeff=hp.d_cols, commits=adv_commits, ranges=self.adv_ranges, n_total=n_cols)
         n_perm = self.n_perm
         # the gate columns once more as a group of their own: only they are read at rows 1..3 (halo2 opens a column at the rotations
         # its queries name — the lookup columns only at the current row)
-        polys = {"adv": adv, "advg": _Poly("advg", n_adv, coeff=hp.d_cols, commits=adv_commits[:n_adv])}
+        polys = {"adv": adv, "advg": _Poly("advg", my_adv, coeff=hp.d_cols, commits=adv_commits[:n_adv], ranges=[(a_lo, a_hi)], n_total=n_adv)}
         # Everything below works on blocks of `blk` columns: the Lagrange forms, the sigma columns and every extended coset
         # exist one block at a time (the advice cosets too, unless the hot path keeps them resident); what stays in HBM is the
         # streams, the coefficient forms and the derived columns.
         blk = max(2 * CHUNK_LEN, min(self.block_cols, self.blk_alloc) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
-        blk_l = blk // 2
         d_lag_a, d_lag_s, d_ea, d_eb, d_ez, d_zf, d_zlast, d_lklag = self.d_lag_a, self.d_lag_s, self.d_ea, self.d_eb, self.d_ez, self.d_zf, self.d_zlast, self.d_lklag
         omega = api.root_of_unity(k)
         bp_p, n_bp = api._p(hp.bp), ctypes.c_uint64(len(hp.bp))
         from .pipeline import MINIMUM_ROWS
         lk_blind = hp.d_blind.at(hp.n_adv_cols * N_BLIND * B)
+        foreign_slot = {c: i for i, c in enumerate(self.foreign)}
+
+        def runs(c0, nb):
+            """the permutation's columns c0 .. c0 + nb cut into stretches of one kind: (kind, first column, count) with kind
+            "adv" / "lk" (this rank's), "foreign" (another rank's, received), "cst", "inst" """
+            out = []
+            for c in range(c0, c0 + nb):
+                kind = ("cst" if c == n_cols else "inst" if c == n_cols + 1 else "adv" if a_lo <= c < a_hi else
+                        "lk" if l_lo <= c - n_adv < l_hi else "foreign")
+                if kind == "foreign" and c not in foreign_slot:
+                    raise AssertionError("a column of this rank's sets that nobody sent")
+                if out and out[-1][0] == kind and kind not in ("cst", "inst") and (kind != "foreign" or foreign_slot[c] == foreign_slot[c - 1] + 1):
+                    out[-1][2] += 1
+                else:
+                    out.append([kind, c, 1])
+            return out
 
         def lagrange_block(c0, nb, dest):
             """the permutation's columns c0 .. c0 + nb in Lagrange form: advice from the stream, lookup from their laid-out copy, constants, instances"""
-            a1, l0_, l1_ = min(c0 + nb, n_adv), max(c0, n_adv), min(c0 + nb, n_cols)
-            if c0 < a1:
-                check(lib.vdb_layout_columns_range_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), bp_p, n_bp, k, ctypes.c_uint64(c0), ctypes.c_uint64(a1),
-                                                       dest.ptr, hp.d_blind.ptr, N_BLIND))
-            if l0_ < l1_:
-                check(lib.vdb_memcpy_d2d(dest.at((l0_ - c0) * rows * B), d_lklag.at((l0_ - n_adv) * rows * B), _sz((l1_ - l0_) * rows * B)))
-            for col, src in ((n_cols, fx["cst"].lag), (n_cols + 1, self.d_inst_lag)):
-                if c0 <= col < c0 + nb:
-                    check(lib.vdb_memcpy_d2d(dest.at((col - c0) * rows * B), src.ptr, _sz(rows * B)))
+            for kind, c, m in runs(c0, nb):
+                to = dest.at((c - c0) * rows * B)
+                if kind == "adv":
+                    check(lib.vdb_layout_columns_range_dev(hp.d_stream.ptr, ctypes.c_uint64(hp.n_cells), bp_p, n_bp, k, ctypes.c_uint64(c), ctypes.c_uint64(c + m),
+                                                           to, hp.d_blind.ptr, N_BLIND))
+                else:
+                    src = (d_lklag.at((c - n_adv - l_lo) * rows * B) if kind == "lk" else self.d_foreign_lag.at(foreign_slot[c] * rows * B) if kind == "foreign"
+                           else fx["cst"].lag.ptr if kind == "cst" else self.d_inst_lag.ptr)
+                    check(lib.vdb_memcpy_d2d(to, src, _sz(m * rows * B)))
+
+        def local_ext_index(c):
+            """position of permutation column c in the hot path's coset buffer [my advice | my lookup | constants | instance], None: not there"""
+            loc = self._col_local(c)
+            if loc is not None:
+                return loc
+            return my_cols + (c - n_cols) if c >= n_cols else None
 
         def adv_ext_block(c0, nb):
             """(pointer, first column) of a buffer that holds the cosets of the permutation's columns c0 .. c0 + nb"""
             if resident:
-                return hp.d_ext.ptr, 0
-            n_real = max(0, min(c0 + nb, n_cols) - c0)
-            if n_real:
-                check(lib.vdb_coeff_to_extended_dev(hp.d_cols.at(c0 * rows * B), d_ea.ptr, _sz(n_real), k, EXT_K))
-            for col, src in ((n_cols, fx["cst"].ext), (n_cols + 1, self.d_inst_ext)):
-                if c0 <= col < c0 + nb:
-                    check(lib.vdb_memcpy_d2d(d_ea.at((col - c0) * ne * B), src.ptr, _sz(ne * B)))
+                loc = [local_ext_index(c) for c in range(c0, c0 + nb)]
+                if None not in loc and loc == list(range(loc[0], loc[0] + nb)):
+                    return hp.d_ext.ptr, c0 - loc[0]
+            for kind, c, m in runs(c0, nb):
+                to = d_ea.at((c - c0) * ne * B)
+                if kind in ("adv", "lk"):
+                    if resident:
+                        check(lib.vdb_memcpy_d2d(to, hp.d_ext.at(self._col_local(c) * ne * B), _sz(m * ne * B)))
+                    else:
+                        check(lib.vdb_coeff_to_extended_dev(hp.d_cols.at(self._col_local(c) * rows * B), to, _sz(m), k, EXT_K))
+                elif kind == "foreign":
+                    check(lib.vdb_coeff_to_extended_dev(self.d_foreign_coeff.at(foreign_slot[c] * rows * B), to, _sz(m), k, EXT_K))
+                else:
+                    check(lib.vdb_memcpy_d2d(to, (fx["cst"].ext if kind == "cst" else self.d_inst_ext).ptr, _sz(ne * B)))
             return d_ea.ptr, c0
 
         def col_ptr(base, col0, c):
-            return ctypes.c_void_p(base.value + (c - col0) * ne * B)
+            return ctypes.c_void_p((base.value if hasattr(base, "value") else int(base)) + (c - col0) * ne * B)
 
         # round 2: the lookup argument's permuted columns
-        counts = {"pa": n_lk, "ps": n_lk, "zp": n_sets, "zl": n_lk}
+        counts = {"pa": my_lk, "ps": my_lk, "zp": my_sets, "zl": my_lk}
         der, off = {}, 0
         for name, m in counts.items():
             der[name] = _View(self.pool_der, off * rows * B, m * rows * B)
@@ -596,37 +778,80 @@ class ProverRounds:
         d_pa, d_ps, d_zp, d_zl = der["pa"], der["ps"], der["zp"], der["zl"]
 
         def permute():
-            if n_lk:
-                check(lib.vdb_layout_lookup_range_dev(hp.d_lookup.ptr, ctypes.c_uint64(hp.n_lookup), k, MINIMUM_ROWS, ctypes.c_uint64(0), ctypes.c_uint64(n_lk),
+            if my_lk:
+                check(lib.vdb_layout_lookup_range_dev(hp.d_lookup.ptr, ctypes.c_uint64(hp.n_lookup), k, MINIMUM_ROWS, ctypes.c_uint64(l_lo), ctypes.c_uint64(l_hi),
                                                       d_lklag.ptr, lk_blind, N_BLIND))
-            check(lib.vdb_lookup_permute_dev(d_lklag.ptr, fx["table"].lag.ptr, _sz(n_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
+            check(lib.vdb_lookup_permute_dev(d_lklag.ptr, fx["table"].lag.ptr, _sz(my_lk), _sz(rows), _sz(usable), hp.L, d_pa.ptr, d_ps.ptr))
         stage("lookup_permute", permute)
-        self._blind(d_pa, n_lk, usable, next(seeds))
-        self._blind(d_ps, n_lk, usable, next(seeds))
-        polys["pa"] = _Poly("pa", n_lk, lag=d_pa, commits=stage("commit_permuted", lambda: self._commit(d_pa, n_lk, 1, dense=False)))
-        polys["ps"] = _Poly("ps", n_lk, lag=d_ps, commits=stage("commit_permuted", lambda: self._commit(d_ps, n_lk, 1, dense=False)))
+        self._blind(d_pa, my_lk, usable, next(seeds), lk_ranges, n_lk)
+        self._blind(d_ps, my_lk, usable, next(seeds), lk_ranges, n_lk)
+        pa_c = stage("commit_permuted", lambda: self._commit(d_pa, my_lk, 1, dense=False))
+        ps_c = stage("commit_permuted", lambda: self._commit(d_ps, my_lk, 1, dense=False))
+        if world > 1:
+            both = self._globalize(np.concatenate([pa_c, ps_c], axis=1), lk_ranges, n_lk)
+            pa_c, ps_c = np.ascontiguousarray(both[:, :8]), np.ascontiguousarray(both[:, 8:])
+        polys["pa"] = _Poly("pa", my_lk, lag=d_pa, commits=pa_c, ranges=lk_ranges, n_total=n_lk)
+        polys["ps"] = _Poly("ps", my_lk, lag=d_ps, commits=ps_c, ranges=lk_ranges, n_total=n_lk)
         if n_lk:
             write_points(np.stack([polys["pa"].commits, polys["ps"].commits], axis=1).reshape(-1, 8))     # (pa_c, ps_c) per lookup column
         squeeze("beta", "gamma")
 
+        # the columns of my sets that another rank holds (the set that spans the advice / lookup junction): their holder sends the
+        # Lagrange form, blinding rows included; the coefficient form is made here
+        all_foreign = self.map.all_foreign_cols() if world > 1 else []
+        if all_foreign:
+            slab = np.zeros((len(all_foreign), rows, 4), dtype=np.uint64)
+            tmp = api.DeviceBuffer(rows * B)
+            for i, c in enumerate(all_foreign):
+                if self._col_local(c) is not None:
+                    lagrange_block(c, 1, tmp)
+                    slab[i] = tmp.download((rows, 4))
+            tmp.free()
+            slab = comm.sum_disjoint(slab)
+            for i, c in enumerate(all_foreign):
+                if c in foreign_slot:
+                    self.d_foreign_lag.upload(slab[i], offset=foreign_slot[c] * rows * B)
+            if self.foreign:
+                check(lib.vdb_memcpy_d2d(self.d_foreign_coeff.ptr, self.d_foreign_lag.ptr, _sz(len(self.foreign) * rows * B)))
+                check(lib.vdb_lagrange_to_coeff_dev(self.d_foreign_coeff.ptr, _sz(len(self.foreign)), k))
+            del slab
+
         # round 3 (beta, gamma): the running products of both arguments
         def products():
-            for c0 in range(0, n_perm, blk):
-                nb = min(blk, n_perm - c0)
-                lagrange_block(c0, nb, d_lag_a)
-                if self.d_map32 is not None:
-                    check(lib.vdb_permutation_sigma_packed_dev(self.d_map32.at(c0 * rows * 4), _sz(nb), _sz(n_perm), k, api._p(self.delta), d_lag_s.ptr))
-                else:                                      # a key loaded from a file: back from the coefficient form
-                    check(lib.vdb_memcpy_d2d(d_lag_s.ptr, fx["sigma"].coeff.at(c0 * rows * B), _sz(nb * rows * B)))
-                    check(lib.vdb_ntt_batch_dev(d_lag_s.ptr, _sz(nb), k, api._p(omega), 0))
-                check(lib.vdb_permutation_product_range_dev(d_lag_a.ptr, d_lag_s.ptr, _sz(nb), _sz(c0), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
-                                                            api._p(self.delta), d_zp.at(c0 // CHUNK_LEN * rows * B)))
-            check(lib.vdb_permutation_chain_dev(d_zp.ptr, _sz(n_sets), k, _sz(usable)))
-            check(lib.vdb_lookup_product_dev(d_lklag.ptr, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(n_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
+            for s_lo, s_hi in self.set_ranges:
+                p_lo, p_hi = self.map.range_cols((s_lo, s_hi))
+                for c0 in range(p_lo, p_hi, blk):
+                    nb = min(blk, p_hi - c0)
+                    lagrange_block(c0, nb, d_lag_a)
+                    if self.d_map32 is not None:
+                        check(lib.vdb_permutation_sigma_packed_dev(self.d_map32.at(c0 * rows * 4), _sz(nb), _sz(n_perm), k, api._p(self.delta), d_lag_s.ptr))
+                    else:                                      # a key loaded from a file: back from the coefficient form
+                        check(lib.vdb_memcpy_d2d(d_lag_s.ptr, fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), _sz(nb * rows * B)))
+                        check(lib.vdb_ntt_batch_dev(d_lag_s.ptr, _sz(nb), k, api._p(omega), 0))
+                    check(lib.vdb_permutation_product_range_dev(d_lag_a.ptr, d_lag_s.ptr, _sz(nb), _sz(c0), k, _sz(usable), _sz(CHUNK_LEN), p["beta"], p["gamma"],
+                                                                api._p(self.delta), d_zp.at(self._set_local(c0 // CHUNK_LEN) * rows * B)))
+                # the products of a range run on from set to set
+                check(lib.vdb_permutation_chain_dev(d_zp.at(self._set_local(s_lo) * rows * B), _sz(s_hi - s_lo), k, _sz(usable)))
+            if world > 1:
+                # ... and from range to range across the ranks: every range starts where the one before it ended.  One field
+                # element per range is exchanged (its last running product at the last usable row), every rank multiplies up the
+                # ranges before its own.
+                order = self.map.all_ranges()
+                ends = np.zeros((len(order), 4), dtype=np.uint64)
+                for i, (lo, hi, r) in enumerate(order):
+                    if r == rank:
+                        check(lib.vdb_memcpy_d2h(api._p(ends[i]), d_zp.at((self._set_local(hi - 1) * rows + usable) * B), _sz(B)))
+                ends = comm.sum_disjoint(ends)
+                acc = 1
+                for i, (lo, hi, r) in enumerate(order):
+                    if r == rank and acc != 1:
+                        check(lib.vdb_poly_scale_dev(d_zp.at(self._set_local(lo) * rows * B), api._p(_fr_from_int(acc)), _sz((hi - lo) * rows)))
+                    acc = acc * _fr_to_int(ends[i]) % R_MOD
+            check(lib.vdb_lookup_product_dev(d_lklag.ptr, fx["table"].lag.ptr, d_pa.ptr, d_ps.ptr, _sz(my_lk), _sz(rows), _sz(usable), p["beta"], p["gamma"],
                                              d_zl.ptr))
         stage("products", products)
-        self._blind(d_zp, n_sets, usable + 1, next(seeds))
-        self._blind(d_zl, n_lk, usable + 1, next(seeds))
+        self._blind(d_zp, my_sets, usable + 1, next(seeds), self.set_ranges, n_sets)
+        self._blind(d_zl, my_lk, usable + 1, next(seeds), lk_ranges, n_lk)
         def derived_forms(names):
             for name in names:
                 q = polys[name]
@@ -635,22 +860,45 @@ class ProverRounds:
         # The host absorbs one batch of commitments while the device works on the next thing that needs no challenge: the lookup
         # products' MSM beside the permutation products' commitments, the coefficient forms (needed by the quotient, independent of y)
         # beside the lookup products' commitments.
-        polys["zp"] = _Poly("zp", n_sets, lag=d_zp, commits=stage("commit_products", lambda: self._commit(d_zp, n_sets, 1)))
-        stage("commit_products", lambda: self._commit_begin(d_zl, n_lk, 1))
+        zp_c = self._globalize(stage("commit_products", lambda: self._commit(d_zp, my_sets, 1)), self.set_ranges, n_sets)
+        polys["zp"] = _Poly("zp", my_sets, lag=d_zp, commits=zp_c, ranges=self.set_ranges, n_total=n_sets)
+        stage("commit_products", lambda: self._commit_begin(d_zl, my_lk, 1))
         try:
             write_points(polys["zp"].commits)
         except Exception:
             lib.vdb_msm_batch_end(None, _sz(0))       # a deferred MSM must always be collected, or every later MSM is refused
             raise
-        polys["zl"] = _Poly("zl", n_lk, lag=d_zl, commits=stage("commit_products", lambda: self._commit_end(n_lk)))
+        zl_c = self._globalize(stage("commit_products", lambda: self._commit_end(my_lk)), lk_ranges, n_lk)
+        polys["zl"] = _Poly("zl", my_lk, lag=d_zl, commits=zl_c, ranges=lk_ranges, n_total=n_lk)
         stage("derived_ntt", lambda: derived_forms(("pa", "ps", "zp", "zl")))
         write_points(polys["zl"].commits)
         squeeze("y")
 
+        # the boundary products other ranks ask for, in coefficient form: the set before each of their ranges, and the first set
+        # for the rank that closes the chain
+        zp = polys["zp"]
+        z_slot = {i: j for j, i in enumerate(self.z_req)}
+        all_z = self.map.all_z_requests() if world > 1 else []
+        if all_z:
+            slab = np.zeros((len(all_z), rows, 4), dtype=np.uint64)
+            for j, i in enumerate(all_z):
+                if self.map.set_owner(i) == rank:
+                    check(lib.vdb_memcpy_d2h(api._p(slab[j]), zp.coeff.at(self._set_local(i) * rows * B), _sz(rows * B)))
+            slab = comm.sum_disjoint(slab)
+            for j, i in enumerate(all_z):
+                if i in z_slot:
+                    self.d_zhalo.upload(slab[j], offset=z_slot[i] * rows * B)
+            del slab
+
+        def z_coeff(i):
+            """coefficient form of product polynomial i: mine, or the copy its owner sent"""
+            if i in z_slot:
+                return self.d_zhalo.at(z_slot[i] * rows * B)
+            return zp.coeff.at(self._set_local(i) * rows * B)
+
         # round 4 (y): the quotient
         d_h = self.d_h
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
-        zp = polys["zp"]
 
         def to_ext(coeff_ptr, dest_ptr, m):
             check(lib.vdb_coeff_to_extended_dev(coeff_ptr, dest_ptr, _sz(m), k, EXT_K))
@@ -666,45 +914,76 @@ class ProverRounds:
             # The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on the
             # coset of 2 n points inside the 4 n (every second point of the advice cosets; the selector cosets are made for 2 n
             # points only: half the transform), divided and brought back to coefficients there, and joined in coefficient form.
+            # Sharded: a rank folds the terms of its own columns and sets (the folds skip what other ranks hold: _Fold); every step
+            # after that — the joins, the division by X^n - 1, the way back to coefficients — is linear, so each rank ends with a
+            # share of h's coefficients and the shares are added (the one bulk exchange of the proof: 2^(k+2) x 32 B per rank).
             ag, a2, a3, a4 = self.d_hg, self.d_h2, self.d_h3, self.d_h4
             for a in (a2, a3, a4):
                 check(lib.vdb_memset_dev(a.ptr, 0, _sz(ne * B)))
             check(lib.vdb_memset_dev(ag.ptr, 0, _sz((rows << GATE_EXT_K) * B)))
+            n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
+            f_g, f_2, f_3, f_4 = _Fold(ag, rows << GATE_EXT_K, "y", n_adv), _Fold(a2, ne, "y", n2), _Fold(a3, ne, "y", n3), _Fold(a4, ne, "y", n4)
             perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
-            # l0 (1 - z_0), l_last (z_last^2 - z_last): the first two terms of group 2
-            to_ext(zp.coeff.ptr, d_zf.ptr, 1)
-            to_ext(zp.coeff.at((n_sets - 1) * rows * B), d_zlast.ptr, 1)
-            check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
+            # l0 (1 - z_0), l_last (z_last^2 - z_last): the first two terms of group 2, folded in by the owner of the last set
+            if self.map.head_owner() == rank:
+                to_ext(z_coeff(0), d_zf.ptr, 1)
+                to_ext(z_coeff(n_sets - 1), d_zlast.ptr, 1)
+                f_2.skip_to(0, 2)
+                check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
             third = blk // 3
-            for c0 in range(0, n_perm, blk):
-                nb = min(blk, n_perm - c0)
-                base, col0 = adv_ext_block(c0, nb)
-                g1 = min(c0 + nb, n_adv)
-                if c0 < g1:                                            # gates of the block's advice columns
-                    check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at(c0 * rows * B), d_eb.ptr, _sz(g1 - c0), k, GATE_EXT_K))
-                    check(lib.vdb_gate_eval_sub_dev(col_ptr(base, col0, c0), EXT_K, d_eb.ptr, _sz(g1 - c0), k, GATE_EXT_K, p["y"], ag.ptr))
-                # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
-                set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
-                z0 = max(set_lo - 1, 0)
-                to_ext(fx["sigma"].coeff.at(c0 * rows * B), d_eb.ptr, nb)
-                to_ext(zp.coeff.at(z0 * rows * B), d_ez.ptr, set_hi - z0)
-                if max(set_lo, 1) < set_hi:
-                    check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
-                                                             _sz(0), _sz(0)))
-                check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 0, _sz(0), _sz(0), _sz(set_lo),
-                                                         _sz(set_hi)))
-                # lookup argument of the block's lookup columns: [permuted input | permuted table | product] cosets in thirds of one buffer
-                j_lo, j_hi = max(c0, n_adv) - n_adv, min(c0 + nb, n_cols) - n_adv
+
+            def lookup_terms(base, col0, j_lo, j_hi):
+                """the lookup argument of my lookup columns j_lo .. j_hi, whose input cosets are in the block at `base`:
+                [permuted input | permuted table | product] cosets in thirds of one buffer"""
                 for j0 in range(j_lo, max(j_hi, j_lo), third):
                     m = min(third, j_hi - j0)
-                    to_ext(polys["pa"].coeff.at(j0 * rows * B), d_eb.ptr, m)
-                    to_ext(polys["ps"].coeff.at(j0 * rows * B), d_eb.at(third * ne * B), m)
-                    to_ext(polys["zl"].coeff.at(j0 * rows * B), d_eb.at(2 * third * ne * B), m)
+                    to_ext(polys["pa"].coeff.at((j0 - l_lo) * rows * B), d_eb.ptr, m)
+                    to_ext(polys["ps"].coeff.at((j0 - l_lo) * rows * B), d_eb.at(third * ne * B), m)
+                    to_ext(polys["zl"].coeff.at((j0 - l_lo) * rows * B), d_eb.at(2 * third * ne * B), m)
+                    f_4.skip_to(5 * j0, 5 * m)
                     check(lib.vdb_lookup_eval_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
                                                   _sz(m), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
+            # my lookup columns that complete another rank's set (the head of the lookup columns, at the advice / lookup junction):
+            # their lookup argument is mine all the same, and comes first in the order of the terms
+            stray_lk = sorted(c for c in self.stray if c >= n_adv)
+            if stray_lk:
+                assert stray_lk == list(range(stray_lk[0], stray_lk[0] + len(stray_lk)))
+                base, col0 = adv_ext_block(stray_lk[0], len(stray_lk))
+                lookup_terms(base, col0, stray_lk[0] - n_adv, stray_lk[-1] + 1 - n_adv)
+            assert all(c >= n_adv for c in self.stray), "an advice column outside its rank's sets"
+            for s_lo, s_hi in self.set_ranges:
+                p_lo, p_hi = self.map.range_cols((s_lo, s_hi))
+                for c0 in range(p_lo, p_hi, blk):
+                    nb = min(blk, p_hi - c0)
+                    base, col0 = adv_ext_block(c0, nb)
+                    g0, g1 = max(c0, a_lo), min(c0 + nb, a_hi)
+                    if g0 < g1:                                            # gates of the block's advice columns
+                        check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at((g0 - a_lo) * rows * B), d_eb.ptr, _sz(g1 - g0), k, GATE_EXT_K))
+                        f_g.skip_to(g0, g1 - g0)
+                        check(lib.vdb_gate_eval_sub_dev(col_ptr(base, col0, g0), EXT_K, d_eb.ptr, _sz(g1 - g0), k, GATE_EXT_K, p["y"], ag.ptr))
+                    # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
+                    set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
+                    z0 = max(set_lo - 1, 0)
+                    to_ext(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, nb)
+                    if z0 < set_lo and (z0 in z_slot or z0 < s_lo):          # the set in front is another rank's (or another range's)
+                        to_ext(z_coeff(z0), d_ez.ptr, 1)
+                        to_ext(z_coeff(set_lo), d_ez.at(ne * B), set_hi - set_lo)
+                    else:
+                        to_ext(z_coeff(z0), d_ez.ptr, set_hi - z0)
+                    if max(set_lo, 1) < set_hi:
+                        f_2.skip_to(max(set_lo, 1) + 1, set_hi - max(set_lo, 1))
+                        check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
+                                                                 _sz(0), _sz(0)))
+                    f_3.skip_to(set_lo, set_hi - set_lo)
+                    check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 0, _sz(0), _sz(0), _sz(set_lo),
+                                                             _sz(set_hi)))
+                    # lookup argument of the block's lookup columns that are mine
+                    j_lo, j_hi = max(c0 - n_adv, l_lo), min(c0 + nb - n_adv, l_hi)
+                    lookup_terms(base, col0, j_lo, j_hi)
+            for f in (f_g, f_2, f_3, f_4):
+                f.finish()
             # join the groups that live on the 4 n points (acc_next += y^(terms of the next group) * acc), divide, back to coefficients
             y_int = _fr_to_int(ch["y"])
-            n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
             check(lib.vdb_poly_axpy_dev(a3.ptr, api._p(_fr_from_int(pow(y_int, n3, R_MOD))), a2.ptr, _sz(ne)))
             check(lib.vdb_poly_axpy_dev(a4.ptr, api._p(_fr_from_int(pow(y_int, n4, R_MOD))), a3.ptr, _sz(ne)))
             check(lib.vdb_memcpy_d2d(d_h.ptr, a4.ptr, _sz(ne * B)))
@@ -714,9 +993,10 @@ class ProverRounds:
             check(lib.vdb_divide_by_vanishing_dev(ag.ptr, k, GATE_EXT_K))
             check(lib.vdb_extended_to_coeff_dev(ag.ptr, _sz(1), k, GATE_EXT_K))
             check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
+            comm.sum_field_dev(d_h.ptr, ne)                      # every rank's share of h (nothing to do on one rank)
         stage("quotient", quotient)
         n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
-        polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)))
+        polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)), replicated=True)
         write_points(polys["h"].commits)
         squeeze("x")
 
@@ -725,8 +1005,8 @@ class ProverRounds:
         allp = {**polys, **fx}
         opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
-        opened = {rot: [name for name in names if allp[name].n_cols] for rot, names in opened.items()}    # a circuit without lookups
-        opened = {rot: names for rot, names in opened.items() if names}                                  # opens nothing at w^-1 x
+        opened = {rot: [name for name in names if allp[name].n_total] for rot, names in opened.items()}    # a circuit without lookups
+        opened = {rot: names for rot, names in opened.items() if names}                                   # opens nothing at w^-1 x
         x_int = _fr_to_int(ch["x"])
         w_int = _fr_to_int(api.root_of_unity(k))
         evals, points = {}, {}
@@ -741,6 +1021,23 @@ class ProverRounds:
                 out = np.zeros((q.n_cols, 4), dtype=np.uint64)
                 check(lib.vdb_eval_polys_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), api._p(_fr_from_int(points[rot])), api._p(out)))
                 evals[(name, rot)] = out
+            if world > 1:
+                # every rank evaluated its own polynomials: one exchange puts every group's evaluations in the global order
+                # (the polynomials every rank holds are not exchanged)
+                shared = [(rot, name) for rot, name in groups if not allp[name].replicated]
+                whole = np.zeros((sum(allp[name].n_total for _rot, name in shared), 4), dtype=np.uint64)
+                o = 0
+                for rot, name in shared:
+                    q, loc = allp[name], 0
+                    for lo, hi in q.ranges:
+                        whole[o + lo: o + hi] = evals[(name, rot)][loc: loc + hi - lo]
+                        loc += hi - lo
+                    o += q.n_total
+                whole = comm.sum_disjoint(whole)
+                o = 0
+                for rot, name in shared:
+                    evals[(name, rot)] = np.ascontiguousarray(whole[o: o + allp[name].n_total])
+                    o += allp[name].n_total
 
         def evaluate_and_absorb():
             # the device evaluates group i + 1 while the host absorbs the evaluations of group i (the sponge's host work — ~6 us per four
@@ -772,7 +1069,7 @@ class ProverRounds:
                 api.sync()
                 d_ev.free()
 
-        if tr is not None and timings is None and os.environ.get("VDB_EVAL_PIPELINE", "1") != "0":
+        if world == 1 and tr is not None and timings is None and os.environ.get("VDB_EVAL_PIPELINE", "1") != "0":
             evaluate_and_absorb()
         else:
             stage("evaluations", evaluate)
@@ -783,7 +1080,7 @@ class ProverRounds:
                 host["transcript"] += (time.perf_counter() - t0) * 1e3
         d_comb, d_quot = self.d_comb, self.d_quot
         if multiopen == "shplonk":
-            openings = self._shplonk(allp, opened, points, evals, p, ch, squeeze, write_points, stage)
+            openings = self._shplonk(allp, opened, points, evals, p, ch, squeeze, write_points, stage, power)
             proof = None
             if tr is not None:
                 proof = tr.proof()
@@ -821,14 +1118,19 @@ class ProverRounds:
                         instances=[_fr_to_int(v) for v in instances])
 
     # ------------------------------------------------------------------ SHPLONK multi-open (halo2 poly/kzg/multiopen/shplonk)
-    def _shplonk(self, allp, opened, points, evals, p, ch, squeeze, write_points, stage):
+    def _shplonk(self, allp, opened, points, evals, p, ch, squeeze, write_points, stage, power):
         """Polynomials opened at the same set of points form a rotation set S.  With q_S = the set's polynomials combined with
         powers of yo, r_S the interpolant of q_S's values on S and Z_S the vanishing polynomial of S:
             f = sum_S v^(m-1-s) (q_S - r_S) / Z_S                          -> commitment W1, then u,
             L = sum_S v^(m-1-s) Z_{T minus S}(u) (q_S - r_S(u)) - Z_T(u) f,  L(u) = 0  -> W2 = commit(L / (X - u)).
         The polynomial work (combinations, divisions by the linear factors, scaled sums, commits) runs on the device; the
-        interpolants have at most four points and are host integers."""
+        interpolants have at most four points and are host integers.
+        Sharded: q_S is a sum over the set's polynomials, so each rank combines the ones it holds (their powers of yo by their
+        place in the whole set); the quotient of a division by Z_S — the remainder dropped — and L's division by X - u are
+        linear, so every rank commits its share of f and of L / (X - u) and the shares are added as points (vdb_g1_sum: RCCL has no
+        curve operator, two 64-byte points per rank are gathered)."""
         lib, rows = self.lib, self.rows
+        comm, world, rank = self.comm, self.world, self.rank
         R = R_MOD
         by_poly = {}
         for rot, names in opened.items():
@@ -874,15 +1176,38 @@ class ProverRounds:
                 acc = acc * (x - points[rot]) % R
             return acc
 
+        def combine(names, dest):
+            """dest <- this rank's share of the set's polynomials combined with powers of yo: polynomial j of the M the set has in
+            all enters with yo^(M - 1 - j).  Horner over the ones held here; a stretch another rank holds multiplies by yo^(its length)."""
+            check(lib.vdb_memset_dev(dest.ptr, 0, _sz(rows * B)))
+            pos, base, live = 0, 0, False
+            for name in names:
+                q = allp[name]
+                loc = 0
+                for lo, hi in (q.ranges if (not q.replicated or rank == 0) else []):
+                    if live and base + lo > pos:
+                        check(lib.vdb_poly_scale_dev(dest.ptr, api._p(power("yo", base + lo - pos)), _sz(rows)))
+                    check(lib.vdb_poly_lincomb_dev(q.coeff.at(loc * rows * B), _sz(hi - lo), _sz(rows), p["yo"], dest.ptr))
+                    pos, live, loc = base + hi, True, loc + hi - lo
+                base += q.n_total
+            if live and base > pos:
+                check(lib.vdb_poly_scale_dev(dest.ptr, api._p(power("yo", base - pos)), _sz(rows)))
+
+        def share(point):
+            """the sum over the ranks of their partial commitments"""
+            if world == 1:
+                return point
+            out = np.zeros((1, 8), dtype=np.uint64)
+            parts = np.ascontiguousarray(comm.gather_rows(np.asarray(point, dtype=np.uint64).reshape(1, 8)))
+            check(lib.vdb_g1_sum(api._p(parts), _sz(world), _sz(1), api._p(out)))
+            return out[0]
+
         r_polys, rems = [], []
 
         def quotient_f():
             check(lib.vdb_memset_dev(d_f.ptr, 0, _sz(rows * B)))
             for s_i, (rots, names) in enumerate(sets):
-                check(lib.vdb_memset_dev(d_q[s_i].ptr, 0, _sz(rows * B)))
-                for name in names:
-                    q = allp[name]
-                    check(lib.vdb_poly_lincomb_dev(q.coeff.ptr, _sz(q.n_cols), _sz(rows), p["yo"], d_q[s_i].ptr))
+                combine(names, d_q[s_i])
                 vals = []
                 for rot in rots:                                   # the set's evaluations at this point, combined with powers of yo (host, compiled)
                     acc = np.zeros(4, dtype=np.uint64)
@@ -892,12 +1217,14 @@ class ProverRounds:
                     vals.append(_fr_to_int(acc))
                 r = interpolate([points[rot] for rot in rots], vals)
                 r_polys.append(r)
-                # (q_S - r_S) / Z_S: the low coefficients on the host, one division per point on the device
+                # (q_S - r_S) / Z_S: the low coefficients on the host, one division per point on the device.  (r_S has fewer
+                # coefficients than Z_S has roots: it changes the remainders only, which is why a rank's share needs no r_S.)
                 check(lib.vdb_memcpy_d2d(d_a.ptr, d_q[s_i].ptr, _sz(rows * B)))
-                low = np.zeros((len(r), 4), dtype=np.uint64)
-                check(lib.vdb_memcpy_d2h(api._p(low), d_a.ptr, _sz(low.nbytes)))
-                low = np.stack([_fr_from_int(_fr_to_int(low[i]) - r[i]) for i in range(len(r))])
-                check(lib.vdb_memcpy_h2d(d_a.ptr, api._p(low), _sz(low.nbytes)))
+                if world == 1:
+                    low = np.zeros((len(r), 4), dtype=np.uint64)
+                    check(lib.vdb_memcpy_d2h(api._p(low), d_a.ptr, _sz(low.nbytes)))
+                    low = np.stack([_fr_from_int(_fr_to_int(low[i]) - r[i]) for i in range(len(r))])
+                    check(lib.vdb_memcpy_h2d(d_a.ptr, api._p(low), _sz(low.nbytes)))
                 src, dst = d_a, d_b
                 for rot in rots:
                     rem = np.zeros((1, 4), dtype=np.uint64)
@@ -905,7 +1232,7 @@ class ProverRounds:
                     rems.append(_fr_to_int(rem[0]))
                     src, dst = dst, src
                 check(lib.vdb_poly_lincomb_dev(src.ptr, _sz(1), _sz(rows), p["v"], d_f.ptr))          # f = f v + (q_S - r_S) / Z_S
-            return self._commit(d_f, 1, 0)[0]
+            return share(self._commit(d_f, 1, 0)[0])
         W1 = stage("openings", quotient_f)
         write_points([W1])
         squeeze("u")
@@ -920,14 +1247,15 @@ class ProverRounds:
                 check(lib.vdb_poly_axpy_dev(d_a.ptr, api._p(_fr_from_int(coef)), d_q[s_i].ptr, _sz(rows)))
                 const = (const + coef * at(r_polys[s_i], u)) % R
             check(lib.vdb_poly_axpy_dev(d_a.ptr, api._p(_fr_from_int(-vanish(all_rots, u))), d_f.ptr, _sz(rows)))
-            c0 = np.zeros((1, 4), dtype=np.uint64)
-            check(lib.vdb_memcpy_d2h(api._p(c0), d_a.ptr, _sz(32)))
-            c0[0] = _fr_from_int(_fr_to_int(c0[0]) - const)
-            check(lib.vdb_memcpy_h2d(d_a.ptr, api._p(c0), _sz(32)))
+            if rank == 0:                                     # the constant term belongs to one share
+                c0 = np.zeros((1, 4), dtype=np.uint64)
+                check(lib.vdb_memcpy_d2h(api._p(c0), d_a.ptr, _sz(32)))
+                c0[0] = _fr_from_int(_fr_to_int(c0[0]) - const)
+                check(lib.vdb_memcpy_h2d(d_a.ptr, api._p(c0), _sz(32)))
             rem = np.zeros((1, 4), dtype=np.uint64)
             check(lib.vdb_kate_div_dev(d_a.ptr, _sz(1), _sz(rows), p["u"], d_b.ptr, api._p(rem)))
             rems.append(_fr_to_int(rem[0]))
-            return self._commit(d_b, 1, 0)[0]
+            return share(self._commit(d_b, 1, 0)[0])
         W2 = stage("openings", linearisation)
         write_points([W2])
         for b in d_q + [d_f]:
@@ -939,7 +1267,8 @@ class ProverRounds:
             q.free()
         self.fixed = {}
         self._vk_digest = None
-        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32", "d_inst_lag", "d_inst_coeff", "d_inst_ext", "d_inst_cells"):
+        for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32", "d_inst_lag", "d_inst_coeff", "d_inst_ext", "d_inst_cells",
+                     "d_foreign_lag", "d_foreign_coeff", "d_zhalo"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

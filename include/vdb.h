@@ -367,6 +367,9 @@ int vdb_fill_rows_dev(vdb_fr *cols_dev, size_t n_cols, size_t n, size_t from_row
  * polynomial of a SHPLONK rotation set — is this call once per point. */
 /* acc <- acc + a * x over n coefficients (SHPLONK's linearisation polynomial is a sum of polynomials with unrelated scalars) */
 int vdb_poly_axpy_dev(vdb_fr *acc_dev, const vdb_fr *a, const vdb_fr *x_dev, size_t n);
+/* x <- a * x over n elements.  The sharded prover rounds use it for what a rank does not hold: a fold acc <- acc y + term that
+ * skips g terms of other ranks is acc <- y^g acc, and a rank's running products start from the product of all earlier ranks'. */
+int vdb_poly_scale_dev(vdb_fr *x_dev, const vdb_fr *a, size_t n);
 int vdb_poly_lincomb_dev(const vdb_fr *polys_dev, size_t n_cols, size_t n, const vdb_fr *v, vdb_fr *acc_dev);
 int vdb_kate_div_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb_fr *x, vdb_fr *quot_dev, vdb_fr *rem_host);
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */

@@ -1,0 +1,67 @@
+"""The prover rounds sharded over ranks (halo2_vectordb_amd/rounds.py with a dist.Comm; SURVEY §8e, north_star's "partitioned
+across the GPUs of one node ... all-reduce only for the final coefficient reduction"): a proof made by two or three ranks —
+launched as the driver launches bench.py, torch.distributed.run with one process per rank, here sharing this box's one GPU over
+gloo (VDB_DIST_BACKEND=gloo; the same code runs over RCCL on a multi-GPU node) — is, with the same blinding seeds, BYTE FOR BYTE
+the proof one rank makes; and the stand-alone verifier accepts those bytes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, circuit, out, port, extra=()):
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    script = os.path.join(ROOT, "tools", "sharded_prove.py")
+    if world == 1:
+        cmd = [sys.executable, script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    res = subprocess.run(cmd + ["--circuit", circuit, "--out", out, *extra], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("circuit,worlds", [("kmeans", (2, 3)), ("merkle", (2,)), ("c2", (2,))])
+def test_sharded_proof_is_the_single_rank_proof(tmp_path, circuit, worlds):
+    one = _run(1, circuit, str(tmp_path / "p1.bin"), 0)
+    assert one["every_rank_wrote_the_same_bytes"] and one["quotient_identity_at_x_holds"] and one["mock_prover_violations"] == 0
+    want = open(tmp_path / "p1.bin", "rb").read()
+    for i, world in enumerate(worlds):
+        rep = _run(world, circuit, str(tmp_path / f"p{world}.bin"), 29541 + i)
+        assert rep["world"] == world and rep["every_rank_wrote_the_same_bytes"] and rep["quotient_identity_at_x_holds"]
+        got = open(tmp_path / f"p{world}.bin", "rb").read()
+        assert got == want, (circuit, world, rep)
+        assert rep["sha256"] == one["sha256"] and rep["n_instances"] == one["n_instances"]
+
+
+def test_sharded_streamed_proof_and_the_verifier(tmp_path, O):
+    """two ranks, cosets held 7 columns at a time and blocks of 12 columns (the streamed rounds): the same bytes again, and the
+    stand-alone verifier of tests/test_gpu_rounds.py accepts them against the gathered fixed commitments"""
+    from halo2_vectordb_amd import api
+    from oracle import pairing as PR
+    from test_gpu_rounds import TAU, _verify
+    api.init(0)
+    one = _run(1, "kmeans", str(tmp_path / "p1.bin"), 0)
+    two = _run(2, "kmeans", str(tmp_path / "p2.bin"), 29547, extra=("--ext-block-cols", "7", "--block-cols", "12"))
+    proof = open(tmp_path / "p2.bin", "rb").read()
+    assert proof == open(tmp_path / "p1.bin", "rb").read()
+    with np.load(str(tmp_path / "p2.bin") + ".vk.npz", allow_pickle=False) as doc:
+        meta = json.loads(bytes(doc["meta"]).decode())
+        fixed = {name[6:]: np.ascontiguousarray(doc[name]) for name in doc.files if name.startswith("fixed_")}
+        instances = [int(v) for v in doc["instances"]]
+    with np.load(str(tmp_path / "p1.bin") + ".vk.npz", allow_pickle=False) as doc:
+        for name in fixed:                       # the sharded keygen gathers the same verifying key
+            assert np.array_equal(fixed[name], doc["fixed_" + name]), name
+    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND, _fr_to_int
+    vk = dict(meta=dict(rows=meta["rows"], k=meta["k"], n_adv=meta["n_adv"], n_lk=meta["n_lk"], n_cols=meta["n_cols"], n_sets=meta["n_sets"], chunk_len=CHUNK_LEN,
+                        n_blind=N_BLIND, delta=_fr_to_int(api.fr_delta()), n_instances=len(instances)),
+              opened={int(r): v for r, v in meta["opened"].items()}, fixed=fixed, tau_h=PR.pt_mul(PR.G2, TAU), instances=instances)
+    assert _verify(O, api, proof, vk)
+    assert not _verify(O, api, proof, {**vk, "instances": instances[:-1] + [(instances[-1] + 1) % O.R_MOD]})
+    assert one["sha256"] == two["sha256"]

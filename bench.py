@@ -98,7 +98,30 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     ns = cols_sample.shape[0]
     total_cells = hp.n_cells + hp.n_lookup
     t_full = t_wit * hp.I + (t_msm + t_ntt) * hp.n_cols / ns
+    # unit costs of what the rest of create_proof is made of (the oracle's C restatements that check polyops.hip), for the
+    # whole-proof estimate main() attaches once the proved circuit's shape is known
+    rng = np.random.default_rng(1)
+    n = hp.rows
+    dense = O.random_fr(rng, 8 * n).reshape(8, n, 4)
+    t0 = time.perf_counter()
+    O.msm_batch(dense, hp.g_lagrange, threads=cores)
+    t_dense = (time.perf_counter() - t0) / 8                     # per column of full-width scalars (products, permuted columns' z)
+    t0 = time.perf_counter()
+    O.grand_product(dense[:4], dense[4:])
+    t_gp = (time.perf_counter() - t0) / 4                        # per column, one thread
+    t0 = time.perf_counter()
+    O.eval_polys(dense[:4], dense[4, 0])
+    t_eval = (time.perf_counter() - t0) / 4                      # per polynomial, one thread
+    t0 = time.perf_counter()
+    O.fr_mul(dense.reshape(-1, 4)[: 4 * n], dense.reshape(-1, 4)[4 * n:])
+    t_mul = (time.perf_counter() - t0) / (4 * n)                 # per field product, one thread
+    t0 = time.perf_counter()
+    np.sort(rng.integers(0, 1 << 15, size=n))
+    t_sort = time.perf_counter() - t0                            # per lookup column (stand-in for permute_expression_pair's sort)
+    units = {"witness_s_per_cell": t_wit / cells_one_iter, "msm_witness_col_s": t_msm / ns, "ntt_pair_col_s": t_ntt / ns, "msm_dense_col_s": t_dense,
+             "grand_product_col_s_1thread": t_gp, "eval_poly_s_1thread": t_eval, "fr_mul_s_1thread": t_mul, "sort_col_s_1thread": t_sort}
     return {
+        "proof_unit_costs": units,
         "value": total_cells / t_full, "unit": "constraints/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
         "sample": (f"oracle C restatement: 1 of {hp.I} k-means iterations of witness gen single-threaded ({t_wit:.2f} s, "
                    f"{cells_one_iter} cells), Pippenger MSM + iNTT/coset-NTT of {ns} of {hp.n_cols} real columns on {cores} threads "
@@ -109,37 +132,87 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     }
 
 
-def whole_proof(api):
+def cpu_proof_estimate(units, cores, shape):
+    """What create_proof costs the CPU port for a circuit of `shape` (cells, n_adv, n_lk, n_sets, n_evals, rows), from the unit
+    costs cpu_baseline measured on this host: a count of halo2's steps ([UPSTREAM-RECALL] create_proof: per committed column one
+    MSM, one lagrange_to_coeff and one coset transform; per lookup column a sort, two commitments and a grand product; per
+    permutation set a grand product over three columns; the quotient's terms on the 4 n points; one Horner pass per evaluation;
+    SHPLONK's two linear combinations of every polynomial) times those unit costs, work that is parallel over columns divided by
+    the cores.  An estimate of the port, kind "port": the reference's Rust prover cannot run here."""
+    n, n_adv, n_lk, n_sets = shape["rows"], shape["n_adv"], shape["n_lk"], shape["n_sets"]
+    n_cols, n_perm = n_adv + n_lk, n_adv + n_lk + 2
+    u, par = units, float(cores)
+    mul = u["fr_mul_s_1thread"] / par
+    parts = {
+        "witness (one thread)": u["witness_s_per_cell"] * shape["cells"],
+        "advice: commit + transforms": n_cols * (u["msm_witness_col_s"] + u["ntt_pair_col_s"]),
+        "lookup: permute, 2 commits + transforms": n_lk * (u["sort_col_s_1thread"] / par + 2 * (u["msm_witness_col_s"] + u["ntt_pair_col_s"])),
+        "products: terms + grand products": (n_perm * n * 4 + n_lk * n * 4) * mul + (n_sets + n_lk) * u["grand_product_col_s_1thread"] / par,
+        "products: commits + transforms": (n_sets + n_lk) * (u["msm_dense_col_s"] + u["ntt_pair_col_s"]),
+        "quotient on 4 n points": 4 * n * (3 * n_adv + 8 * n_perm + 14 * n_lk) * mul + 5 * u["ntt_pair_col_s"],
+        "evaluations": shape["n_evals"] * u["eval_poly_s_1thread"] / par,
+        "multi-open": 2 * (3 * n_cols + n_adv + n_perm + n_sets * 3 + n_lk * 4) * n * mul + 6 * u["msm_dense_col_s"],
+    }
+    return sum(parts.values()), {k: round(v, 2) for k, v in parts.items()}
+
+
+def whole_proof(api, rank=0, world=1, comm=None):
     """BASELINE.json's metric also asks for the proof-generation time.  The whole proof — advice round (= the hot path above),
     lookup permutation, running products, quotient, evaluations, SHPLONK, Fiat–Shamir transcript, fresh blinding — with the
     circuit's whole constraint map in the permutation argument (halo2_vectordb_amd/rounds.py), of the SATISFIABLE k = 16
     k-means circuit: the cosine variant the reference's example runs (examples/kmeans.rs:48-49; the Euclidean one cannot be
     proven).  1.37 G cells, 20,969 columns: larger than HBM with its cosets, so the rounds stream it in column
-    blocks.  Reported beside the bench line, never as `value`."""
+    blocks.  Reported beside the bench line, never as `value`.
+    With N > 1 the rounds are sharded by the hot path's column blocks (rounds.ProverRounds with a dist.Comm): every rank proves
+    its columns and sets, commitments / evaluations / the quotient's shares are exchanged over RCCL, every rank ends with the
+    same proof bytes; `proof_ms` is then the slowest rank's wall time (barrier before, max over ranks after)."""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     t0 = time.perf_counter()
-    hp = KmeansHotPath(n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="cosine")
+    hp = KmeansHotPath(n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="cosine", col_shard=(rank, world))
     hp.ext_block_cols = 256          # the rounds recompute the cosets block by block; HBM goes to the proving key
     hp.setup()
-    pr = ProverRounds(hp).keygen()
+    pr = ProverRounds(hp, comm=comm).keygen()
     keygen_s = time.perf_counter() - t0
+
+    def everyone(ms):
+        """the slowest rank's figure"""
+        if comm is None:
+            return ms
+        return float(comm.gather_rows(np.array([ms], dtype=np.float64).view(np.uint64)).view(np.float64).max())
     # untimed proofs for `proof_ms` (the host's transcript work runs beside whatever the device still has queued), then one
     # instrumented proof for the device time per stage (its timers wait for the device after every stage)
     best = None
     for _ in range(2):
+        if comm is not None:
+            api.sync()
+            comm.barrier()
         t0 = time.perf_counter()
         out = pr.prove(None)
-        wall = (time.perf_counter() - t0) * 1e3
+        api.sync()
+        wall = everyone((time.perf_counter() - t0) * 1e3)
         if best is None or wall < best[0]:
             best = (wall, dict(pr.host_ms), out)
     wall, host_ms, out = best
+    # the satisfiable circuit's hot path on its own (witness -> commit -> lagrange_to_coeff -> the cosets streamed through the
+    # buffer block after block), so that its throughput is measured by the run that reports it
+    hot = []
+    for _ in range(3):
+        if comm is not None:
+            api.sync()
+            comm.barrier()
+        t0 = time.perf_counter()
+        hp.step()
+        hot.append(everyone((time.perf_counter() - t0) * 1e3))
     T = {}
     pr.prove(None, timings=T)
     rep = pr.keygen_report
     res = {"circuit": "kmeans K=4 I=8 over 256x128, P=48, LOOKUP_BITS=15, COSINE (the satisfiable variant of BASELINE configs[3]), k=16",
            "cells": hp.n_cells + hp.n_lookup, "columns": hp.n_cols, "product_columns": pr.n_sets + pr.n_lk,
-           "proof_ms": wall, "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
+           "shape": {"cells": hp.n_cells + hp.n_lookup, "rows": hp.rows, "n_adv": pr.n_adv, "n_lk": pr.n_lk, "n_sets": pr.n_sets,
+                     "n_evals": int(sum(len(v) for v in out["evals"].raw.values()))},
+           "n_gpus": world, "proof_ms": wall, "hot_path_ms": min(hot), "hot_path_constraints_per_s": (hp.n_cells + hp.n_lookup) / (min(hot) * 1e-3),
+           "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
            "constraints_per_s": (hp.n_cells + hp.n_lookup) / (wall * 1e-3), "proof_bytes": len(out["proof"]),
            "keygen_and_setup_s": round(keygen_s, 1),
            "n_instances": len(out["instances"]),        # the public statement: the K x dim centroid words, tied to the instance column
@@ -296,15 +369,28 @@ def main():
             cpu = cpu_baseline(hp, cols, commitments[idx])
 
     proof = None
-    if rank == 0 and world == 1 and not args.no_proof and not args.small:
+    if not args.no_proof and not args.small:
         try:
             from halo2_vectordb_amd._lib import check as _check
             hp.free()
             _check(api.init().vdb_scratch_release())
-            proof = whole_proof(api)
+            comm = None
+            if dist is not None:
+                from halo2_vectordb_amd.dist import Comm
+                comm = Comm(dist)
+            proof = whole_proof(api, rank, world, comm)
         except Exception as e:      # the bench line above stands on its own
+            if dist is not None:
+                raise               # a rank that drops out of a sharded proof leaves the others waiting in a collective
             proof = {"error": repr(e)[:300]}
 
+    if rank == 0 and cpu is not None and proof is not None and "shape" in proof:
+        est, parts = cpu_proof_estimate(cpu["proof_unit_costs"], cpu["cores"], proof["shape"])
+        cpu["est_full_proof_s"] = est
+        cpu["est_full_proof_parts_s"] = parts
+        cpu["est_full_proof_note"] = ("the CPU port's unit costs above x the step counts of create_proof for the circuit of `proof` (cosine k-means, k = 16): the "
+                                      "neighbour of proof.proof_ms; an estimate, not a run")
+        proof["vs_cpu_port_estimate"] = est / (proof["proof_ms"] * 1e-3)
     if rank == 0:
         out = {
             "metric": "constraints/sec, proving hot path (witness+layout+commit MSM+NTT), kmeans k=16 circuit",

@@ -164,6 +164,44 @@ def test_sharded_ranks_reproduce_the_unsharded_job(api, O, world, metric):
     assert np.array_equal(np.concatenate(adv + lk), want_commit)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_nearest_vector_ranks_reproduce_the_unsharded_job(api, O, world):
+    """SURVEY §8(e) for nearest_vector: "gather N distances then the short min chain" — here every rank computes the N distance
+    values and the minimum chain itself (value-only walk, no exchange) and stores only the cells of its own columns.  Ranks
+    emulated one after another on one GPU with a poisoned stream: columns, commitments, indicator and result vector equal the
+    unsharded job's."""
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    cfg = dict(n=9, dim=6, k=11, P=48, L=10, seed=23, blind_seed=4)
+    full = NearestHotPath(**cfg).setup()
+    want_commit = full.step().copy()
+    full.relayout()
+    want_cols = full.download_columns(list(range(full.n_cols)))
+    want_ind, want_res = full.results()
+    assert full.n_adv_cols >= 2 * world and full.n_lk_cols >= 1
+    full.free()
+    adv, lk, stored = [], [], []
+    for r in range(world):
+        hp = NearestHotPath(col_shard=(r, world), **cfg).setup()
+        assert hp.shard_witness
+        assert hp.lib.vdb_memset_dev(hp.d_stream.ptr, 0xA5, hp.n_cells * 32) == 0
+        assert hp.lib.vdb_memset_dev(hp.d_lookup.ptr, 0xA5, max(hp.n_lookup, 1) * 32) == 0
+        got = hp.step().copy()
+        adv.append(got[: hp.my_adv])
+        lk.append(got[hp.my_adv:])
+        hp._witness()
+        api.sync()
+        poison = np.full(4, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+        stored.append(int((hp.d_stream.download((hp.n_cells, 4)) != poison).any(axis=1).sum()))
+        hp.relayout()
+        mine = hp.global_columns()
+        assert np.array_equal(hp.download_columns(mine), want_cols[mine]), f"rank {r} columns"
+        ind, res = hp.results()
+        assert np.array_equal(ind, want_ind) and np.array_equal(res, want_res)
+        hp.free()
+    assert np.array_equal(np.concatenate(adv + lk), want_commit)
+    assert max(stored) < 0.75 * sum(stored)               # no rank stores (nearly) the whole witness any more
+
+
 def test_pinning_file_keygen_then_prove(api, O, tmp_path):
     """Keygen arm writes configs/{name}.json, Prove arm reads it back (src/scaffold/mod.rs:272, 285-287): same break
     points, same commitments; a pinning of another circuit is refused."""

@@ -335,3 +335,26 @@ def test_two_device_contexts_in_one_process(api, O):
         os.environ.pop("VDB_TEST_ALIAS_DEVICES", None)
         api.shutdown()
         api.init(0)
+
+
+@pytest.mark.parametrize("window_bits", [13, 14])
+def test_msm_wide_windows(api, O, window_bits):
+    """the windows chosen for columns of full-width scalars (product columns, Poseidon states; api.Srs(window_bits=14)): dense
+    columns, a witness-like mix in which short and long scalars share wavefronts, edge values, ragged length; against the oracle"""
+    rng = np.random.default_rng(300 + window_bits)
+    k = 11
+    n = 1 << k
+    g, gl = O.srs_from_tau(k, 0xD161 + window_bits)
+    srs = api.Srs(k, g, gl, window_bits=window_bits)
+    assert srs.info()[1] == window_bits
+    cols = O.random_fr(rng, 6 * n).reshape(6, n, 4)
+    cols[1] = witness_like(O, rng, n)
+    cols[2] = 0
+    cols[3] = O.fr_from_ints([R - 1] * n)
+    cols[4, ::3] = O.fr_from_ints([int(v) for v in rng.integers(0, 1 << 15, size=len(range(0, n, 3)))])     # short among long, lane by lane
+    cols[0, :8] = O.fr_from_ints([0, 1, R - 1, (R - 1) // 2, (R + 1) // 2, 1 << 253, (1 << 42) - 1, 1 << 41])
+    for basis, bases in ((1, gl), (0, g)):
+        assert np.array_equal(api.msm_batch(srs, cols, basis=basis), O.msm_batch(cols, bases, threads=4)), basis
+    short = cols[:, : n - 37]
+    assert np.array_equal(api.msm_batch(srs, short, basis=0), O.msm_batch(short, g[: n - 37], threads=4))
+    srs.free()

@@ -90,7 +90,9 @@ _SIGNATURES = {
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
     "vdb_scratch_release": [], "vdb_mem_info": [_P, _P],
     "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P, _U64, _P],
-    "vdb_gather_fr_dev": [_P, _P, _SZ, _P], "vdb_mock_check_instances_dev": [_P, _U64, _P, _P, _U64, _P],
+    "vdb_gather_fr_dev": [_P, _P, _SZ, _P], "vdb_copymap_init_dev": [_U64, _U64, _P, _P, _P, _P],
+    "vdb_copymap_place_dev": [_P, _P, _P, _U64, _P, _U64, _P, _P, _P, _U64, _U64, _U64, _U64, _P, _P, _P, _P],
+    "vdb_copymap_finish_dev": [_P, _P, _U64, _P, _U64, _P, _P, _P], "vdb_mock_check_instances_dev": [_P, _U64, _P, _P, _U64, _P],
     "vdb_fill_rows_dev": [_P, _SZ, _SZ, _SZ, _P],
     "vdb_poly_axpy_dev": [_P, _P, _P, _SZ], "vdb_poly_scale_dev": [_P, _P, _SZ],
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],

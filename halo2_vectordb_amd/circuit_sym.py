@@ -585,7 +585,7 @@ def _distance_block(metric, dim, P, L):
     return Block(s, [out])
 
 
-def build_nearest(metric, n, dim, P, L):
+def build_nearest(metric, n, dim, P, L, builder=None):
     """nearest_vector(query, vectors) after [query | vectors] have been assigned (tests/vectordb/mod.rs:220-247): the map the
     whole-circuit trace gives, assembled from one distance block, one qmin block and the closing cells"""
     db = _distance_block(metric, dim, P, L)
@@ -596,7 +596,7 @@ def build_nearest(metric, n, dim, P, L):
     iseq0 = qmin0 + (n - 1) * qm.n
     sel0 = iseq0 + 12 * n
     total = sel0 + dim * (1 + 3 * n)
-    B = _Builder(total, n * db.n_lk + (n - 1) * qm.n_lk)
+    B = (builder or _Builder)(total, n * db.n_lk + (n - 1) * qm.n_lk)
     query = np.arange(dim, dtype=np.int64)
     vec = dim + np.arange(n * dim, dtype=np.int64).reshape(n, dim)
     i = np.arange(n, dtype=np.int64)
@@ -618,10 +618,11 @@ def build_nearest(metric, n, dim, P, L):
     return B.finish(), (ind, res)
 
 
-def build_kmeans(metric, n, dim, K, I, P, L):
+def build_kmeans(metric, n, dim, K, I, P, L, builder=None):
     """kmeans::<K, I>(vectors) after the vectors have been assigned (examples/kmeans.rs:40-49), in the stream order of
     witness.hip (KmLayout): [one, zero] then per iteration N x (K distances, assignment), the sizes chain, and per cluster
-    (N filters, the sums chain, D divisions)"""
+    (N filters, the sums chain, D divisions).  `builder`: the class that holds the map's arrays (default: numpy on the host;
+    circuit_dev.DeviceBuilder assembles them on the GPU)"""
     db = _distance_block(metric, dim, P, L)
     s = Sym(P, L)
     ab = Block(s, s.assign_block(ext(0), ext(1), [ext(2 + k) for k in range(K)]))
@@ -638,7 +639,7 @@ def build_kmeans(metric, n, dim, K, I, P, L):
     it_cells, it_lk = assign + sizes + K * per_cluster, assign_l + K * per_cluster_l
     n_in = n * dim
     total, total_l = n_in + 2 + I * it_cells, I * it_lk
-    B = _Builder(total, total_l)
+    B = (builder or _Builder)(total, total_l)
     one, zero = n_in, n_in + 1
     B.constant_cell(one, quantize(1.0, P))
     B.constant_cell(zero, 0)

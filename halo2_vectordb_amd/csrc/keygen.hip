@@ -109,9 +109,155 @@ __global__ __launch_bounds__(256) void k_pm_link(const uint64_t* __restrict__ ke
   }
 }
 
+// ---- the circuit's constraint map, instantiated on the device -------------------------------------------------------------
+// The gadgets' copy structure is data independent and repeats: one traced block (a distance, a per-vector assignment, a filter, a
+// division: circuit_sym.py) is placed at hundreds of thousands of stream offsets.  Block cell codes: src >= 0 copies block cell src,
+// src <= MAP_EXT0 is external input number MAP_EXT0 - src of the instance, anything else ties the cell to nothing (itself).
+constexpr int64_t MAP_EXT0 = -10;
+__global__ __launch_bounds__(256) void k_map_iota(int64_t* __restrict__ a, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = (int64_t)i;
+}
+__global__ __launch_bounds__(256) void k_map_place(const int64_t* __restrict__ blk_src, const int64_t* __restrict__ blk_cid, const uint8_t* __restrict__ blk_flags,
+                                                  uint64_t n_blk, const int64_t* __restrict__ bases, const int64_t* __restrict__ ext, uint64_t m, uint64_t n_ext,
+                                                  uint64_t n_cells, int64_t* __restrict__ copy_of, int64_t* __restrict__ const_idx, uint8_t* __restrict__ flags,
+                                                  int* __restrict__ err) {
+  const uint64_t total = m * n_blk, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t inst = t / n_blk, c = t % n_blk;
+    const int64_t b = bases[inst], src = blk_src[c];
+    const uint64_t idx = (uint64_t)b + c;
+    if (b < 0 || idx >= n_cells) {
+      *err = 1;
+      continue;
+    }
+    int64_t val = (int64_t)idx;
+    if (src >= 0) val = b + src;
+    else if (src <= MAP_EXT0) {
+      const uint64_t e = (uint64_t)(MAP_EXT0 - src);
+      if (e >= n_ext) {
+        *err = 1;
+        continue;
+      }
+      val = ext[inst * n_ext + e];
+    }
+    copy_of[idx] = val;
+    const_idx[idx] = blk_cid[c];
+    flags[idx] = blk_flags[c];
+  }
+}
+__global__ __launch_bounds__(256) void k_map_place_lookups(const int64_t* __restrict__ blk_lk, uint64_t n_blk_lk, const int64_t* __restrict__ bases,
+                                                          const int64_t* __restrict__ lk_bases, const int64_t* __restrict__ ext, uint64_t m, uint64_t n_ext,
+                                                          uint64_t n_lookup, int64_t* __restrict__ lookup_src, int* __restrict__ err) {
+  const uint64_t total = m * n_blk_lk, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t inst = t / n_blk_lk, c = t % n_blk_lk;
+    const int64_t src = blk_lk[c], lb = lk_bases[inst];
+    if (lb < 0 || (uint64_t)lb + c >= n_lookup) {
+      *err = 1;
+      continue;
+    }
+    int64_t val;
+    if (src <= MAP_EXT0) {
+      const uint64_t e = (uint64_t)(MAP_EXT0 - src);
+      if (e >= n_ext) {
+        *err = 1;
+        continue;
+      }
+      val = ext[inst * n_ext + e];
+    } else {
+      val = bases[inst] + (src > 0 ? src : 0);
+    }
+    lookup_src[(uint64_t)lb + c] = val;
+  }
+}
+// parent[i] for vdb_permutation_mapping_dev: the fixed cell of its constant for a tied cell (which must copy nothing), else the cell it
+// copies; counts[0] = tied cells that copy another cell, counts[1] = lookup cells without a source
+__global__ __launch_bounds__(256) void k_map_finish(const int64_t* __restrict__ copy_of, const int64_t* __restrict__ const_idx, uint64_t n_cells,
+                                                   const int64_t* __restrict__ lookup_src, uint64_t n_lookup, int64_t* __restrict__ parent,
+                                                   unsigned long long* __restrict__ counts) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long bad = 0, nosrc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+    const int64_t c = const_idx[i], p = copy_of[i];
+    if (c >= 0 && p != (int64_t)i) bad++;
+    if (parent) parent[i] = c >= 0 ? (int64_t)n_cells + c : p;
+  }
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_lookup; j += stride)
+    if (lookup_src[j] < 0) nosrc++;
+  if (bad) atomicAdd(&counts[0], bad);
+  if (nosrc) atomicAdd(&counts[1], nosrc);
+}
+
 }  // namespace vdb
 
 using namespace vdb;
+
+extern "C" int vdb_copymap_init_dev(uint64_t n_cells, uint64_t n_lookup, int64_t* copy_of_dev, int64_t* const_idx_dev, uint8_t* flags_dev, int64_t* lookup_src_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(copy_of_dev && const_idx_dev && flags_dev && (lookup_src_dev || n_lookup == 0), "null pointer");
+  Context& cx = ctx();
+  hipLaunchKernelGGL(k_map_iota, dim3((unsigned)(cx.cu_count * 16)), dim3(256), 0, cx.stream, copy_of_dev, n_cells);
+  VDB_LAUNCH_CHECK();
+  VDB_HIP(hipMemsetAsync(const_idx_dev, 0xff, n_cells * sizeof(int64_t), cx.stream));   // -1: tied to no constant
+  VDB_HIP(hipMemsetAsync(flags_dev, 0, n_cells, cx.stream));
+  if (n_lookup) VDB_HIP(hipMemsetAsync(lookup_src_dev, 0xff, n_lookup * sizeof(int64_t), cx.stream));
+  return VDB_OK;
+}
+
+extern "C" int vdb_copymap_place_dev(const int64_t* blk_src_dev, const int64_t* blk_cid_dev, const uint8_t* blk_flags_dev, uint64_t n_blk, const int64_t* blk_lk_dev,
+                                     uint64_t n_blk_lk, const int64_t* bases_dev, const int64_t* lk_bases_dev, const int64_t* ext_dev, uint64_t m, uint64_t n_ext,
+                                     uint64_t n_cells, uint64_t n_lookup, int64_t* copy_of_dev, int64_t* const_idx_dev, uint8_t* flags_dev,
+                                     int64_t* lookup_src_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(blk_src_dev && blk_cid_dev && blk_flags_dev && bases_dev && copy_of_dev && const_idx_dev && flags_dev, "null pointer");
+  VDB_ARG((n_ext == 0 || ext_dev) && (n_blk_lk == 0 || (blk_lk_dev && lk_bases_dev && lookup_src_dev)), "null pointer");
+  if (m == 0 || n_blk == 0) return VDB_OK;
+  Context& cx = ctx();
+  int* derr = (int*)scratch_get(5, 64);
+  if (!derr) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), cx.stream));
+  const unsigned grid = (unsigned)(cx.cu_count * 16);
+  {
+    VDB_PROF("k_map_place");
+    hipLaunchKernelGGL(k_map_place, dim3(grid), dim3(256), 0, cx.stream, blk_src_dev, blk_cid_dev, blk_flags_dev, n_blk, bases_dev, ext_dev, m, n_ext, n_cells,
+                       copy_of_dev, const_idx_dev, flags_dev, derr);
+    if (n_blk_lk)
+      hipLaunchKernelGGL(k_map_place_lookups, dim3(grid), dim3(256), 0, cx.stream, blk_lk_dev, n_blk_lk, bases_dev, lk_bases_dev, ext_dev, m, n_ext, n_lookup,
+                         lookup_src_dev, derr);
+  }
+  VDB_LAUNCH_CHECK();
+  int herr = 0;
+  VDB_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));   // also: the caller's small host arrays may be reused after the call
+  if (herr) {
+    set_error("copy map: a block instance lies outside the stream, or names an external input it was not given");
+    return VDB_ERR_ARG;
+  }
+  return VDB_OK;
+}
+
+extern "C" int vdb_copymap_finish_dev(const int64_t* copy_of_dev, const int64_t* const_idx_dev, uint64_t n_cells, const int64_t* lookup_src_dev, uint64_t n_lookup,
+                                      int64_t* parent_dev, uint64_t* tied_not_root, uint64_t* lookups_without_source) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(copy_of_dev && const_idx_dev && tied_not_root && lookups_without_source && (lookup_src_dev || n_lookup == 0), "null pointer");
+  Context& cx = ctx();
+  unsigned long long* d = (unsigned long long*)scratch_get(5, 64);
+  if (!d) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), cx.stream));
+  {
+    VDB_PROF("k_map_finish");
+    hipLaunchKernelGGL(k_map_finish, dim3((unsigned)(cx.cu_count * 16)), dim3(256), 0, cx.stream, copy_of_dev, const_idx_dev, n_cells, lookup_src_dev, n_lookup,
+                       parent_dev, d);
+  }
+  VDB_LAUNCH_CHECK();
+  unsigned long long h[2];
+  VDB_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, cx.stream));
+  VDB_HIP(hipStreamSynchronize(cx.stream));
+  *tied_not_root = h[0];
+  *lookups_without_source = h[1];
+  return VDB_OK;
+}
 
 extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t* break_points, uint64_t n_bp, uint32_t k,
                                            const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,

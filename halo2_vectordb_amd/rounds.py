@@ -259,16 +259,16 @@ class ProverRounds:
         sigma cosets — 4x the columns — are produced block by block inside the quotient instead of being held).  With `ranges`
         the buffer holds this rank's part of a set of n_total polynomials: every rank commits its part, the commitments of the
         whole set are exchanged (they make the verifying key's digest); without, every rank holds the (small) whole."""
-        coeff = self._to_coeff(lag_buf, n_cols)
         commits = self._commit(lag_buf, n_cols, 1)
         if ranges is not None:
             commits = self._globalize(commits, ranges, n_total)
+        if keep_lag:
+            coeff = self._to_coeff(lag_buf, n_cols)
+        else:                      # transformed where it lies: no second buffer of tens of GB for the sigma columns and the selectors
+            check(self.lib.vdb_lagrange_to_coeff_dev(lag_buf.ptr, _sz(n_cols), self.k))
+            coeff, lag_buf = lag_buf, None
         p = _Poly(name, n_cols, lag=lag_buf, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=commits,
                   ranges=ranges, n_total=n_total, replicated=ranges is None)
-        if not keep_lag:
-            api.sync()
-            lag_buf.free()
-            p.lag = None
         self.fixed[name] = p
         return p
 
@@ -289,11 +289,15 @@ class ProverRounds:
             self.public_cells = [int(self.root_cell)]                               # examples/merkle.rs:47 make_public.push(root)
             return cm
         from . import circuit_sym as CS
+        from .circuit_dev import DeviceBuilder
+        # the unit blocks are traced on the host (a few thousand cells each); their hundreds of thousands of instances are placed
+        # by the device (circuit_dev.py): the map's 10^9-cell arrays never exist on the host
+        builder = DeviceBuilder if getattr(self, "map_on_device", True) else None
         if isinstance(hp, NearestHotPath):
-            cm, (_ind, res) = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L)
+            cm, (_ind, res) = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L, builder=builder)
             self.public_cells = [int(c) for c in res]                               # examples/query.rs:58 make_public.extend(result)
         else:
-            cm, (cent, _ind) = CS.build_kmeans(hp.metric_name, hp.n, hp.dim, hp.K, hp.I, hp.P, hp.L)
+            cm, (cent, _ind) = CS.build_kmeans(hp.metric_name, hp.n, hp.dim, hp.K, hp.I, hp.P, hp.L, builder=builder)
             self.public_cells = [int(c) for c in np.asarray(cent).reshape(-1)]      # examples/kmeans.rs:51-56: every centroid, word by word
         return cm
 
@@ -320,7 +324,9 @@ class ProverRounds:
         self.instance_cells = [int(c) for c in instance_cells]
         if len(self.instance_cells) > self.usable or any(not 0 <= c < hp.n_cells for c in self.instance_cells):
             raise ValueError("public cells outside the stream, or more of them than usable rows of the instance column")
-        if cm.n_cells != hp.n_cells or (cm.lookup_src is not None and len(cm.lookup_src) != hp.n_lookup):
+        on_dev = hasattr(cm, "d_copy_of")
+        n_src = cm.n_lookup if on_dev else (None if cm.lookup_src is None else len(cm.lookup_src))
+        if cm.n_cells != hp.n_cells or (n_src is not None and n_src != hp.n_lookup):
             raise ValueError("the constraint map does not describe this circuit (cell counts differ)")
         self.circuit = cm
         self.consts = [int(v) for v in cm.consts]
@@ -333,29 +339,41 @@ class ProverRounds:
         # the tests compare it with).  A map without lookup sources leaves the lookup columns untied: only the tests' negative
         # cases want that.
         from .pipeline import MINIMUM_ROWS
-        parent = cm.copy_of.astype(np.int64, copy=True)
-        tied = cm.const_idx >= 0
-        if (parent[tied] != np.flatnonzero(tied)).any():
-            raise ValueError("a cell tied to a constant must be the root of its copies")
-        parent[tied] = hp.n_cells + cm.const_idx[tied]
-        d_parent = api.DeviceBuffer(parent.nbytes)
-        d_parent.upload(parent)
-        del parent
-        tie_lookups = bool(hp.n_lookup) and cm.lookup_src is not None
+        d_parent = api.DeviceBuffer(hp.n_cells * 8)
         d_lsrc = None
-        if tie_lookups:
-            d_lsrc = api.DeviceBuffer(hp.n_lookup * 8)
-            d_lsrc.upload(np.ascontiguousarray(cm.lookup_src, dtype=np.int64))
+        if on_dev:
+            bad, nosrc = ctypes.c_uint64(), ctypes.c_uint64()
+            _chk(lib.vdb_copymap_finish_dev(cm.d_copy_of.ptr, cm.d_const_idx.ptr, ctypes.c_uint64(hp.n_cells), cm.d_lookup_src.ptr, ctypes.c_uint64(hp.n_lookup),
+                                            d_parent.ptr, ctypes.byref(bad), ctypes.byref(nosrc)))
+            if bad.value:
+                raise ValueError("a cell tied to a constant must be the root of its copies")
+            tie_lookups = bool(hp.n_lookup)
+            lsrc_ptr = cm.d_lookup_src.ptr
+        else:
+            parent = cm.copy_of.astype(np.int64, copy=True)
+            tied = cm.const_idx >= 0
+            if (parent[tied] != np.flatnonzero(tied)).any():
+                raise ValueError("a cell tied to a constant must be the root of its copies")
+            parent[tied] = hp.n_cells + cm.const_idx[tied]
+            d_parent.upload(parent)
+            del parent
+            tie_lookups = bool(hp.n_lookup) and cm.lookup_src is not None
+            if tie_lookups:
+                d_lsrc = api.DeviceBuffer(hp.n_lookup * 8)
+                d_lsrc.upload(np.ascontiguousarray(cm.lookup_src, dtype=np.int64))
+            lsrc_ptr = d_lsrc.ptr if tie_lookups else None
         d_map = api.DeviceBuffer(self.n_perm * rows * 8)
         bp64 = np.ascontiguousarray(hp.bp, dtype=np.uint64)
         self._upload_instance_cells()
         _chk(lib.vdb_permutation_mapping_dev(d_parent.ptr, ctypes.c_uint64(hp.n_cells), ctypes.c_uint64(len(self.consts)), api._p(bp64), ctypes.c_uint64(len(bp64)), k,
-                                             d_lsrc.ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
+                                             lsrc_ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
                                              ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols),
                                              self.d_inst_cells.ptr, ctypes.c_uint64(len(self.instance_cells)), d_map.ptr))
         d_parent.free()
         if d_lsrc is not None:
             d_lsrc.free()
+        if on_dev and hp.n_cells >= (1 << 28) and not getattr(self, "keep_circuit", False):
+            cm.free()                    # tens of GB at BASELINE sizes: the proof needs the room; small circuits keep their map (tests, mock_check)
         self._d_map_for_tests = d_map if getattr(self, "keep_mapping", False) else None
         # the mapping stays with the key in 32 bits per cell when column and row fit: the product round makes the sigma columns'
         # Lagrange form from it (one product per cell) instead of transforming their coefficient form back
@@ -447,9 +465,14 @@ class ProverRounds:
             bufs.append(b)
             return b
         try:
-            d_copy = dev(cm.copy_of, np.int64)
-            d_lsrc = dev(cm.lookup_src, np.int64) if hp.n_lookup and cm.lookup_src is not None else None
-            d_cidx = dev(cm.const_idx, np.int64)
+            if hasattr(cm, "d_copy_of"):
+                if cm.d_copy_of is None:
+                    raise RuntimeError("the circuit's constraint map was released after keygen (set keep_circuit = True before keygen to keep it)")
+                d_copy, d_cidx, d_lsrc = cm.d_copy_of, cm.d_const_idx, cm.d_lookup_src if hp.n_lookup else None
+            else:
+                d_copy = dev(cm.copy_of, np.int64)
+                d_lsrc = dev(cm.lookup_src, np.int64) if hp.n_lookup and cm.lookup_src is not None else None
+                d_cidx = dev(cm.const_idx, np.int64)
             tab = np.zeros((max(len(cm.consts), 1), 4), dtype=np.uint64)
             if len(cm.consts):
                 tab[: len(cm.consts)] = api.fr_from_canonical(np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in cm.consts], dtype=np.uint64))
@@ -1273,6 +1296,8 @@ class ProverRounds:
             if b is not None:
                 b.free()
                 setattr(self, name, None)
+        if hasattr(getattr(self, "circuit", None), "free"):
+            self.circuit.free()
         for name in ("srs_m", "srs_few"):
             if getattr(self, name, None) is not None:
                 getattr(self, name).free()

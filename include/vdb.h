@@ -439,6 +439,24 @@ int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t ca
 int vdb_permutation_mapping_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
                                 const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
                                 const int64_t *instance_cells_dev, uint64_t n_instances, uint64_t *mapping_dev);
+/* The constraint map itself built on the device.  halo2-base records one equality per `Existing` / `Constant` cell while the closure
+ * runs (reached from src/scaffold/mod.rs:378-400); the gadgets' structure is data independent and repeats, so a caller that knows a
+ * block's template (one distance, one assignment, one filter, one division: halo2_vectordb_amd/circuit_sym.py) places it at all its
+ * stream offsets with one call instead of walking 10^9 cells on the host.  All pointers are device pointers.
+ *   vdb_copymap_init_dev    copy_of[i] = i, const_idx[i] = -1, flags[i] = 0, lookup_src[j] = -1
+ *   vdb_copymap_place_dev   m instances of a block of n_blk cells at stream offsets bases[m]: block cell c with code blk_src[c] >= 0
+ *                           copies block cell blk_src[c] of the same instance, <= -10 copies the instance's external input number
+ *                           -10 - blk_src[c] (ext[m][n_ext]: stream cells), anything else copies nothing; const_idx <- blk_cid[c]
+ *                           (index of the fixed-column value, -1 none); flags <- blk_flags[c] (bit 0 gate start, bit 1 the tie is an
+ *                           assert_is_const); the block's n_blk_lk lookup cells at lk_bases[m] get their source cells likewise
+ *   vdb_copymap_finish_dev  parent_dev (may be NULL) <- the input of vdb_permutation_mapping_dev; counts cells tied to a constant that
+ *                           also copy another cell (must be 0) and lookup cells without a source (must be 0) */
+int vdb_copymap_init_dev(uint64_t n_cells, uint64_t n_lookup, int64_t *copy_of_dev, int64_t *const_idx_dev, uint8_t *flags_dev, int64_t *lookup_src_dev);
+int vdb_copymap_place_dev(const int64_t *blk_src_dev, const int64_t *blk_cid_dev, const uint8_t *blk_flags_dev, uint64_t n_blk, const int64_t *blk_lk_dev,
+                          uint64_t n_blk_lk, const int64_t *bases_dev, const int64_t *lk_bases_dev, const int64_t *ext_dev, uint64_t m, uint64_t n_ext,
+                          uint64_t n_cells, uint64_t n_lookup, int64_t *copy_of_dev, int64_t *const_idx_dev, uint8_t *flags_dev, int64_t *lookup_src_dev);
+int vdb_copymap_finish_dev(const int64_t *copy_of_dev, const int64_t *const_idx_dev, uint64_t n_cells, const int64_t *lookup_src_dev, uint64_t n_lookup,
+                           int64_t *parent_dev, uint64_t *tied_not_root, uint64_t *lookups_without_source);
 /* out_dev[i] = src_dev[idx_dev[i]]: the public cells read out of the witness stream in instance order (what
  * circuit.instances() returns, src/scaffold/mod.rs:265) without leaving HBM */
 int vdb_gather_fr_dev(const vdb_fr *src_dev, const int64_t *idx_dev, size_t n, vdb_fr *out_dev);

@@ -280,3 +280,39 @@ def test_streamed_rounds_give_the_resident_proof(api, O):
             pr.free()
             hp.free()
     assert proofs["resident"] == proofs["streamed"]
+
+
+@pytest.mark.parametrize("shape", [("kmeans", "cosine", 9, 5, 3, 2), ("kmeans", "euclidean", 20, 6, 4, 3), ("nearest", "euclidean", 7, 4, 0, 0), ("nearest", "cosine", 12, 3, 0, 0)])
+def test_constraint_map_built_on_the_device_is_the_host_built_map(api, O, shape):
+    """circuit_dev.DeviceBuilder (vdb_copymap_place_dev: one kernel per placement of a traced unit block) against the numpy
+    builder of circuit_sym.py that tests/test_circuit_sym_cpu.py holds against real witnesses: the same copy_of, const_idx, gate
+    and asserted flags, lookup sources, constants and output cells; keygen's parent array from the device map closes the same way"""
+    import ctypes
+    from halo2_vectordb_amd import circuit_sym as CS
+    from halo2_vectordb_amd.circuit_dev import DeviceBuilder
+    kind, metric, n, dim, K, I = shape
+    if kind == "kmeans":
+        host, outs_h = CS.build_kmeans(metric, n, dim, K, I, 48, 10)
+        dev, outs_d = CS.build_kmeans(metric, n, dim, K, I, 48, 10, builder=DeviceBuilder)
+    else:
+        host, outs_h = CS.build_nearest(metric, n, dim, 48, 10)
+        dev, outs_d = CS.build_nearest(metric, n, dim, 48, 10, builder=DeviceBuilder)
+    try:
+        assert dev.n_cells == host.n_cells and dev.consts == host.consts
+        for a, b in zip(outs_h, outs_d):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        for name in ("copy_of", "const_idx", "gate", "asserted", "lookup_src"):
+            assert np.array_equal(getattr(dev, name), getattr(host, name)), name
+        # the parent array keygen hands to vdb_permutation_mapping_dev
+        d_parent = api.DeviceBuffer(host.n_cells * 8)
+        bad, nosrc = ctypes.c_uint64(), ctypes.c_uint64()
+        lib = api.init()
+        assert lib.vdb_copymap_finish_dev(dev.d_copy_of.ptr, dev.d_const_idx.ptr, ctypes.c_uint64(host.n_cells), dev.d_lookup_src.ptr, ctypes.c_uint64(len(host.lookup_src)),
+                                          d_parent.ptr, ctypes.byref(bad), ctypes.byref(nosrc)) == 0
+        want = host.copy_of.astype(np.int64, copy=True)
+        tied = host.const_idx >= 0
+        want[tied] = host.n_cells + host.const_idx[tied]
+        assert bad.value == 0 and nosrc.value == 0 and np.array_equal(d_parent.download((host.n_cells,), dtype=np.int64), want)
+        d_parent.free()
+    finally:
+        dev.free()

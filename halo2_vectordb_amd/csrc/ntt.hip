@@ -40,6 +40,7 @@ struct NttPass {
   uint64_t in_len;                // elements >= in_len of the input column read as zero
   uint64_t in_stride, out_stride; // column strides (elements)
   uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
+  uint32_t ren_out;               // the write-out starts with a carry pass (the last step left limbs a product cannot take)
   const ColSrc* srcs;             // pass 0 only: columns still lying in a witness stream (null: read `in`)
   uint32_t n_blind;
   uint32_t n_cols;                // columns of this launch
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     if (e >= T) break;
     uint32_t g = e & (G - 1), q = e >> p.logG;
     L9 v = lds_get(D, g * row + bitrev_s(q, S));
-    l9_renorm(v);
+    if (p.ren_out) l9_renorm(v);
     if (!LAST) {
       v = l9_mul(v, l9_split(twv[it]));
       // below 1.2 r and exactly normalised: stored without the final conditional subtraction (the next pass only needs
@@ -603,6 +604,11 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
             st += 1;
           }
         }
+        // the write-out multiplies (inter-pass twiddle, 1/n, zeta) unless it is a forward transform's last pass, whose reduction
+        // carries on its own (l9_canon_wide): a carry pass only when the last step left limbs above what a product takes
+        const bool out_mul = !last || p.scale || p.coset_out;
+        static const bool always = getenv("VDB_NTT_REN_OUT") && getenv("VDB_NTT_REN_OUT")[0] == '1';   // A/B: the unconditional pass of rounds 1-2
+        p.ren_out = (always || (out_mul && b >= 6.1)) ? 1u : 0u;
       }
       const u256* src;
       u256* out;

@@ -65,3 +65,13 @@ def test_sharded_streamed_proof_and_the_verifier(tmp_path, O):
     assert _verify(O, api, proof, vk)
     assert not _verify(O, api, proof, {**vk, "instances": instances[:-1] + [(instances[-1] + 1) % O.R_MOD]})
     assert one["sha256"] == two["sha256"]
+
+
+def test_comm_over_rccl_on_the_device():
+    """dist.Comm with the nccl (RCCL) backend, as many ranks as the box has GPUs (one here): the collectives' tensors live in HBM
+    and the field sum moves the library's own device allocations through torch tensors — the interop the multi-GPU run depends on"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "comm_nccl_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-3000:])
+    rep = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep == {"backend": "nccl", "world": 1, "sum_disjoint": True, "gather_rows": True, "sum_field_dev": True}

@@ -156,7 +156,7 @@ def cpu_proof_estimate(units, cores, shape):
     return sum(parts.values()), {k: round(v, 2) for k, v in parts.items()}
 
 
-def whole_proof(api, rank=0, world=1, comm=None):
+def whole_proof(api, rank=0, world=1, comm=None, small=False):
     """BASELINE.json's metric also asks for the proof-generation time.  The whole proof — advice round (= the hot path above),
     lookup permutation, running products, quotient, evaluations, SHPLONK, Fiat–Shamir transcript, fresh blinding — with the
     circuit's whole constraint map in the permutation argument (halo2_vectordb_amd/rounds.py), of the SATISFIABLE k = 16
@@ -169,8 +169,11 @@ def whole_proof(api, rank=0, world=1, comm=None):
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     t0 = time.perf_counter()
-    hp = KmeansHotPath(n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="cosine", col_shard=(rank, world))
-    hp.ext_block_cols = 256          # the rounds recompute the cosets block by block; HBM goes to the proving key
+    if small:                        # functional check of this very code path (tests): a circuit of a few hundred columns
+        hp = KmeansHotPath(n=16, dim=8, K=2, I=2, k=12, P=48, L=11, metric="cosine", col_shard=(rank, world))
+    else:
+        hp = KmeansHotPath(n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="cosine", col_shard=(rank, world))
+        hp.ext_block_cols = 256      # the rounds recompute the cosets block by block; HBM goes to the proving key
     hp.setup()
     pr = ProverRounds(hp, comm=comm).keygen()
     keygen_s = time.perf_counter() - t0
@@ -207,7 +210,12 @@ def whole_proof(api, rank=0, world=1, comm=None):
     T = {}
     pr.prove(None, timings=T)
     rep = pr.keygen_report
-    res = {"circuit": "kmeans K=4 I=8 over 256x128, P=48, LOOKUP_BITS=15, COSINE (the satisfiable variant of BASELINE configs[3]), k=16",
+    import hashlib
+    digest = hashlib.sha256(out["proof"]).digest()
+    same = True if comm is None else bool((lambda rows: (rows == rows[0]).all())(comm.gather_rows(np.frombuffer(digest, dtype=np.uint64))))
+    res = {"circuit": "kmeans K=4 I=8 over 256x128, P=48, LOOKUP_BITS=15, COSINE (the satisfiable variant of BASELINE configs[3]), k=16"
+                      if not small else "SMALL functional check (cosine k-means, k=12)",
+           "every_rank_wrote_the_same_proof_bytes": same,
            "cells": hp.n_cells + hp.n_lookup, "columns": hp.n_cols, "product_columns": pr.n_sets + pr.n_lk,
            "shape": {"cells": hp.n_cells + hp.n_lookup, "rows": hp.rows, "n_adv": pr.n_adv, "n_lk": pr.n_lk, "n_sets": pr.n_sets,
                      "n_evals": int(sum(len(v) for v in out["evals"].raw.values()))},
@@ -369,7 +377,7 @@ def main():
             cpu = cpu_baseline(hp, cols, commitments[idx])
 
     proof = None
-    if not args.no_proof and not args.small:
+    if not args.no_proof:
         try:
             from halo2_vectordb_amd._lib import check as _check
             hp.free()
@@ -378,7 +386,7 @@ def main():
             if dist is not None:
                 from halo2_vectordb_amd.dist import Comm
                 comm = Comm(dist)
-            proof = whole_proof(api, rank, world, comm)
+            proof = whole_proof(api, rank, world, comm, small=args.small)
         except Exception as e:      # the bench line above stands on its own
             if dist is not None:
                 raise               # a rank that drops out of a sharded proof leaves the others waiting in a collective

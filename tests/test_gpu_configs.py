@@ -308,6 +308,10 @@ def test_two_rank_timed_path_with_the_collective(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["gathered_commitments_match_unsharded_job"] is True
     assert out["value"] > 0 and out["roofline"]["launches_per_step"] > 0
+    # ... and the whole proof that follows the timed region ran sharded over the same two ranks (rounds.ProverRounds with a dist.Comm)
+    pf = out["proof"]
+    assert pf["n_gpus"] == 2 and pf["every_rank_wrote_the_same_proof_bytes"] and pf["quotient_identity_at_x_holds"] and pf["mock_prover_violations"] == 0
+    assert pf["proof_ms"] > 0 and pf["n_instances"] == 2 * 8
 
 
 def test_extended_cosets_in_column_blocks(api, O):

@@ -41,6 +41,7 @@ struct NttPass {
   uint64_t in_stride, out_stride; // column strides (elements)
   uint32_t ren_mask;              // bit i: butterfly step i starts with a carry pass over its operands
   uint32_t ren_out;               // the write-out starts with a carry pass (the last step left limbs a product cannot take)
+  uint32_t blk0;                  // the step at stage 2 takes the product-free path for its block 0
   const ColSrc* srcs;             // pass 0 only: columns still lying in a witness stream (null: read `in`)
   uint32_t n_blind;
   uint32_t n_cols;                // columns of this launch
@@ -230,11 +231,25 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       const uint32_t h2 = h >> 1;
       // (the body is instantiated per (first step, carry pass) combination: a run-time `if (ren)` inside one body makes the
       // compiler merge the two register sets with ~30 moves per step on the path that does not renormalise)
-      auto radix4 = [&](auto first_c, auto ren_c, auto shoup_c) {
-        constexpr bool FIRST = decltype(first_c)::value, REN = decltype(ren_c)::value, SHOUP = decltype(shoup_c)::value;
+      // `s2_c`: the step that starts at stage 2.  Its block 0 — a quarter of its butterflies — has the twiddles of the very first step
+      // (1, 1 and omega_4): three of its four products are products by one.  The threads are numbered block-major there (block,
+      // row, position), so that with 1024-element tiles a wavefront lies inside one block and the branch costs nothing.
+      auto radix4 = [&](auto first_c, auto ren_c, auto shoup_c, auto s2_c) {
+        constexpr bool FIRST = decltype(first_c)::value, REN = decltype(ren_c)::value, SHOUP = decltype(shoup_c)::value, S2 = decltype(s2_c)::value;
         for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
-          const uint32_t g = t >> (S - 2), gi = t & ((m >> 2) - 1);
-          const uint32_t r = gi & (h2 - 1), blk = gi >> (logh - 1);
+          uint32_t g, r, blk;
+          if (S2) {
+            const uint32_t lb = p.logG + logh - 1;   // log2(threads per block) = log2(G h2)
+            // (rotated by the workgroup's number: a CU's resident workgroups then put their light wavefront on different SIMDs)
+            blk = ((t >> lb) + blockIdx.x + (blockIdx.x >> 8)) & 3u;
+            g = (t >> (logh - 1)) & (G - 1);
+            r = t & (h2 - 1);
+          } else {
+            const uint32_t gi = t & ((m >> 2) - 1);
+            g = t >> (S - 2);
+            r = gi & (h2 - 1);
+            blk = gi >> (logh - 1);
+          }
           const uint32_t j0 = g * row + (blk << (logh + 1)) + r;
           L9 x0 = lds_get(D, j0), x1 = lds_get(D, j0 + h2), x2 = lds_get(D, j0 + h), x3 = lds_get(D, j0 + h + h2);
           if (REN) {
@@ -249,6 +264,26 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
             L9 a1 = l9_add(x1, x3), a3 = l9_sub(x1, x3, p.ckp);
             l9_carry(a1);  // a1 is subtracted below: its limbs must be below 2^29 again
             const L9 t3 = l9_mul(a3, lds_get(W, m >> 2));
+            x0 = l9_add(a0, a1);
+            x1 = l9_sub(a0, a1, p.ckp);
+            x2 = l9_add(a2, t3);
+            x3 = l9_sub(a2, t3, p.ckp);
+          } else if (S2 && blk == 0) {
+            // twiddles 1, 1, omega_4.  x2, x3 and a1 are subtracted as they are: their limbs are brought below 2^29 first (their values,
+            // at most 4.8 r and 9.6 r — block 0 holds the sums of sums of the first step, or freshly loaded values — stay below the
+            // 13 r the offset covers); every limb bound stays below the general path's
+            l9_carry(x2);
+            l9_carry(x3);
+            L9 a0 = l9_add(x0, x2), a2 = l9_sub(x0, x2, p.ckp);
+            L9 a1 = l9_add(x1, x3), a3 = l9_sub(x1, x3, p.ckp);
+            l9_carry(a1);
+            L9 t3;
+            if (SHOUP) {
+              const uint32_t iq = (m >> 2) >> p.sh_res_log;
+              t3 = l9_mul_shoup<Fr>(a3, lds_get(WS, iq), lds_get(WQ, iq));
+            } else {
+              t3 = l9_mul(a3, lds_get(W, m >> 2));
+            }
             x0 = l9_add(a0, a1);
             x1 = l9_sub(a0, a1, p.ckp);
             x2 = l9_add(a2, t3);
@@ -289,15 +324,18 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       };
       using T_ = std::true_type;
       using F_ = std::false_type;
+      const bool s2 = s == 2 && !ren && p.blk0;   // (the schedule never carries at the start of this step; if it ever did: the general body)
       if (s == 0) {
-        if (ren) radix4(T_{}, T_{}, F_{});
-        else radix4(T_{}, F_{}, F_{});
+        if (ren) radix4(T_{}, T_{}, F_{}, F_{});
+        else radix4(T_{}, F_{}, F_{}, F_{});
       } else if (p.sh_tab && (int32_t)s <= p.sh_max_s) {
-        if (ren) radix4(F_{}, T_{}, T_{});
-        else radix4(F_{}, F_{}, T_{});
+        if (ren) radix4(F_{}, T_{}, T_{}, F_{});
+        else if (s2) radix4(F_{}, F_{}, T_{}, T_{});
+        else radix4(F_{}, F_{}, T_{}, F_{});
       } else {
-        if (ren) radix4(F_{}, T_{}, F_{});
-        else radix4(F_{}, F_{}, F_{});
+        if (ren) radix4(F_{}, T_{}, F_{}, F_{});
+        else if (s2) radix4(F_{}, F_{}, F_{}, T_{});
+        else radix4(F_{}, F_{}, F_{}, F_{});
       }
       s += 2;
     } else {
@@ -607,6 +645,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
         // the write-out multiplies (inter-pass twiddle, 1/n, zeta) unless it is a forward transform's last pass, whose reduction
         // carries on its own (l9_canon_wide): a carry pass only when the last step left limbs above what a product takes
         const bool out_mul = !last || p.scale || p.coset_out;
+        static const bool blk0_on = !(getenv("VDB_NTT_BLK0") && getenv("VDB_NTT_BLK0")[0] == '0');
+        p.blk0 = blk0_on ? 1u : 0u;
         static const bool always = getenv("VDB_NTT_REN_OUT") && getenv("VDB_NTT_REN_OUT")[0] == '1';   // A/B: the unconditional pass of rounds 1-2
         p.ren_out = (always || (out_mul && b >= 6.1)) ? 1u : 0u;
       }

@@ -7,7 +7,7 @@ must not depend on the number of ranks (tests/test_gpu_sharded.py).
         tools/sharded_prove.py --circuit kmeans --out /tmp/p2.bin
 
 Circuits: "kmeans" (a small cosine k-means), "nearest" (small), "c2" (BASELINE configs[1]: nearest_vector over 64 x 128, k = 14),
-"merkle" (small, no lookup columns).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
+"merkle" (small, no lookup columns), "mid" (cosine k-means over 128 x 64 vectors, K = 4, I = 4, at 2^16 rows).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
 own transcript ended with the same bytes (sha256 exchanged)."""
 import argparse
 import hashlib
@@ -63,6 +63,8 @@ def main():
         hp = NearestHotPath(n=6, dim=4, k=12, L=11, tau=TAU, col_shard=shard)
     elif args.circuit == "c2":
         hp = NearestHotPath(n=64, dim=128, k=14, L=13, tau=TAU, col_shard=shard)
+    elif args.circuit == "mid":      # a k = 16 cosine k-means of a few thousand columns: per-rank work and exchange overheads at a real row count
+        hp = KmeansHotPath(n=128, dim=64, K=4, I=4, k=16, P=48, L=15, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "merkle":
         hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU, col_shard=shard)
     else:

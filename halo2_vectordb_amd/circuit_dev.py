@@ -134,3 +134,109 @@ class DeviceBuilder:
                 b.free()
         self._small.free()
         return DeviceCopyMap(self.n_cells, self.n_lookup, self.d_copy_of, self.d_const_idx, self.d_flags, self.d_lookup_src, self.consts)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# merkle_commitment (copymap.py's map) placed by the device: one block per kind of permutation
+class _PermBlock:
+    """one PoseidonChip::permutation as a unit block for DeviceBuilder.place: copymap.permutation_template's cell codes turned into
+    the builder's (external inputs 0..2: the sponge state, 3..4: the absorbed words), for one combination of
+    (words absorbed, state starts from the chip's initial state, the words copy assigned cells)"""
+
+    def __init__(self, src, fin, flags, values, fresh, tied_msgs):
+        from .circuit_sym import EXT0, SELF
+        from .copymap import T
+        src = np.asarray(src, dtype=np.int64)
+        self.n, self.n_lk = src.size, 0
+        out = np.where(src >= 0, src, SELF).astype(np.int64)
+        cst = (np.asarray(flags) & 2) != 0
+        consts, cmap = [], {}
+        cidx = np.full(src.size, -1, dtype=np.int64)
+
+        def cid(v):
+            if v not in cmap:
+                cmap[v] = len(consts)
+                consts.append(v)
+            return cmap[v]
+        for i in np.flatnonzero(cst):
+            cidx[i] = cid(int(values[i]))
+        for i in range(T):
+            cols = np.flatnonzero(src == -10 - i)
+            if fresh:                                  # capacity 2^64, then zeros: constants of the circuit though the kernels do not flag them
+                for c in cols:
+                    cidx[c] = cid((1 << 64) if i == 0 else 0)
+            else:
+                out[cols] = EXT0 - i
+        for i in range(2):
+            cols = np.flatnonzero(src == -20 - i)
+            if tied_msgs:
+                out[cols] = EXT0 - (T + i)
+        self.src, self.cidx, self.consts = out, cidx, consts
+        self.gate = (np.asarray(flags) & 1).astype(bool)
+        self.asserted = np.zeros(0, dtype=np.int64)
+        self.lk = np.zeros(0, dtype=np.int64)
+        self.outs = np.asarray(fin, dtype=np.int64)
+
+
+def place_merkle(B, n, dim, base, vec_base, fetch_flags, fetch_values):
+    """merkle_commitment over n vectors of `dim` words (src/gadget/vectordb.rs:165-223) whose trace starts at stream cell `base`,
+    placed into DeviceBuilder `B` in the cell order of witness.hip: the leaves' sponges, the load_zero cell of the padding, the
+    tree.  `vec_base`: stream cell of word 0 of vector 0 (the assigned vectors the leaves absorb; None: free words).
+    fetch_flags(lo, hi) / fetch_values(lo, hi): the kernel's flag bytes / the canonical values of stream cells [lo, hi) of a
+    keygen-style run (one instance of each kind of permutation is read).  Returns the stream cell of the root."""
+    from .copymap import T, perm_cells, permutation_template
+    nperm = (dim + 1) // 2 + (1 if dim % 2 == 0 else 0)
+    n_ins = [max(0, min(2, dim - 2 * p)) for p in range(nperm)]
+    sizes = [perm_cells(k) for k in n_ins]
+    leaf_cells = sum(sizes)
+    lp = 1
+    while lp < n:
+        lp <<= 1
+    zero_cell = 1 if lp > n else 0
+    node_cells = perm_cells(2) + perm_cells(0)
+    blocks = {}
+
+    def block(n_in, at, fresh, tied):
+        key = (n_in, fresh, tied)
+        if key not in blocks:
+            size = perm_cells(n_in)
+            flags = np.asarray(fetch_flags(at, at + size), dtype=np.uint8)
+            src, fin = permutation_template(flags, n_in)
+            blocks[key] = _PermBlock(src, fin, flags, fetch_values(at, at + size), fresh, tied)
+        return blocks[key]
+
+    def place(bases, n_in, state, msgs):
+        m = bases.size
+        ext = np.zeros((m, T + 2), dtype=np.int64)
+        fresh = state[0] is None
+        if not fresh:
+            for i in range(T):
+                ext[:, i] = state[i]
+        tied = n_in > 0 and msgs[0] is not None
+        if tied:
+            for i in range(n_in):
+                ext[:, T + i] = msgs[i]
+        outs = B.place(block(n_in, int(bases[0]), fresh, tied), bases, np.zeros(m, dtype=np.int64), ext)
+        return [outs[:, i] for i in range(T)]
+
+    leaf_base = base + np.arange(n, dtype=np.int64) * leaf_cells
+    state, off = [None] * T, 0
+    for p in range(nperm):
+        msg = [vec_base + np.arange(n, dtype=np.int64) * dim + 2 * p + i for i in range(n_ins[p])] if vec_base is not None else [None] * n_ins[p]
+        state = place(leaf_base + off, n_ins[p], state, msg)
+        off += sizes[p]
+    zero_at = base + n * leaf_cells
+    if zero_cell:
+        B.constant_cell(zero_at, 0)                          # ctx.load_zero() for the padding leaves
+    digest = np.full(lp, zero_at, dtype=np.int64)
+    digest[:n] = state[1]
+    pos, width = base + n * leaf_cells + zero_cell, lp
+    while width > 1:
+        half = width // 2
+        bases = pos + np.arange(half, dtype=np.int64) * node_cells
+        st1 = place(bases, 2, [None] * T, [digest[0:width:2], digest[1:width:2]])
+        st2 = place(bases + perm_cells(2), 0, st1, [])
+        digest = st2[1]
+        pos += half * node_cells
+        width = half
+    return int(digest[0]), pos

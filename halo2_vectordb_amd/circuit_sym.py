@@ -585,9 +585,11 @@ def _distance_block(metric, dim, P, L):
     return Block(s, [out])
 
 
-def build_nearest(metric, n, dim, P, L, builder=None):
+def build_nearest(metric, n, dim, P, L, builder=None, extra_cells=0, finish=True):
     """nearest_vector(query, vectors) after [query | vectors] have been assigned (tests/vectordb/mod.rs:220-247): the map the
-    whole-circuit trace gives, assembled from one distance block, one qmin block and the closing cells"""
+    whole-circuit trace gives, assembled from one distance block, one qmin block and the closing cells.  `extra_cells`: room for a
+    gadget that follows in the same stream (the query circuit's merkle_commitment); with finish=False the builder itself is returned,
+    (builder, outputs, cells used so far), for the caller to go on placing"""
     db = _distance_block(metric, dim, P, L)
     s = Sym(P, L)
     qm = Block(s, [s.qmin(ext(0), ext(1))])
@@ -596,7 +598,7 @@ def build_nearest(metric, n, dim, P, L, builder=None):
     iseq0 = qmin0 + (n - 1) * qm.n
     sel0 = iseq0 + 12 * n
     total = sel0 + dim * (1 + 3 * n)
-    B = (builder or _Builder)(total, n * db.n_lk + (n - 1) * qm.n_lk)
+    B = (builder or _Builder)(total + extra_cells, n * db.n_lk + (n - 1) * qm.n_lk)
     query = np.arange(dim, dtype=np.int64)
     vec = dim + np.arange(n * dim, dtype=np.int64).reshape(n, dim)
     i = np.arange(n, dtype=np.int64)
@@ -615,6 +617,8 @@ def build_nearest(metric, n, dim, P, L, builder=None):
     sb = Block(s, [s.g_select_by_indicator([ext(k) for k in range(n)], [ext(n + k) for k in range(n)])])
     jd = np.arange(dim, dtype=np.int64)
     res = B.place(sb, sel0 + jd * (1 + 3 * n), np.zeros(dim, dtype=np.int64), np.concatenate([vec.T, np.broadcast_to(ind, (dim, n))], axis=1))[:, 0]
+    if not finish:
+        return B, (ind, res), total
     return B.finish(), (ind, res)
 
 

@@ -661,3 +661,55 @@ class NearestHotPath(KmeansHotPath):
         if getattr(self, "d_res", None) is not None:
             self.d_res.free()
             self.d_res = None
+
+
+class QueryHotPath(NearestHotPath):
+    """The reference's `query` circuit — "exhaustively find the similar vector & commit to the database" (examples/query.rs:32-73;
+    tests/vectordb/mod.rs:220-247 chip_nearest_vector): nearest_vector(query, database) and merkle_commitment(database) in ONE
+    circuit over the same assigned vectors, the result vector and the Merkle root public.  Stream: [query | vectors | nearest_vector's
+    cells | merkle_commitment's cells]; the lookup cells are nearest_vector's.  (PoseidonChip::new's three load_constant cells are
+    not emitted, as in MerkleHotPath: the sponge's initial state is pinned as constants of the circuit.)"""
+
+    def _circuit_size(self):
+        n_in, nv_cells, lk = super()._circuit_size()
+        mk = ctypes.c_uint64()
+        check(self.lib.vdb_wit_merkle_size(self.n, self.dim, 0, ctypes.byref(mk)))
+        self.nearest_cells, self.merkle_cells = nv_cells, mk.value
+        return n_in, nv_cells + mk.value, lk
+
+    def _alloc_outputs(self):
+        super()._alloc_outputs()
+        self.d_root = api.DeviceBuffer(32)
+        self.d_pub = api.DeviceBuffer((self.dim + 1) * 32)      # [result vector | root]: the public statement, in make_public order
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        super()._witness(sel)                                       # inputs + nearest_vector (windowed like NearestHotPath)
+        off = self.n_in + self.nearest_cells
+        windowed = sel is None and self.shard_witness and self.world > 1
+        if windowed:                                                 # in the coordinates of the Merkle trace's first cell
+            lo, hi = (max(0, x - off) for x in self.win_adv)
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(0), ctypes.c_uint64(0)))
+        try:
+            check(lib.vdb_wit_merkle_dev(self.d_vec.at(self.dim * 32), self.n, self.dim, 0, self.d_stream.at(off * 32),
+                                         ctypes.c_void_p(sel.ptr.value + off) if sel is not None else None, self.d_root.ptr))
+        finally:
+            if windowed:
+                check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2**64 - 1)))
+        check(lib.vdb_memcpy_d2d(self.d_pub.ptr, self.d_res.ptr, ctypes.c_size_t(self.dim * 32)))
+        check(lib.vdb_memcpy_d2d(self.d_pub.at(self.dim * 32), self.d_root.ptr, ctypes.c_size_t(32)))
+
+    def public_values_dev(self):
+        return self.d_pub.ptr, self.dim + 1          # examples/query.rs:58 make_public.extend(result), :69 make_public.push(root)
+
+    def results(self):
+        ind, res = super().results()
+        return ind, res, self.d_root.download((4,))
+
+    def free(self):
+        super().free()
+        for name in ("d_root", "d_pub"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).free()
+                setattr(self, name, None)
+

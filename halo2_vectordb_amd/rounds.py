@@ -276,23 +276,43 @@ class ProverRounds:
     def circuit_map(self, d_flags):
         """The circuit's constraint map (circuit_sym.CopyMap) for the gadget this hot path runs: the symbolic trace of the
         fixed-point gadgets, or of the Poseidon sponge for the Merkle circuit."""
-        from .pipeline import MerkleHotPath, NearestHotPath
+        from .pipeline import MerkleHotPath, NearestHotPath, QueryHotPath
         hp = self.hp
-        if isinstance(hp, MerkleHotPath):
-            from .copymap import merkle_circuit_map
-            flags = d_flags.download((hp.n_cells,), dtype=np.uint8)
+        on_device = getattr(self, "map_on_device", True)
 
-            def fetch(lo, hi):
-                c = api.fr_to_canonical(hp.d_stream.download((hi - lo, 4), offset=lo * B))
-                return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in c]
-            cm, self.root_cell = merkle_circuit_map(hp.n, hp.dim, flags, fetch)
+        def fetch(lo, hi):
+            c = api.fr_to_canonical(hp.d_stream.download((hi - lo, 4), offset=lo * B))
+            return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in c]
+
+        def fetch_flags(lo, hi):
+            return d_flags.download((hi - lo,), dtype=np.uint8, offset=lo)
+        if isinstance(hp, MerkleHotPath):
+            if on_device:
+                from .circuit_dev import DeviceBuilder, place_merkle
+                bld = DeviceBuilder(hp.n_cells, 0)
+                self.root_cell, end = place_merkle(bld, hp.n, hp.dim, hp.n_in, 0, fetch_flags, fetch)
+                assert end == hp.n_cells
+                cm = bld.finish()
+            else:
+                from .copymap import merkle_circuit_map
+                cm, self.root_cell = merkle_circuit_map(hp.n, hp.dim, d_flags.download((hp.n_cells,), dtype=np.uint8), fetch)
             self.public_cells = [int(self.root_cell)]                               # examples/merkle.rs:47 make_public.push(root)
             return cm
         from . import circuit_sym as CS
         from .circuit_dev import DeviceBuilder
         # the unit blocks are traced on the host (a few thousand cells each); their hundreds of thousands of instances are placed
         # by the device (circuit_dev.py): the map's 10^9-cell arrays never exist on the host
-        builder = DeviceBuilder if getattr(self, "map_on_device", True) else None
+        builder = DeviceBuilder if on_device else None
+        if isinstance(hp, QueryHotPath):
+            # nearest_vector, then merkle_commitment over the same assigned vectors, in one map (examples/query.rs)
+            from .circuit_dev import place_merkle
+            bld, (_ind, res), used = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L, builder=DeviceBuilder, extra_cells=hp.merkle_cells, finish=False)
+            assert used == hp.n_in + hp.nearest_cells
+            self.root_cell, end = place_merkle(bld, hp.n, hp.dim, used, hp.dim, fetch_flags, fetch)
+            assert end == hp.n_cells
+            cm = bld.finish()
+            self.public_cells = [int(c) for c in res] + [int(self.root_cell)]       # examples/query.rs:58, :69: the result vector, then the root
+            return cm
         if isinstance(hp, NearestHotPath):
             cm, (_ind, res) = CS.build_nearest(hp.metric_name, hp.n, hp.dim, hp.P, hp.L, builder=builder)
             self.public_cells = [int(c) for c in res]                               # examples/query.rs:58 make_public.extend(result)

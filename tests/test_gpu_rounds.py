@@ -638,8 +638,9 @@ def test_copy_constraints_are_enforced(O):
         pr = ProverRounds(hp).keygen()
         if label == "layout ties only":        # the same circuit with the copies of the Poseidon trace left out (constants stay pinned)
             cm = pr.circuit
-            pr.free()
-            pr = ProverRounds(hp).keygen(circuit=CopyMap(np.arange(hp.n_cells, dtype=np.int64), cm.const_idx, cm.consts, cm.asserted, cm.gate, cm.lookup_src))
+            loose = CopyMap(np.arange(hp.n_cells, dtype=np.int64), cm.const_idx.copy(), list(cm.consts), cm.asserted.copy(), cm.gate.copy(), cm.lookup_src.copy())
+            pr.free()                            # (releases the map's device arrays too)
+            pr = ProverRounds(hp).keygen(circuit=loose)
         try:
             vk = lambda out: dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=tau_h,
                                   instances=out["instances"])

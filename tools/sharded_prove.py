@@ -7,7 +7,7 @@ must not depend on the number of ranks (tests/test_gpu_sharded.py).
         tools/sharded_prove.py --circuit kmeans --out /tmp/p2.bin
 
 Circuits: "kmeans" (a small cosine k-means), "nearest" (small), "c2" (BASELINE configs[1]: nearest_vector over 64 x 128, k = 14),
-"merkle" (small, no lookup columns), "mid" (cosine k-means over 128 x 64 vectors, K = 4, I = 4, at 2^16 rows).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
+"merkle" (small, no lookup columns), "query" (small: nearest_vector and merkle_commitment in one circuit), "mid" (cosine k-means over 128 x 64 vectors, K = 4, I = 4, at 2^16 rows).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
 own transcript ended with the same bytes (sha256 exchanged)."""
 import argparse
 import hashlib
@@ -54,13 +54,15 @@ def main():
         comm = Comm(dist)
     else:
         api.init(0)
-    from halo2_vectordb_amd.pipeline import KmeansHotPath, MerkleHotPath, NearestHotPath
+    from halo2_vectordb_amd.pipeline import KmeansHotPath, MerkleHotPath, NearestHotPath, QueryHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     shard = (rank, world)
     if args.circuit == "kmeans":
         hp = KmeansHotPath(n=8, dim=4, K=2, I=2, k=12, L=11, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "nearest":
         hp = NearestHotPath(n=6, dim=4, k=12, L=11, tau=TAU, col_shard=shard)
+    elif args.circuit == "query":    # examples/query.rs: nearest_vector + merkle_commitment in one circuit, result vector and root public
+        hp = QueryHotPath(n=6, dim=4, k=12, L=11, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "c2":
         hp = NearestHotPath(n=64, dim=128, k=14, L=13, tau=TAU, col_shard=shard)
     elif args.circuit == "mid":      # a k = 16 cosine k-means of a few thousand columns: per-rank work and exchange overheads at a real row count

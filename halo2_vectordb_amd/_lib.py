@@ -107,7 +107,7 @@ _SIGNATURES = {
     "vdb_msm_batch_src_dev_begin": [_P, _I, _P, _SZ, _SZ, _U32, _P, _P], "vdb_lagrange_to_coeff_src_dev": [_P, _P, _SZ, _U32, _U32],
     "vdb_ntt_batch": [_P, _SZ, _U32, _P, _I], "vdb_ntt_batch_dev": [_P, _SZ, _U32, _P, _I],
     "vdb_lagrange_to_coeff": [_P, _SZ, _U32], "vdb_lagrange_to_coeff_dev": [_P, _SZ, _U32],
-    "vdb_coeff_to_extended": [_P, _P, _SZ, _U32, _U32], "vdb_coeff_to_extended_dev": [_P, _P, _SZ, _U32, _U32],
+    "vdb_coeff_to_extended": [_P, _P, _SZ, _U32, _U32], "vdb_coeff_to_extended_dev": [_P, _P, _SZ, _U32, _U32], "vdb_coeff_to_extended_scaled_dev": [_P, _P, _SZ, _U32, _U32, _P],
     "vdb_fr_root_of_unity": [_U32, _P], "vdb_profile_end": [_P, _SZ],
     "vdb_poseidon_hash_many": [_P, _SZ, _SZ, _P], "vdb_poseidon_merkle_root": [_P, _SZ, _SZ, _P], "vdb_poseidon_permute": [_P, _SZ],
 }

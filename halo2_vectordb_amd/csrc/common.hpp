@@ -160,6 +160,6 @@ u256 host_fr_from_u64(uint64_t v);
 
 // internal device-level entry points shared between translation units (all on ctx().stream)
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out);
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale = nullptr);
 
 }  // namespace vdb

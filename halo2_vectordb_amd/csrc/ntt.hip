@@ -33,7 +33,7 @@ struct NttPass {
   uint32_t nprev;                 // last pass: number of previous passes
   uint32_t prevS[NTT_MAX_PASSES]; // their sizes (S_0 .. S_{L-2})
   uint32_t first;                 // this is pass 0 (input staging rules apply)
-  uint32_t coset;                 // multiply input element e by zeta^(e mod 3)
+  uint32_t coset;                 // 1: multiply input element e by zeta^(e mod 3); 2: by s zeta^(e mod 3) for a scalar s (zeta0 = 32 s)
   uint32_t coset_out;             // last pass: multiply output element e by zeta^-(e mod 3) (extended_to_coeff)
   uint32_t scale;                 // multiply output by n^{-1}
   uint32_t s0;                    // first butterfly stage to run (2 when the top three quarters of every row are zero padding)
@@ -49,6 +49,7 @@ struct NttPass {
                                   // after tile (the same tile of all g columns back to back), so a tile's 32-B inter-pass
                                   // twiddles and stage twiddles are L2 hits for every column after the first on an XCD
   u256 zeta1, zeta2, fin;         // 32*zeta, 32*zeta^2, 32/n — all mod r, Montgomery (zeta^-1 = zeta^2: the same two serve coset_out)
+  u256 zeta0;                     // coset == 2: 32 s (and zeta1, zeta2 carry the factor s too)
   uint32_t ckp[9];                // 14 r as limbs that dominate any normalised operand (see l9_sub)
   // Shoup products for the stage twiddles (shoup_core29, field.hpp): per twiddle index e that is a multiple of 2^sh_res_log the
   // plain residue of omega_m^e and its quotient floor(omega_m^e 2^261 / r), 2 x 9 limbs; null: every product is a Montgomery product
@@ -191,10 +192,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   // load tile.  With s0 == 2 only the first quarter of every row is data; the two skipped stages would just copy
   // it into the other three quarters.
   const uint32_t mload = m >> p.s0, Tload = mload * G;
-  L9 Z1, Z2;
+  L9 Z0, Z1, Z2;
   if (p.coset) {
     Z1 = l9_split(p.zeta1);
     Z2 = l9_split(p.zeta2);
+    if (p.coset == 2) Z0 = l9_split(p.zeta0);
   }
   for (uint32_t e = tid; e < Tload; e += NTT_THREADS) {
     uint32_t j, g;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         uint32_t r3 = (uint32_t)(idx % 3);
         if (r3 == 1) v = l9_mul(v, Z1);
         else if (r3 == 2) v = l9_mul(v, Z2);
+        else if (p.coset == 2) v = l9_mul(v, Z0);
       }
     } else {
 #pragma unroll
@@ -522,7 +525,7 @@ static const uint32_t* get_shoup_table(uint32_t log_n, const u256& omega, uint32
 // Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
 // result goes to out (stride n) or back into data when out == nullptr.
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out) {
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale) {
   Context& c = ctx();
   if (n_cols == 0) return VDB_OK;
   if (log_n > 26) {
@@ -569,6 +572,12 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   u256 z1 = host_zeta(), z2 = fr_mul(z1, z1);
   z1 = fr_mul(z1, m32);
   z2 = fr_mul(z2, m32);
+  u256 z0 = m32;
+  if (in_scale) {  // the polynomial s p(X) on the coset: the scalar rides on the coset factors (one more product on a third of the inputs)
+    z0 = fr_mul(z0, *in_scale);
+    z1 = fr_mul(z1, *in_scale);
+    z2 = fr_mul(z2, *in_scale);
+  }
   static const bool shoup_on = !(getenv("VDB_NTT_SHOUP") && getenv("VDB_NTT_SHOUP")[0] == '0');
   // 14 r with limbs that dominate a normalised subtrahend (l9_sub)
   uint32_t ckp[9];
@@ -597,7 +606,8 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.log_inner = log_n - done_bits - S[l];
       p.first = (l == 0);
       const bool last = (l == L - 1);
-      p.coset = (l == 0 && coset_in);
+      p.coset = (l == 0 && coset_in) ? (in_scale ? 2u : 1u) : 0u;
+      p.zeta0 = z0;
       p.in_len = in_len;
       p.srcs = (l == 0 && srcs) ? srcs + c0 : nullptr;
       p.n_blind = n_blind;
@@ -752,7 +762,7 @@ int vdb_ntt_batch_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t log_n, const vdb
   VDB_ARG(cols_dev && omega, "null pointer");
   u256 w;
   memcpy(&w, omega, 32);
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0, nullptr, 0, false);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, log_n, w, (flags & VDB_NTT_INVERSE_SCALE) != 0, false, 0, nullptr, 0, false, nullptr);
 }
 int vdb_ntt_batch(vdb_fr* const* cols, size_t n_cols, uint32_t log_n, const vdb_fr* omega, int flags) {
   VDB_REQUIRE_INIT();
@@ -769,13 +779,13 @@ int vdb_lagrange_to_coeff_dev(vdb_fr* cols_dev, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
   VDB_ARG(cols_dev && k <= 26, "bad argument");
   u256 w = mont_inv<Fr>(host_root_of_unity(k));
-  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0, nullptr, 0, false);
+  return ntt_dev(as_u256(cols_dev), nullptr, n_cols, k, w, true, false, 0, nullptr, 0, false, nullptr);
 }
 int vdb_lagrange_to_coeff_src_dev(const vdb_colsrc* src_dev, vdb_fr* coeff_dev, size_t n_cols, uint32_t k, uint32_t n_blind) {
   VDB_REQUIRE_INIT();
   VDB_ARG(src_dev && coeff_dev && k <= 26 && k > 10, "bad argument (column sources are supported for k > 10)");
   u256 w = mont_inv<Fr>(host_root_of_unity(k));
-  return ntt_dev(nullptr, as_u256(coeff_dev), n_cols, k, w, true, false, 0, reinterpret_cast<const ColSrc*>(src_dev), n_blind, false);
+  return ntt_dev(nullptr, as_u256(coeff_dev), n_cols, k, w, true, false, 0, reinterpret_cast<const ColSrc*>(src_dev), n_blind, false, nullptr);
 }
 int vdb_lagrange_to_coeff(vdb_fr* const* cols, size_t n_cols, uint32_t k) {
   VDB_REQUIRE_INIT();
@@ -792,13 +802,20 @@ int vdb_coeff_to_extended_dev(const vdb_fr* coeff_dev, vdb_fr* ext_dev, size_t n
   VDB_REQUIRE_INIT();
   VDB_ARG(coeff_dev && ext_dev && k + ext_k <= 26, "bad argument");
   u256 w = host_root_of_unity(k + ext_k);
-  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0, false);
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0, false, nullptr);
+}
+int vdb_coeff_to_extended_scaled_dev(const vdb_fr* coeff_dev, vdb_fr* ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* scale) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && ext_dev && scale && k + ext_k <= 26, "bad argument");
+  u256 w = host_root_of_unity(k + ext_k), sv;
+  memcpy(&sv, scale, 32);
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(ext_dev), n_cols, k + ext_k, w, false, true, (size_t)1 << k, nullptr, 0, false, &sv);
 }
 int vdb_extended_to_coeff_dev(vdb_fr* ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();
   VDB_ARG(ext_dev && k + ext_k <= 26, "bad argument");
   u256 w = mont_inv<Fr>(host_root_of_unity(k + ext_k));
-  return ntt_dev(as_u256(ext_dev), nullptr, n_cols, k + ext_k, w, true, false, 0, nullptr, 0, true);
+  return ntt_dev(as_u256(ext_dev), nullptr, n_cols, k + ext_k, w, true, false, 0, nullptr, 0, true, nullptr);
 }
 int vdb_coeff_to_extended(const vdb_fr* const* coeff_cols, vdb_fr* const* ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();

@@ -453,7 +453,7 @@ struct QuotArgs {
 struct PermParts {
   uint64_t adv_col0, z_set0, chain_lo, chain_hi;
   const u256 *z_first, *z_last;
-  int head;
+  int head;          // bit 0: fold in the two terms of the first / last product alone; bit 1: the sigma cosets are those of beta sigma
 };
 __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv, const u256* __restrict__ sigma, const u256* __restrict__ z, uint64_t n_cols,
                                                    uint32_t chunk_len, uint64_t set_lo, uint64_t set_hi, const u256* __restrict__ bx, u256 dstart, QuotArgs q,
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
   (void)n_sets;
   z -= pp.z_set0 * ne;          // index by global set number from here on (only sets the caller provides are touched)
   adv -= pp.adv_col0 * ne;
-  if (pp.head) {
+  if (pp.head & 1) {
     // l0 (1 - z_0)
     h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(mont_one<Fr>()), l9_split32(ld256(pp.z_first + j)), q.c34), L0);
     // l_last (z_last^2 - z_last)
@@ -491,7 +491,10 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
     L9 left = l9_split32(ld256(z + i * ne + ((j + r) & mask))), right = l9_split32(ld256(z + i * ne + j));
     for (uint64_t c = c0; c < c1; c++) {
       const L9 v = l9_add(l9_split32(ld256(adv + c * ne + j)), G);
-      left = l9_mul<Fr>(l9_add(v, l9_mul<Fr>(l9_split32(ld256(sigma + (c - cb) * ne + j)), B)), left);
+      // (beta sigma: one product per column and extended row, unless the caller extended beta sigma(X) in the first place —
+      //  vdb_coeff_to_extended_scaled_dev: the scalar then costs a third of a product per BASE row)
+      const L9 sg = l9_split32(ld256(sigma + (c - cb) * ne + j));
+      left = l9_mul<Fr>(l9_add(v, (pp.head & 2) ? sg : l9_mul<Fr>(sg, B)), left);
       right = l9_mul<Fr>(l9_add(v, cur), right);
       cur = l9_mul<Fr>(cur, D);
     }
@@ -975,7 +978,7 @@ int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigm
   VDB_ARG(z_ext_dev && chunk_len >= 1, "bad argument");
   const size_t n_sets = (n_cols + chunk_len - 1) / chunk_len;
   const uint64_t ne = 1ull << (k + ext_k);
-  PermParts pp{0, 0, set_lo == 0 ? 1u : 0u, set_lo == 0 ? n_sets : 0u, as_u256(z_ext_dev), as_u256(z_ext_dev) + (n_sets ? n_sets - 1 : 0) * ne, set_lo == 0};
+  PermParts pp{0, 0, set_lo == 0 ? 1u : 0u, set_lo == 0 ? n_sets : 0u, as_u256(z_ext_dev), as_u256(z_ext_dev) + (n_sets ? n_sets - 1 : 0) * ne, set_lo == 0 ? 1 : 0};
   return permutation_eval_parts(adv_ext_dev, sigma_ext_block_dev, z_ext_dev, n_cols, chunk_len, k, ext_k, usable_rows, l0_ext_dev, l_last_ext_dev, l_active_ext_dev,
                                 beta, gamma, delta, y, acc_dev, set_lo, set_hi, pp);
 }
@@ -984,7 +987,7 @@ int vdb_permutation_eval_parts_dev(const vdb_fr* adv_ext_block_dev, size_t adv_c
                                    size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev, const vdb_fr* l_active_ext_dev, const vdb_fr* beta,
                                    const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev, int head, size_t chain_lo, size_t chain_hi,
                                    size_t set_lo, size_t set_hi) {
-  VDB_ARG(!head || (z_first_ext_dev && z_last_ext_dev), "the head terms read the first and the last product coset");
+  VDB_ARG(!(head & 1) || (z_first_ext_dev && z_last_ext_dev), "the head terms read the first and the last product coset");
   VDB_ARG(chain_lo >= chain_hi || (chain_lo >= 1 && chain_lo - 1 >= z_set0), "the chaining term of set i reads set i - 1");
   VDB_ARG(set_lo >= set_hi || (set_lo >= z_set0 && set_lo * chunk_len >= adv_col0), "the block buffers start after the first set asked for");
   PermParts pp{adv_col0, z_set0, chain_lo, chain_hi, as_u256(z_first_ext_dev), as_u256(z_last_ext_dev), head};

@@ -974,6 +974,7 @@ class ProverRounds:
                 f_2.skip_to(0, 2)
                 check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
             third = blk // 3
+            sigma_scaled = os.environ.get("VDB_SIGMA_SCALED", "1") != "0"      # (0: the A/B baseline — sigma's own cosets, the product by beta per point)
 
             def lookup_terms(base, col0, j_lo, j_hi):
                 """the lookup argument of my lookup columns j_lo .. j_hi, whose input cosets are in the block at `base`:
@@ -1007,7 +1008,11 @@ class ProverRounds:
                     # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
                     set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
                     z0 = max(set_lo - 1, 0)
-                    to_ext(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, nb)
+                    # (the cosets of beta sigma: the scalar rides on the transform's coset factors, the evaluation skips a product per point)
+                    if sigma_scaled:
+                        check(lib.vdb_coeff_to_extended_scaled_dev(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, _sz(nb), k, EXT_K, p["beta"]))
+                    else:
+                        to_ext(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, nb)
                     if z0 < set_lo and (z0 in z_slot or z0 < s_lo):          # the set in front is another rank's (or another range's)
                         to_ext(z_coeff(z0), d_ez.ptr, 1)
                         to_ext(z_coeff(set_lo), d_ez.at(ne * B), set_hi - set_lo)
@@ -1018,7 +1023,7 @@ class ProverRounds:
                         check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
                                                                  _sz(0), _sz(0)))
                     f_3.skip_to(set_lo, set_hi - set_lo)
-                    check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 0, _sz(0), _sz(0), _sz(set_lo),
+                    check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 2 if sigma_scaled else 0, _sz(0), _sz(0), _sz(set_lo),
                                                              _sz(set_hi)))
                     # lookup argument of the block's lookup columns that are mine
                     j_lo, j_hi = max(c0 - n_adv, l_lo), min(c0 + nb - n_adv, l_hi)

@@ -341,7 +341,8 @@ int vdb_permutation_eval_range_dev(const vdb_fr *adv_ext_dev, const vdb_fr *sigm
  * puts all chunks of all blocks on one chain (z_c starts where z_{c-1} ended), as vdb_permutation_product_dev does in one go.
  * vdb_permutation_eval_parts_dev: the permutation part of the quotient numerator with block buffers — adv_ext_block holds the
  * cosets of columns adv_col0 .., z_ext_block those of product sets z_set0 .., z_first / z_last the cosets of the first and last
- * set; `head`: fold in l0 (1 - z_0) and l_last (z_last^2 - z_last); [chain_lo, chain_hi): fold in l0 (z_i - z_{i-1}(..)) for these
+ * set; `head` bit 0: fold in l0 (1 - z_0) and l_last (z_last^2 - z_last); bit 1: sigma_ext_block holds the cosets of beta sigma(X)
+ * (vdb_coeff_to_extended_scaled_dev) and the kernel skips its product by beta; [chain_lo, chain_hi): fold in l0 (z_i - z_{i-1}(..)) for these
  * sets (reads sets chain_lo - 1 .. chain_hi - 1); [set_lo, set_hi): fold in the product terms of these sets (reads their columns,
  * sigma_ext_block starting at column set_lo * chunk_len).  Terms must be folded in the order head, chain 1 .. n_sets - 1, products
  * 0 .. n_sets - 1 to agree with the resident form. */
@@ -375,6 +376,9 @@ int vdb_kate_div_dev(const vdb_fr *coeff_dev, size_t n_cols, size_t n, const vdb
 /* coeff_to_extended: zeta-coset scaling [1, ZETA, ZETA^2] cyclic, zero-extend to 2^(k+ext_k), forward NTT */
 int vdb_coeff_to_extended(const vdb_fr *const *coeff_cols, vdb_fr *const *ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k);
 int vdb_coeff_to_extended_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);
+/* the coset image of scale * p(X): the scalar rides on the coset factors of the transform's first pass (a third of a product per
+ * coefficient) — how the quotient takes beta sigma(X) instead of multiplying every point of every sigma coset by beta */
+int vdb_coeff_to_extended_scaled_dev(const vdb_fr *coeff_dev, vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr *scale);
 /* EvaluationDomain::extended_to_coeff without the final truncation (the way back for h(X)): in place, per
  * column of 2^(k+ext_k) evaluations on the extended coset -> the 2^(k+ext_k) coefficients. */
 int vdb_extended_to_coeff_dev(vdb_fr *ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k);

@@ -603,3 +603,58 @@ def test_gate_eval_on_the_sub_coset(api, O):
     assert np.array_equal(d_h2.download((2 * n, 4)), before)
     for b in bufs + [d_h1, d_h2]:
         b.free()
+
+
+def test_scaled_coset_extension_and_prescaled_sigma(api, O):
+    """vdb_coeff_to_extended_scaled_dev(c, s) is the coset image of s c(X) — bit for bit vdb_coeff_to_extended_dev of the scaled
+    coefficients —, and the permutation part of the quotient fed with the cosets of beta sigma (head bit 1) is, bit for bit, the
+    accumulator it computes from the cosets of sigma with its own product by beta."""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    sz = ctypes.c_size_t
+    rng = np.random.default_rng(4242)
+    k, ext, chunk = 9, 2, 3
+    n, ne = 1 << k, 1 << (k + ext)
+    n_cols = 7
+    coeff = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    s = O.random_fr(rng, 1)[0]
+    d_c, d_e1, d_e2, d_sc = (api.DeviceBuffer(n_cols * m * 32) for m in (n, ne, ne, n))
+    d_c.upload(coeff)
+    check(lib.vdb_coeff_to_extended_scaled_dev(d_c.ptr, d_e1.ptr, sz(n_cols), k, ext, api._p(s)))
+    scaled = O.fr_mul(coeff.reshape(-1, 4), np.broadcast_to(s, (n_cols * n, 4)).copy()).reshape(n_cols, n, 4)
+    d_sc.upload(scaled)
+    check(lib.vdb_coeff_to_extended_dev(d_sc.ptr, d_e2.ptr, sz(n_cols), k, ext))
+    got, want = d_e1.download((n_cols, ne, 4)), d_e2.download((n_cols, ne, 4))
+    assert np.array_equal(got, want)
+    _, want_o = O.lde_batch(api.ntt_batch(scaled[:2], api.root_of_unity(k)), ext=ext, threads=2)     # (lde_batch takes Lagrange form)
+    assert np.array_equal(got[:2], want_o)
+    # the permutation terms: adv / sigma / z cosets of random polynomials, two sets + a short third
+    usable = n - 6
+    beta, gamma, y = O.random_fr(rng, 3)
+    adv_c, sig_c, z_c = (O.random_fr(rng, m * n).reshape(m, n, 4) for m in (n_cols, n_cols, 3))
+    lag_c = O.random_fr(rng, 3 * n).reshape(3, n, 4)
+    bufs = {}
+    for name, c in (("adv", adv_c), ("sig", sig_c), ("z", z_c), ("lag", lag_c)):
+        bc, be = api.DeviceBuffer(c.shape[0] * n * 32), api.DeviceBuffer(c.shape[0] * ne * 32)
+        bc.upload(c)
+        check(lib.vdb_coeff_to_extended_dev(bc.ptr, be.ptr, sz(c.shape[0]), k, ext))
+        bufs[name] = (bc, be)
+    d_sig_b = api.DeviceBuffer(n_cols * ne * 32)
+    check(lib.vdb_coeff_to_extended_scaled_dev(bufs["sig"][0].ptr, d_sig_b.ptr, sz(n_cols), k, ext, api._p(beta)))
+    l0, ll, la = (ctypes.c_void_p(bufs["lag"][1].ptr.value + i * ne * 32) for i in range(3))
+    acc0 = O.random_fr(rng, ne)
+    outs = []
+    for sig_ptr, head in ((bufs["sig"][1].ptr, 0), (d_sig_b.ptr, 2)):
+        d_acc = api.DeviceBuffer(ne * 32)
+        d_acc.upload(acc0)
+        check(lib.vdb_permutation_eval_parts_dev(bufs["adv"][1].ptr, sz(0), sig_ptr, bufs["z"][1].ptr, sz(0), None, None, sz(n_cols), sz(chunk), k, ext, sz(usable),
+                                                 l0, ll, la, api._p(beta), api._p(gamma), api._p(api.fr_delta()), api._p(y), d_acc.ptr, head, sz(0), sz(0), sz(0), sz(3)))
+        outs.append(d_acc.download((ne, 4)))
+        d_acc.free()
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], acc0)
+    for bc, be in bufs.values():
+        bc.free()
+        be.free()
+    for b in (d_c, d_e1, d_e2, d_sc, d_sig_b):
+        b.free()

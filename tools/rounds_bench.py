@@ -61,7 +61,7 @@ cells = hp.n_cells + hp.n_lookup
 free, total = api.mem_info()
 print(json.dumps({"workload": f"kmeans K=4 I={I} 256x128 k=16 {metric}, whole constraint map, transcript, fresh blinds",
                   "advice_columns": pr.n_adv, "lookup_columns": pr.n_lk, "product_columns": pr.n_sets + pr.n_lk, "cells": cells,
-                  "copies": int((pr.circuit.copy_of != __import__("numpy").arange(pr.circuit.n_cells)).sum()), "constants_in_fixed_column": len(pr.consts),
+                  "constants_in_fixed_column": len(pr.consts),
                   "advice_cosets_resident": bool(hp.ext_cols >= hp.n_cols + 2), "mock_report_on_keygen_witness": rep,
                   "quotient_identity_at_x_holds": bool(identity), "proof_bytes": len(out["proof"]),
                   "hot_path_setup_s": round(t_hp, 1), "keygen_s": round(t_keygen, 1), "proof_wall_ms": round(wall, 1),

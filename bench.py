@@ -377,20 +377,43 @@ def main():
             cpu = cpu_baseline(hp, cols, commitments[idx])
 
     proof = None
+    abandoned = False
     if not args.no_proof:
-        try:
-            from halo2_vectordb_amd._lib import check as _check
-            hp.free()
-            _check(api.init().vdb_scratch_release())
-            comm = None
-            if dist is not None:
-                from halo2_vectordb_amd.dist import Comm
-                comm = Comm(dist)
-            proof = whole_proof(api, rank, world, comm, small=args.small)
-        except Exception as e:      # the bench line above stands on its own
-            if dist is not None:
-                raise               # a rank that drops out of a sharded proof leaves the others waiting in a collective
-            proof = {"error": repr(e)[:300]}
+        from halo2_vectordb_amd._lib import check as _check
+        hp.free()
+        _check(api.init().vdb_scratch_release())
+        if dist is None:
+            try:
+                proof = whole_proof(api, small=args.small)
+            except Exception as e:      # the bench line above stands on its own
+                proof = {"error": repr(e)[:300]}
+        else:
+            # The sharded proof must never cost the run its bench line: a rank that fails inside it leaves the others waiting in
+            # a collective.  It runs in a worker thread that the main thread gives a bounded time; if a rank fails or the time runs
+            # out, rank 0 still prints the line (proof = the error) and every rank leaves without another collective.
+            import threading
+            box = {}
+
+            def work():
+                try:
+                    if dist.get_backend() == "nccl":
+                        import torch
+                        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # the current device is per thread
+                    from halo2_vectordb_amd.dist import Comm
+                    if os.environ.get("VDB_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: this rank drops out of the proof
+                        raise RuntimeError("rank failure injected by the test")
+                    box["proof"] = whole_proof(api, rank, world, Comm(dist), small=args.small)
+                except BaseException as e:
+                    box["proof"] = {"error": repr(e)[:300]}
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("VDB_BENCH_PROOF_TIMEOUT", "420")))
+            if th.is_alive():
+                proof = {"error": "the sharded proof did not finish in time on this rank (a rank failed, or a collective hangs)"}
+                abandoned = True
+            else:
+                proof = box["proof"]
+                abandoned = "error" in proof
 
     if rank == 0 and cpu is not None and proof is not None and "shape" in proof:
         est, parts = cpu_proof_estimate(cpu["proof_unit_costs"], cpu["cores"], proof["shape"])
@@ -415,8 +438,11 @@ def main():
         }
         if gather_ok is not None:
             out["gathered_commitments_match_unsharded_job"] = gather_ok
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        if abandoned:               # other ranks may be stuck in a collective of the abandoned proof: no barrier, no teardown handshake
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 

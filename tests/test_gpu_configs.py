@@ -314,6 +314,24 @@ def test_two_rank_timed_path_with_the_collective(tmp_path):
     assert pf["proof_ms"] > 0 and pf["n_instances"] == 2 * 8
 
 
+def test_a_failing_rank_of_the_sharded_proof_does_not_cost_the_bench_line(tmp_path):
+    """bench.py with N > 1: the sharded proof runs in a worker thread with a bounded wait.  A rank that drops out of it (injected
+    here) leaves the other rank waiting in a collective; the timed hot-path line is printed all the same, with the failure in
+    `proof`, and every rank exits cleanly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", VDB_BENCH_TEST_FAIL_RANK="1", VDB_BENCH_PROOF_TIMEOUT="12")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "error" in out["proof"]
+
+
 def test_extended_cosets_in_column_blocks(api, O):
     """A circuit whose cosets do not fit HBM streams through: coeff_to_extended runs block after block into one buffer.
     Forced here on a small circuit: same commitments and coefficients as the resident run, and the buffer ends up holding

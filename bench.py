@@ -102,10 +102,11 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     # whole-proof estimate main() attaches once the proved circuit's shape is known
     rng = np.random.default_rng(1)
     n = hp.rows
-    dense = O.random_fr(rng, 8 * n).reshape(8, n, 4)
+    nd = max(8, min(cores, 256))                                 # one column per thread: the aggregate rate of the whole host
+    dense = O.random_fr(rng, nd * n).reshape(nd, n, 4)
     t0 = time.perf_counter()
     O.msm_batch(dense, hp.g_lagrange, threads=cores)
-    t_dense = (time.perf_counter() - t0) / 8                     # per column of full-width scalars (products, permuted columns' z)
+    t_dense = (time.perf_counter() - t0) / nd                    # per column of full-width scalars (products, permuted columns' z)
     t0 = time.perf_counter()
     O.grand_product(dense[:4], dense[4:])
     t_gp = (time.perf_counter() - t0) / 4                        # per column, one thread

@@ -71,6 +71,23 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     from oracle import oracle as O  # test infrastructure: allowed here as the cpu_baseline leg only
     # threads = the host cores this process may run on (the GPU box hands a job a share of its CPU, not all of os.cpu_count())
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ... and no more threads than the CPU time the box grants (a cgroup quota: more threads than that only share the same cores)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                                                                # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    visible = cores
+    if quota:
+        cores = max(1, min(cores, int(round(quota))))
     qv = O.quantize(hp.vectors_f64, hp.P)
     # witness: one k-means iteration of the same circuit (single thread, like the reference's single Context)
     c = O.Ctx(store=True, keygen=False)
@@ -124,6 +141,7 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     return {
         "proof_unit_costs": units,
         "value": total_cells / t_full, "unit": "constraints/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+        "host_threads_visible": visible, "cpu_quota_cores": quota,
         "sample": (f"oracle C restatement: 1 of {hp.I} k-means iterations of witness gen single-threaded ({t_wit:.2f} s, "
                    f"{cells_one_iter} cells), Pippenger MSM + iNTT/coset-NTT of {ns} of {hp.n_cols} real columns on {cores} threads "
                    f"({t_msm:.2f} s + {t_ntt:.2f} s, medians of 3), extrapolated linearly to the full job; the port is plain C "

@@ -67,6 +67,8 @@ def main():
         hp = NearestHotPath(n=64, dim=128, k=14, L=13, tau=TAU, col_shard=shard)
     elif args.circuit == "mid":      # a k = 16 cosine k-means of a few thousand columns: per-rank work and exchange overheads at a real row count
         hp = KmeansHotPath(n=128, dim=64, K=4, I=4, k=16, P=48, L=15, metric="cosine", tau=TAU, col_shard=shard)
+    elif args.circuit == "half":     # BASELINE C4' with half the iterations: 0.69 G cells, ~10.5 k columns at 2^16 rows (two ranks fit one 288 GB card)
+        hp = KmeansHotPath(n=256, dim=128, K=4, I=4, k=16, P=48, L=15, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "merkle":
         hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU, col_shard=shard)
     else:

@@ -3,7 +3,9 @@
 Pins: (1) the Poseidon authors' published known-answer for poseidonperm_x5_254_3 (input [0,1,2]),
 whose first word is also circomlib's poseidon([1,2]); (2) circomlib's first round constant / MDS
 entry for t=3 (same Grain procedure); (3) optimized (PSE sparse-MDS) schedule == textbook schedule;
-(4) independent Python implementation.  The reference itself pins only "root computed twice is
+(4) independent Python implementation; (5) the authors' known-answer for poseidonperm_x5_254_5 (input [0 .. 4], R_F = 8, R_P = 60):
+the width-5 permutation of the Fiat-Shamir transcript (snark-verifier's PoseidonTranscript parameters, src/scaffold/mod.rs:309-310).
+The reference itself pins only "root computed twice is
 equal" (tests/demo/mod.rs:72-77) — reproduced in test_merkle_self_consistency.
 The sponge framing (capacity 2^64, extra padding permutation) is [UPSTREAM-RECALL]: parity unpinned.
 """
@@ -21,6 +23,25 @@ def test_permutation_known_answer(O):
     st = O.fr_from_ints([0, 1, 2])
     assert O.fr_to_ints(O.poseidon_permute(st, optimized=False)) == KAT_OUT
     assert O.fr_to_ints(O.poseidon_permute(st, optimized=True)) == KAT_OUT
+
+
+KAT5_OUT = [
+    0x299C867DB6C1FDD79DCEFA40E4510B9837E60EBB1CE0663DBAA525DF65250465,
+    0x1148AAEF609AA338B27DAFD89BB98862D8BB2B429ACEAC47D86206154FFE053D,
+    0x24FEBB87FED7462E23F6665FF9A0111F4044C38EE1672C1AC6B0637D34F24907,
+    0x0EB08F6D809668A981C186BEAF6110060707059576406B248E5D9CF6E78B3D3E,
+    0x07748BC6877C9B82C8B98666EE9D0626EC7F5BE4205F79EE8528EF1C4A376FC7,
+]
+
+
+def test_width5_permutation_known_answer(O, PY):
+    """the transcript's permutation (t = 5, R_F = 8, R_P = 60: Grain constants and MDS of that width, 68 rounds) against the Poseidon
+    authors' published vector — in the C oracle (textbook and sparse schedules) and the independent Python implementation; the
+    product's three host builds are held to that Python implementation in tests/test_transcript_cpu.py"""
+    st = O.fr_from_ints([0, 1, 2, 3, 4])
+    assert O.fr_to_ints(O.poseidon_permute(st, optimized=False, t=5, r_f=8, r_p=60)) == KAT5_OUT
+    assert O.fr_to_ints(O.poseidon_permute(st, optimized=True, t=5, r_f=8, r_p=60)) == KAT5_OUT
+    assert PY.Poseidon(t=5, r_f=8, r_p=60).permute([0, 1, 2, 3, 4]) == KAT5_OUT
 
 
 def test_grain_constants_match_circomlib(O):

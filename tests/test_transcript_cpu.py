@@ -1,6 +1,7 @@
 """Fiat–Shamir transcript (host code of the product library, no GPU involved) against the independent
-Python restatement of the Poseidon sponge in oracle/pyref.py.  Parity unpinned beyond that: width, round numbers and
-encodings are [UPSTREAM-RECALL] (the reference holds no transcript or proof bytes)."""
+Python restatement of the Poseidon sponge in oracle/pyref.py, whose width-5 permutation is pinned to the Poseidon authors' published
+vector poseidonperm_x5_254_5 (tests/test_oracle_poseidon.py).  Parity unpinned beyond that: that upstream uses this width and these
+round numbers, the sponge's framing and the encodings are [UPSTREAM-RECALL] (the reference holds no transcript or proof bytes)."""
 import numpy as np
 import pytest
 

@@ -31,6 +31,9 @@ def test_root_of_unity_and_zeta(O):
     z = O.fr_to_ints(O.zeta())[0]
     assert z == 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
     assert pow(z, 3, R) == 1 and z != 1
+    # the permutation argument's coset multiplier: halo2curves bn256 Fr::DELTA = GENERATOR^(2^S) with GENERATOR = 7, S = 28, as
+    # published in the crate (fr.rs, recalled) — the value the oracle and the library compute from 7
+    assert O.DELTA_INT == pow(7, 1 << 28, R) == 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
 
 
 def test_field_ops_vs_python(O):

@@ -16,7 +16,7 @@
 using namespace vdbhost;
 
 namespace {
-constexpr uint32_t P = 48, MINIMUM_ROWS = 9, N_BLIND = 6;  // src/scaffold/mod.rs:383; halo2: blinding_factors + 1
+constexpr uint32_t P = 48, MINIMUM_ROWS = 9, N_BLIND = 7;  // src/scaffold/mod.rs:383 (= blinding_factors + 3); halo2: blinding_factors + 1 rows of blinds
 
 struct Dev {  // RAII device allocation
   void* p = nullptr;

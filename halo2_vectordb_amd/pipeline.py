@@ -19,7 +19,11 @@ from . import api
 from ._lib import check
 
 MINIMUM_ROWS = 9   # MINIMUM_ROWS default, src/scaffold/mod.rs:383
-N_BLIND = 6        # blinding rows filled with random scalars by the prover (halo2: blinding_factors + 1)
+# Rows at the end of every column that the prover fills with random scalars: halo2's blinding_factors() + 1.  blinding_factors() =
+# max(3, advice queries per column) + 2 [UPSTREAM-RECALL]; halo2-base's vertical gate reads a column at four rotations, so 6 — which is
+# what the reference's own MINIMUM_ROWS = 9 = blinding_factors() + 3 says (src/scaffold/mod.rs:383) — and the last usable row, where
+# l_last sits and the running products end, is row 2^k - 7.  (Rounds 1-2 used 6.)
+N_BLIND = 7
 
 
 def sift_like_vectors(seed, n, dim, k_distinct=0):

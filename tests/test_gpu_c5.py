@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-K18, L17, N_BLIND = 18, 17, 6
+K18, L17, N_BLIND = 18, 17, 7
 
 
 @pytest.fixture(scope="module")

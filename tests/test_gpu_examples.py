@@ -8,7 +8,7 @@ import pytest
 import examples_common as E
 
 pytestmark = pytest.mark.gpu
-N_BLIND = 6
+N_BLIND = 7
 
 
 @pytest.fixture(scope="module")

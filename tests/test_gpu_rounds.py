@@ -556,7 +556,7 @@ def test_every_proof_draws_fresh_blinding_scalars(circuit, O):
     assert not (c1 == c2).all(axis=1).any()
     assert np.array_equal(hp.step(blind_seed=5), hp.step(blind_seed=5))
     # the blinding rows are uniform field elements: canonical values below r that fill the whole range
-    blinds = O.fr_to_ints(hp.d_blind.download((hp.n_cols * 6, 4)))
+    blinds = O.fr_to_ints(hp.d_blind.download((hp.n_cols * 7, 4)))
     assert len(set(blinds)) == len(blinds) and max(v.bit_length() for v in blinds) >= 252 and all(v < O.R_MOD for v in blinds)
 
 

@@ -31,6 +31,7 @@ from ._lib import check
 from .pipeline import N_BLIND
 
 B = 32
+DERIVED = ("hf",)   # opened polynomials whose evaluation is not in the proof: the verifier computes it (h folded at x, from the quotient identity)
 FIXED = ("sel", "sigma", "cst", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
 EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
 CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
@@ -542,6 +543,7 @@ class ProverRounds:
         # the instance column: Lagrange form (the public values in rows 0 .. n_instances - 1, zero below), coefficients, coset —
         # made anew for every proof from the values of the statement
         self.d_inst_lag, self.d_inst_coeff, self.d_inst_ext = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B), api.DeviceBuffer(self.ne * B)
+        self.d_rand, self.d_hf = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)       # the vanishing argument's random polynomial, h folded at x
         check(lib.vdb_memset_dev(self.d_inst_lag.ptr, 0, _sz(rows * B)))
         self._vk_digest = None
         self.vk_digest()            # part of the key, made here so that no proof pays for it
@@ -618,8 +620,9 @@ class ProverRounds:
         """challenges: dict of Montgomery field elements beta, gamma, y, x, v, or None to derive them with the Fiat–Shamir
         transcript (api.Transcript; the proof bytes are then returned as `proof`).  Transcript order: the verifying key's
         digest (vk_digest: one scalar made of the fixed commitments at keygen); the public inputs; advice commitments -> theta (squeezed as halo2 does, unused: the lookups
-        are single-column); permuted input / table commitments -> beta, gamma; product commitments -> y; the quotient's
-        pieces -> x; all evaluations, rotation by rotation -> then the multi-open: "gwc": v, one quotient per rotation
+        are single-column); permuted input / table commitments -> beta, gamma; product commitments, the vanishing argument's random
+        polynomial -> y; the quotient's pieces -> x; all evaluations, rotation by rotation (not h's: h is folded at x and its value follows
+        from the quotient identity, halo2's vanishing argument) -> then the multi-open: "gwc": v, one quotient per rotation
         point; "shplonk" (what the reference's gen_snark_shplonk runs, [UPSTREAM-RECALL] for the order of its challenges):
         yo, v; the quotient f of all rotation sets; u; the quotient of the linearisation polynomial.
         `instances`: the public values, one per public cell of keygen (Montgomery field elements); None = read from the witness
@@ -635,7 +638,7 @@ class ProverRounds:
         comm, world, rank = self.comm, self.world, self.rank
         if world > 1 and multiopen != "shplonk":
             raise ValueError("the sharded rounds open with SHPLONK")
-        seeds = iter([None] * 8 if seed is None else [[int(seed), i] for i in range(1, 9)])
+        seeds = iter([None] * 9 if seed is None else [[int(seed), i] for i in range(1, 10)])
         tr = api.Transcript() if challenges is None else None
         ch = {} if challenges is None else {name: np.ascontiguousarray(v, dtype=np.uint64) for name, v in challenges.items()}
         p = {name: api._p(v) for name, v in ch.items()}
@@ -915,6 +918,21 @@ class ProverRounds:
         polys["zl"] = _Poly("zl", my_lk, lag=d_zl, commits=zl_c, ranges=lk_ranges, n_total=n_lk)
         stage("derived_ntt", lambda: derived_forms(("pa", "ps", "zp", "zl")))
         write_points(polys["zl"].commits)
+        # The vanishing argument's random polynomial (halo2 plonk/vanishing/prover.rs Argument::commit, [UPSTREAM-RECALL]): n uniform
+        # coefficients, committed before y is squeezed and opened at x beside the folded quotient — it blinds the one evaluation of h
+        # the multi-open reveals.  In a sharded proof rank 0 draws it and every rank receives the same coefficients.
+        d_rand = self.d_rand
+        if rank == 0:
+            api.random_scalars_dev(d_rand.ptr, rows, seed=next(seeds))
+        if world > 1:
+            rc = np.zeros((rows, 4), dtype=np.uint64)
+            if rank == 0:
+                check(lib.vdb_memcpy_d2h(api._p(rc), d_rand.ptr, _sz(rows * B)))
+            rc = comm.sum_disjoint(rc)
+            if rank != 0:
+                d_rand.upload(rc)
+        polys["rand"] = _Poly("rand", 1, coeff=d_rand, commits=stage("commit_h", lambda: self._commit(d_rand, 1, 0)), replicated=True)
+        write_points(polys["rand"].commits)
         squeeze("y")
 
         # the boundary products other ranks ask for, in coefficient form: the set before each of their ranges, and the first set
@@ -1047,11 +1065,19 @@ class ProverRounds:
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)), replicated=True)
         write_points(polys["h"].commits)
         squeeze("x")
+        # h folded at x (halo2 vanishing::Constructed::evaluate): hf(X) = sum_i x^(n i) h_i(X), one polynomial of degree below n whose
+        # commitment the verifier forms from the pieces' and whose value at x it computes from the quotient identity — neither is sent
+        xn = pow(_fr_to_int(ch["x"]), rows, R_MOD)
+        d_hf = self.d_hf
+        check(lib.vdb_memcpy_d2d(d_hf.ptr, d_h.ptr, _sz(rows * B)))
+        for i in range(1, n_h):
+            check(lib.vdb_poly_axpy_dev(d_hf.ptr, api._p(_fr_from_int(pow(xn, i, R_MOD))), d_h.at(i * rows * B), _sz(rows)))
+        polys["hf"] = _Poly("hf", 1, coeff=d_hf, commits=stage("commit_h", lambda: self._commit(d_hf, 1, 0)), replicated=True)
 
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "pa", "ps", "zp", "zl", "h"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "pa", "ps", "zp", "zl", "hf", "rand"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_total] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                   # opens nothing at w^-1 x
@@ -1109,6 +1135,8 @@ class ProverRounds:
                     if i + 1 < len(groups):
                         launch(i + 1)
                     evals[(name, rot)] = out
+                    if name in DERIVED:                  # computed by the verifier, not sent
+                        continue
                     t0 = time.perf_counter()
                     tr.write_scalars(out)
                     tr.flush()
@@ -1124,7 +1152,8 @@ class ProverRounds:
             if tr is not None:
                 t0 = time.perf_counter()
                 for rot, name in groups:
-                    tr.write_scalars(evals[(name, rot)])
+                    if name not in DERIVED:
+                        tr.write_scalars(evals[(name, rot)])
                 host["transcript"] += (time.perf_counter() - t0) * 1e3
         d_comb, d_quot = self.d_comb, self.d_quot
         if multiopen == "shplonk":
@@ -1316,7 +1345,7 @@ class ProverRounds:
         self.fixed = {}
         self._vk_digest = None
         for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32", "d_inst_lag", "d_inst_coeff", "d_inst_ext", "d_inst_cells",
-                     "d_foreign_lag", "d_foreign_coeff", "d_zhalo"):
+                     "d_foreign_lag", "d_foreign_coeff", "d_zhalo", "d_rand", "d_hf"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()
@@ -1392,5 +1421,5 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
         acc = (acc * yv + l0 * (PA[c] - PS[c])) % R
         acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
     xn = pow(x, n, R)
-    hx = sum(h_i * pow(xn, i, R) for i, h_i in enumerate(ev("h"))) % R
+    hx = ev("hf")[0]                 # h folded at x: sum_i x^(n i) h_i(x), evaluated by the prover (a verifier computes it from this very identity)
     return acc == hx * (xn - 1) % R and acc != 0

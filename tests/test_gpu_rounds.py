@@ -64,8 +64,33 @@ def instance_poly_at(O, instances, x, k):
     return acc * (pow(x, n, R) - 1) * pow(n, -1, R) % R
 
 
+def folded_h(O, meta, ch, evals, instances, h_commits):
+    """What a verifier derives instead of reading it (halo2's vanishing argument): the value of h folded at x — the quotient
+    identity's numerator over x^n - 1 — and the folded commitment sum_i [x^(n i)] H_i.  None when the statement is malformed."""
+    R = O.R_MOD
+    num = quotient_numerator(O, meta, ch, evals, instances)
+    if num is None:
+        return None
+    x = O.fr_to_ints(np.asarray(ch["x"]).reshape(1, 4))[0]
+    xn = pow(x, meta["rows"], R)
+    value = num * pow((xn - 1) % R, -1, R) % R
+    commit = O.msm_naive(O.fr_from_ints([pow(xn, i, R) for i in range(len(h_commits))]), np.asarray(h_commits))
+    return value, commit
+
+
 def check_quotient_identity(O, meta, ch, evals, instances=()):
-    """gates + permutation + lookup expressions from the evaluations == h(x) (x^n - 1)"""
+    """gates + permutation + lookup expressions from the evaluations == hf(x) (x^n - 1), hf(x) = the prover's own evaluation of h
+    folded at x (returned by prove(); a verifier does not receive it: folded_h)"""
+    R = O.R_MOD
+    num = quotient_numerator(O, meta, ch, evals, instances)
+    if num is None or not evals.get(("hf", 0)):
+        return False
+    x = O.fr_to_ints(np.asarray(ch["x"]).reshape(1, 4))[0]
+    return num == evals[("hf", 0)][0] * (pow(x, meta["rows"], R) - 1) % R and num != 0
+
+
+def quotient_numerator(O, meta, ch, evals, instances=()):
+    """gates + permutation + lookup expressions recombined from the evaluations (None: wrong number of public values)"""
     R = O.R_MOD
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     b, g, yv, x = (to_int(ch[n]) for n in ("beta", "gamma", "y", "x"))
@@ -76,7 +101,7 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
     if len(instances) != meta["n_instances"]:
-        return False
+        return None
     l0, ll, la = ev("lag")
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
     # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (from the public values)
@@ -102,9 +127,7 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
         acc = (acc * yv + la * (Z1[c] * (PA[c] + b) * (PS[c] + g) - Z[c] * (A[c] + b) * (S + g))) % R
         acc = (acc * yv + l0 * (PA[c] - PS[c])) % R
         acc = (acc * yv + la * (PA[c] - PS[c]) * (PA[c] - PAm[c])) % R
-    xn = pow(x, n, R)
-    hx = sum(h_i * pow(xn, i, R) for i, h_i in enumerate(ev("h"))) % R
-    return acc == hx * (xn - 1) % R and acc != 0
+    return acc
 
 
 def check_openings(O, v_int, commitments, evals, openings):
@@ -140,7 +163,7 @@ def test_round_outputs_have_the_expected_shape(circuit, proved):
     ch, out, timings = proved
     assert pr.n_adv >= 2 and pr.n_lk >= 1
     c = out["commitments"]
-    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (4, 8) and c["pa"].shape == (pr.n_lk, 8)
+    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (4, 8) and c["rand"].shape == (1, 8) and c["hf"].shape == (1, 8) and c["pa"].shape == (pr.n_lk, 8)
     assert len(out["openings"]) == 6 and out["proof"] is None
     for name in ("witness", "commit_msm", "ntt", "lookup_permute", "products", "quotient", "evaluations", "openings"):
         assert timings[name] > 0
@@ -214,9 +237,9 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
     counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
-              "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
+              "zp": meta["n_sets"], "zl": meta["n_lk"], "rand": 1, "hf": 0}          # (hf: opened, but its evaluation is not sent)
     n_evals = sum(counts[name] for names in opened.values() for name in names)
-    n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 4 + len(opened)
+    n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 1 + 4 + len(opened)
     assert len(proof) == 32 * (n_points + n_evals)
 
     # ---- the verifier
@@ -243,6 +266,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     ch["beta"], ch["gamma"] = tr.squeeze(), tr.squeeze()
     commitments["zp"] = absorb(take_points(counts["zp"]))
     commitments["zl"] = absorb(take_points(counts["zl"]))
+    commitments["rand"] = absorb(take_points(1))                       # the vanishing argument's random polynomial, before y
     ch["y"] = tr.squeeze()
     commitments["h"] = absorb(take_points(4))
     ch["x"] = tr.squeeze()
@@ -267,8 +291,13 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     # the challenges the prover used are the ones the proof bytes determine
     for name in ("beta", "gamma", "y", "x", "v"):
         assert np.array_equal(ch[name], out["challenges"][name])
-    assert check_quotient_identity(O, meta, ch, evals, out["instances"])
+    # h folded at x: value from the quotient identity, commitment from the pieces' — the opening at x then checks the identity itself
+    hf_value, hf_commit = folded_h(O, meta, ch, evals, out["instances"], commitments["h"])
+    evals[("hf", 0)], commitments["hf"] = [hf_value], hf_commit.reshape(1, 8)
+    assert hf_value == out["evals"][("hf", 0)][0] and np.array_equal(commitments["hf"], out["commitments"]["hf"])
     assert check_openings(O, O.fr_to_ints(ch["v"].reshape(1, 4))[0], commitments, evals, openings)
+    evals[("hf", 0)] = [(hf_value + 1) % O.R_MOD]
+    assert not check_openings(O, O.fr_to_ints(ch["v"].reshape(1, 4))[0], commitments, evals, openings)
 
 
 def test_rounds_on_a_merkle_circuit_without_lookups(O):
@@ -404,7 +433,7 @@ def _verify(O, api, proof, vk):
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
     counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
-              "zp": meta["n_sets"], "zl": meta["n_lk"], "h": 4}
+              "zp": meta["n_sets"], "zl": meta["n_lk"], "rand": 1, "hf": 0}
     pos = 0
     tr = api.Transcript()
     try:
@@ -432,6 +461,7 @@ def _verify(O, api, proof, vk):
         C["pa"], C["ps"] = pairs[0::2], pairs[1::2]
         ch["beta"], ch["gamma"] = tr.squeeze(), tr.squeeze()
         C["zp"], C["zl"] = points(counts["zp"]), points(counts["zl"])
+        C["rand"] = points(1)
         ch["y"] = tr.squeeze()
         C["h"] = points(4)
         ch["x"] = tr.squeeze()
@@ -457,8 +487,12 @@ def _verify(O, api, proof, vk):
         return False
     finally:
         tr.free()
-    if not check_quotient_identity(O, meta, ch, evals, vk.get("instances", [])):
+    # h folded at x is not in the proof: its value is what the quotient identity demands, its commitment the pieces' combination;
+    # the pairing equation below then holds only if the committed h really takes that value
+    hf = folded_h(O, meta, ch, evals, vk.get("instances", []), C["h"])
+    if hf is None:
         return False
+    evals[("hf", 0)], C["hf"] = [hf[0]], hf[1].reshape(1, 8)
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     x, yo, v, u = (to_int(ch[n]) for n in ("x", "yo", "v", "u"))
     w = to_int(O.root_of_unity(meta["k"]))
@@ -529,8 +563,9 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
         rep = verify_file.main(os.path.join(d, "kmeans.snark"))
         assert rep["accepted"] and not rep["tampered_byte_accepted"] and rep["columns"] == pr.n_cols
     assert proof_f == proof and _verify(O, api, proof_f, {**vk, "instances": inst_f})
-    n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 4
-    for where in (5, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 64 + 7, len(proof) - 20):    # a commitment, h, an evaluation, W1, W2
+    n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 1 + 4
+    # a commitment, the random polynomial, h, an evaluation, the last evaluation (the random polynomial's), W1, W2
+    for where in (5, 32 * (n_points - 5) + 3, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 96 + 9, len(proof) - 64 + 7, len(proof) - 20):
         bad = bytearray(proof)
         bad[where] ^= 4
         assert not _verify(O, api, bytes(bad), vk)
@@ -544,7 +579,7 @@ def test_every_proof_draws_fresh_blinding_scalars(circuit, O):
     from oracle import pairing as PR
     hp, pr = circuit
     a, b = pr.prove(None), pr.prove(None)               # seed=None: operating-system entropy
-    for name in ("adv", "pa", "ps", "zp", "zl"):
+    for name in ("adv", "pa", "ps", "zp", "zl", "rand", "h"):
         ca, cb = a["commitments"][name], b["commitments"][name]
         assert ca.shape == cb.shape and not (ca == cb).all(axis=1).any(), name
     assert a["proof"] != b["proof"]

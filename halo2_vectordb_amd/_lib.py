@@ -62,6 +62,7 @@ _SIGNATURES = {
     "vdb_wit_kmeans": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
     "vdb_wit_kmeans_dev": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
     "vdb_wit_merkle_size": [_SZ, _SZ, _I, _P], "vdb_wit_merkle": [_P, _SZ, _SZ, _I, _P, _P, _P],
+    "vdb_wit_distance_dev": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_wit_nearest_dev": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P, _P],
     "vdb_wit_merkle_dev": [_P, _SZ, _SZ, _I, _P, _P, _P],
     "vdb_layout_plan": [_P, _U64, _U32, _U32, _P, _U64, _P], "vdb_layout_plan_dev": [_P, _U64, _U32, _U32, _P, _U64, _P],

@@ -500,6 +500,15 @@ def trace_distance(metric, dim, P, L, n_pairs=1):
     return _whole(s, 2 * dim), outs
 
 
+def trace_distances(metrics, dim, P, L):
+    """ctx.assign_witnesses(a); ctx.assign_witnesses(b); then one distance after the other on the same two vectors
+    (examples/distances.rs:40-59; pipeline.DistancesHotPath)"""
+    s = Sym(P, L)
+    a, b = s.assign_witnesses(dim), s.assign_witnesses(dim)
+    outs = [s.distance(m, a, b) for m in metrics]
+    return _whole(s, 2 * dim), outs
+
+
 def trace_nearest(metric, n, dim, P, L):
     s = Sym(P, L)
     q = s.assign_witnesses(dim)

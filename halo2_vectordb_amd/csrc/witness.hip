@@ -1282,6 +1282,20 @@ int vdb_wit_distance(int metric, uint32_t P, uint32_t L, const vdb_fr* a, const 
   return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
 }
 
+int vdb_wit_distance_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* a_dev, const vdb_fr* b_dev, size_t n_pairs, size_t dim, vdb_fr* stream_dev,
+                         vdb_fr* lookup_dev, uint8_t* selector_dev, vdb_fr* result_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(a_dev && b_dev && stream_dev && lookup_dev && result_dev && n_pairs > 0 && dim > 0, "null pointer or empty input");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  int* derr = (int*)scratch_get(1, 64);
+  if (!derr) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], g_win[2], g_win[3]};
+  TRY(wit_distance_dev(fp, metric, as_u256(a_dev), as_u256(b_dev), n_pairs, dim, st, 0, 0, as_u256(result_dev)));
+  return check_err_flag(derr);
+}
+
 int vdb_wit_nearest_size(int metric, uint32_t P, uint32_t L, size_t n, size_t dim, uint64_t* cells, uint64_t* lookups) {
   VDB_REQUIRE_INIT();
   VDB_ARG(n > 0, "empty database");

@@ -717,3 +717,61 @@ class QueryHotPath(NearestHotPath):
                 getattr(self, name).free()
                 setattr(self, name, None)
 
+
+class DistancesHotPath(KmeansHotPath):
+    """The reference's two-vector circuits through the same hot path: examples/distances.rs:29-59 (assign a, assign b, then
+    euclidean, manhattan and cosine distance of the same two vectors, each made public; the Hamming distance of that example is
+    outside the GPU path) and examples/euclid.rs:26-46 (ten Euclidean distances of one pair, nothing public:
+    `metrics=("euclidean",) * 10, public=False`).  BASELINE configs[0] is this circuit with one Euclidean distance of two 4-dim
+    vectors at k = 13, LOOKUP_BITS = 12.  Stream: [a | b | the cells of each distance in turn]; every rank emits every cell (a few
+    columns: nothing to shard the witness by)."""
+
+    def __init__(self, dim=4, metrics=("euclidean", "manhattan", "cosine"), k=13, P=48, L=12, seed=20260001, tau=None, col_shard=(0, 1), vectors=None,
+                 blind_seed=None, public=True):
+        """`vectors`: (2, dim) f64 rows, a then b"""
+        super().__init__(n=2, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metrics[0], seed=seed, tau=tau, col_shard=col_shard, vectors=vectors,
+                         blind_seed=blind_seed)
+        self.metrics = tuple(metrics)
+        for m in self.metrics:
+            if m not in api.METRICS:
+                raise ValueError("unknown distance: " + str(m))
+        self.public = bool(public)
+        self.shard_witness = False
+
+    def _input_vectors(self):
+        return sift_like_vectors(self.seed, 2, self.dim)
+
+    def _circuit_size(self):
+        self.parts = []
+        cells_total = lk_total = 0
+        for m in self.metrics:
+            cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
+            check(self.lib.vdb_wit_distance_size(api.METRICS[m], self.P, self.L, 1, self.dim, ctypes.byref(cells), ctypes.byref(lk)))
+            self.parts.append((api.METRICS[m], cells_total, lk_total))
+            cells_total, lk_total = cells_total + cells.value, lk_total + lk.value
+        return 2 * self.dim, cells_total, lk_total
+
+    def _alloc_outputs(self):
+        self.d_res = api.DeviceBuffer(len(self.metrics) * 32)
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(self.n_in * 32)))
+        for i, (metric, off, lk_off) in enumerate(self.parts):
+            at = self.n_in + off
+            check(lib.vdb_wit_distance_dev(metric, self.P, self.L, self.d_vec.ptr, self.d_vec.at(self.dim * 32), 1, self.dim, self.d_stream.at(at * 32),
+                                           self.d_lookup.at(lk_off * 32), ctypes.c_void_p(sel.ptr.value + at) if sel is not None else None,
+                                           self.d_res.at(i * 32)))
+
+    def public_values_dev(self):
+        return self.d_res.ptr, len(self.metrics) if self.public else 0      # examples/distances.rs:44-59: make_public.push(dist) after each
+
+    def results(self):
+        return self.d_res.download((len(self.metrics), 4))
+
+    def free(self):
+        super().free()
+        if getattr(self, "d_res", None) is not None:
+            self.d_res.free()
+            self.d_res = None
+

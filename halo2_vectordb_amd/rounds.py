@@ -277,6 +277,15 @@ class ProverRounds:
     def circuit_map(self, d_flags):
         """The circuit's constraint map (circuit_sym.CopyMap) for the gadget this hot path runs: the symbolic trace of the
         fixed-point gadgets, or of the Poseidon sponge for the Merkle circuit."""
+        from .pipeline import DistancesHotPath, MerkleHotPath, NearestHotPath, QueryHotPath
+        hp = self.hp
+        on_device = getattr(self, "map_on_device", True)
+        if isinstance(hp, DistancesHotPath):
+            # two vectors, a handful of distances: the whole trace on the host (examples/distances.rs, examples/euclid.rs)
+            from . import circuit_sym as CS
+            cm, outs = CS.trace_distances(hp.metrics, hp.dim, hp.P, hp.L)
+            self.public_cells = [int(c) for c in outs] if hp.public else []      # examples/distances.rs:44-59 make_public.push(dist)
+            return cm
         from .pipeline import MerkleHotPath, NearestHotPath, QueryHotPath
         hp = self.hp
         on_device = getattr(self, "map_on_device", True)

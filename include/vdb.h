@@ -127,6 +127,10 @@ int vdb_wit_distance_size(int metric, uint32_t precision_bits, uint32_t lookup_b
 /* DistanceChip::{euclidean,cosine,manhattan}_distance for n_pairs independent (a_i, b_i) */
 int vdb_wit_distance(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a, const vdb_fr *b, size_t n_pairs, size_t dim,
                      vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *result_out);
+/* the same with inputs and outputs resident in HBM (the distances circuit of examples/distances.rs / examples/euclid.rs inside the hot
+ * path: pipeline.DistancesHotPath); honours vdb_wit_set_window */
+int vdb_wit_distance_dev(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a_dev, const vdb_fr *b_dev, size_t n_pairs, size_t dim,
+                         vdb_fr *stream_dev, vdb_fr *lookup_dev, uint8_t *selector_dev, vdb_fr *result_dev);
 /* VectorDBChip::nearest_vector (src/gadget/vectordb.rs:122-163): indicator_out n raw 0/1 field bits */
 int vdb_wit_nearest_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, uint64_t *cells, uint64_t *lookups);
 int vdb_wit_nearest(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *query, const vdb_fr *vectors, size_t n, size_t dim,

@@ -41,6 +41,25 @@ def test_distance_map_on_oracle_witnesses(O, metric, dim, P, L):
     assert tied.mean() > 0.4 and cm.asserted.sum() == (0 if metric == "manhattan" else (8 if metric == "euclidean" else 16))   # per qlog2: is_invalid, 3 x 2 in check_power_of_two, the bracket
 
 
+def test_distances_example_map_on_the_oracles_witness(O):
+    """examples/distances.rs:40-59: three distances of the same two assigned vectors in one context; the map's outputs are the cells
+    the example makes public"""
+    metrics = ("euclidean", "manhattan", "cosine")
+    cm, outs = CS.trace_distances(metrics, 3, 48, 12)
+    qa, qb = O.quantize(np.array([0.123, 0.456, 1.789])), O.quantize(np.array([1.123, 0.456, 0.789]))
+    c = O.Ctx(store=True, keygen=True)
+    c.assign_witnesses(qa)
+    c.assign_witnesses(qb)
+    res = [c.distance(m, qa, qb, P=48, L=12) for m in metrics]
+    assert len(c) == cm.n_cells and c.n_lookup == len(cm.lookup_src)
+    vals = to_ints(O, c.advice())
+    ok, bad = clean(cm.check_witness(vals, to_ints(O, c.lookup()), flags=c.selectors()))
+    assert ok, bad
+    assert [vals[o] for o in outs] == [to_ints(O, r)[0] for r in res]
+    # every distance reads the assigned vectors themselves: each of the six input cells is copied by all three
+    assert all(int((cm.copy_of == cell).sum()) >= 4 for cell in range(6))
+
+
 def test_sqrt_of_zero_violates_its_asserted_constant(O):
     """the defect examples/euclid.rs:25 hunts: euclidean distance 0 -> qlog2(0): `is_invalid` is one but assert_is_const ties it to
     zero (fixed_point.rs:742-745), and the bracket 2^n <= a < 2^(n+1) cannot hold either.  Gates, copies and lookups are all

@@ -1,0 +1,112 @@
+"""The reference's two-vector circuits (examples/distances.rs:29-59, examples/euclid.rs:26-46; tests/distances/mod.rs chip_*; BASELINE
+configs[0]) through the hot path and the whole proof: cells against the oracle, results against f64 at the reference tests' tolerance,
+the distances public as `make_public.push(dist)` makes them."""
+import numpy as np
+import pytest
+
+import examples_common as E
+from test_gpu_rounds import FIXED, TAU, _meta, _verify
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init(0)
+    return a
+
+
+def _same_stream(hp, c, O):
+    d_flags = hp.keygen_flags()
+    flags = d_flags.download((hp.n_cells,), dtype=np.uint8)
+    d_flags.free()
+    hp._witness()
+    assert np.array_equal(hp.d_stream.download((hp.n_cells, 4)), c.advice()[: hp.n_cells])
+    assert np.array_equal(hp.d_lookup.download((hp.n_lookup, 4)), c.lookup()[: hp.n_lookup])
+    assert np.array_equal(flags & 1, c.selectors().astype(np.uint8)[: hp.n_cells] & 1)
+
+
+def test_distances_example_proves_with_its_three_public_distances(api, O):
+    """examples/distances.rs on data/distances.in (k and LOOKUP_BITS of the README's command line): [a | b | euclidean | manhattan |
+    cosine] is the oracle's context up to where its Hamming distance starts; the three distances are the proof's instances"""
+    from halo2_vectordb_amd.pipeline import DistancesHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    from oracle import pairing as PR
+    d, cfg = E.load("distances"), E.README["distances"]
+    r = E.oracle_distances(O)
+    hp = DistancesHotPath(dim=len(d["a"]), k=cfg["k"], L=cfg["L"], tau=TAU, vectors=np.array([d["a"], d["b"]], dtype=np.float64)).setup()
+    pr = None
+    try:
+        assert hp.n_cells == r["offsets"][("hamming", 3)][0] and hp.n_lookup == r["offsets"][("hamming", 3)][1]
+        _same_stream(hp, r["ctx"], O)
+        want = [r["results"][(m, i)] for i, m in enumerate(("euclidean", "manhattan", "cosine"))]
+        assert np.array_equal(hp.results(), np.stack(want))
+        for m, got in zip(hp.metrics, api.dequantize(hp.results())):
+            f = E.F64[m](d["a"], d["b"])
+            assert abs(float(got) - f) <= 1e-6 * max(abs(f), 1.0)              # assert_float_relative_eq! of tests/distances_test.rs
+        pr = ProverRounds(hp).keygen()
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        assert len(pr.instance_cells) == 3
+        out = pr.prove(None, seed=3)
+        assert out["instances"] == O.fr_to_ints(np.stack(want))
+        assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
+        for i in range(3):                                                    # another distance than the circuit computed
+            other = list(out["instances"])
+            other[i] = (other[i] + 1) % O.R_MOD
+            assert not _verify(O, api, out["proof"], {**vk, "instances": other})
+        # other vectors under the same key
+        rng = np.random.default_rng(9)
+        v = rng.random((2, hp.dim))
+        hp.set_vectors(v)
+        out2 = pr.prove(None)
+        assert _verify(O, api, out2["proof"], {**vk, "instances": out2["instances"]}) and out2["instances"] != out["instances"]
+        assert not _verify(O, api, out2["proof"], {**vk, "instances": out["instances"]})
+        got = api.dequantize(hp.results())
+        for m, g in zip(hp.metrics, got):
+            f = E.F64[m](list(v[0]), list(v[1]))
+            assert abs(float(g) - f) <= 1e-6 * max(abs(f), 1.0)
+    finally:
+        if pr is not None:
+            pr.free()
+        hp.free()
+
+
+def test_c1_euclid_proves(api, O):
+    """BASELINE configs[0] — one Euclidean distance of two 4-dim vectors, k = 13, LOOKUP_BITS = 12 — beyond its Mock stage
+    (tests/test_gpu_mock.py): keygen, proof, verifier; and examples/euclid.rs's ten distances of one pair with nothing public"""
+    from halo2_vectordb_amd.pipeline import DistancesHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    rng = np.random.default_rng(1)
+    v = rng.random((2, 4))
+    hp = DistancesHotPath(dim=4, metrics=("euclidean",), k=13, L=12, tau=TAU, vectors=v).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.keygen_report.violations() == 0
+        assert hp.n_adv_cols == 3 and hp.n_lk_cols == 1                       # 21.2 k / 3.4 k cells at L = 12
+        out = pr.prove(None)
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert len(out["instances"]) == 1 and _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
+        f = float(np.linalg.norm(v[0] - v[1]))
+        assert abs(float(api.dequantize(hp.results())[0]) - f) <= 1e-6 * max(f, 1.0)
+    finally:
+        pr.free()
+        hp.free()
+    d = E.load("euclid")
+    r = E.oracle_distances(O, "euclid")
+    hp = DistancesHotPath(dim=len(d["a"]), metrics=("euclidean",) * 10, k=13, L=12, tau=TAU, vectors=np.array([d["a"], d["b"]], dtype=np.float64), public=False).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert hp.n_cells == len(r["ctx"])
+        _same_stream(hp, r["ctx"], O)
+        assert pr.keygen_report.violations() == 0 and pr.instance_cells == []
+        out = pr.prove(None)
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert out["instances"] == [] and _verify(O, api, out["proof"], {**vk, "instances": []})
+        assert E.rel_close(api.dequantize(hp.results()), [E.f64_euclidean(d["a"], d["b"])] * 10)
+    finally:
+        pr.free()
+        hp.free()

@@ -81,7 +81,7 @@ def balanced_column_shards(var_adv, var_lk, world, msm_share=0.22):
     return list(zip(adv, lk))
 
 
-SET_COLS = 3   # columns per product polynomial of the permutation argument (rounds.CHUNK_LEN): block boundaries fall on sets
+SET_COLS = 2   # columns per product polynomial of the permutation argument (rounds.CHUNK_LEN): block boundaries fall on sets
 
 
 def align_column_shards(shards, n_adv, n_lk, chunk=SET_COLS):

@@ -33,8 +33,14 @@ from .pipeline import N_BLIND
 B = 32
 DERIVED = ("hf",)   # opened polynomials whose evaluation is not in the proof: the verifier computes it (h folded at x, from the quotient identity)
 FIXED = ("sel", "sigma", "cst", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
-EXT_K = 2        # extended domain 4n: constraint degree 5 [UPSTREAM-RECALL halo2-base: 4 advice rotations x selector]
-CHUNK_LEN = 3    # permutation columns per product polynomial = degree - 2
+# The constraint system's degree, halo2 ConstraintSystem::degree() [UPSTREAM-RECALL; SURVEY App. C.4 / C.5]: the maximum of the
+# permutation argument's required degree (3), the lookup argument's (max(4, 2 + input degree + table degree) = 4: halo2-base's "lookup wo
+# selector" reads one lookup-advice column against the table column, both of degree 1) and the gates' (the vertical gate
+# q (a + b c - d): 3) = 4.  Everything below follows from it the way halo2 derives it.
+MAX_DEGREE = 4
+EXT_K = 2                    # extended domain 2^(k + ceil(log2(degree - 1))) = 4 n
+CHUNK_LEN = MAX_DEGREE - 2   # permutation columns per product polynomial (permutation::Argument: chunk_len = cs.degree() - 2)
+N_H = MAX_DEGREE - 1         # pieces of the quotient (quotient_poly_degree: extended_to_coeff truncates to n (degree - 1) coefficients)
 GATE_EXT_K = 1   # the vertical gate q (a + b c - d) has degree 3: its share of the quotient is determined on the coset of 2 n points
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
@@ -1070,7 +1076,7 @@ class ProverRounds:
             check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
             comm.sum_field_dev(d_h.ptr, ne)                      # every rank's share of h (nothing to do on one rank)
         stage("quotient", quotient)
-        n_h = 1 << EXT_K                                      # h(X) = sum_i X^(n i) h_i(X)
+        n_h = N_H                                             # h(X) = sum_i X^(n i) h_i(X): degree below (MAX_DEGREE - 1) n, the top quarter of the 4 n coefficients is zero
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)), replicated=True)
         write_points(polys["h"].commits)
         squeeze("x")

@@ -126,18 +126,18 @@ def test_aligned_shards_and_the_shard_map_tile_columns_and_sets():
         for world in (1, 2, 3, 4, 8):
             if world > n_adv:
                 continue
-            for balanced in (False, True):
+            for balanced, chunk in ((False, 2), (True, 2), (False, 3), (True, 3)):       # chunk 2: cs.degree() - 2 of the reference's circuits
                 if balanced:
                     shards = balanced_column_shards(rng.integers(0, 65536, n_adv), rng.integers(0, 65536, n_lk), world)
                 else:
                     shards = column_shards(n_adv, n_lk, world)
                 if world > 1:
                     before = shards
-                    shards = align_column_shards(shards, n_adv, n_lk)
+                    shards = align_column_shards(shards, n_adv, n_lk, chunk)
                     for (a0, l0), (a1, l1) in zip(before, shards):
-                        assert abs(a0[1] - a1[1]) <= 2 and (abs(l0[1] - l1[1]) <= 2 or l1[1] in (0, n_lk) or l1[1] == (-n_adv) % 3)
-                m = ShardMap(shards, n_adv, n_lk, 3)
-                assert m.n_perm == n_adv + n_lk + 2 and m.n_sets == -(-m.n_perm // 3)
+                        assert abs(a0[1] - a1[1]) <= 2 and (abs(l0[1] - l1[1]) <= 2 or l1[1] in (0, n_lk) or l1[1] == (-n_adv) % chunk)
+                m = ShardMap(shards, n_adv, n_lk, chunk)
+                assert m.n_perm == n_adv + n_lk + 2 and m.n_sets == -(-m.n_perm // chunk)
                 sets = sorted(x for r in range(world) for x in m.set_ranges(r))
                 assert sets[0][0] == 0 and sets[-1][1] == m.n_sets and all(a[1] == b[0] for a, b in zip(sets, sets[1:]))
                 held = sorted(p for r in range(world) for lo, hi in m.held_ranges(r) for p in range(lo, hi)) if n_adv < 1000 else None

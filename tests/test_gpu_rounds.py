@@ -163,7 +163,9 @@ def test_round_outputs_have_the_expected_shape(circuit, proved):
     ch, out, timings = proved
     assert pr.n_adv >= 2 and pr.n_lk >= 1
     c = out["commitments"]
-    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (4, 8) and c["rand"].shape == (1, 8) and c["hf"].shape == (1, 8) and c["pa"].shape == (pr.n_lk, 8)
+    from halo2_vectordb_amd.rounds import CHUNK_LEN
+    assert CHUNK_LEN == 2            # cs.degree() = 4 for the vertical gate + single-column lookups (d - 2 = 2)
+    assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (CHUNK_LEN + 1, 8) and c["rand"].shape == (1, 8) and c["hf"].shape == (1, 8) and c["pa"].shape == (pr.n_lk, 8)
     assert len(out["openings"]) == 6 and out["proof"] is None
     for name in ("witness", "commit_msm", "ntt", "lookup_permute", "products", "quotient", "evaluations", "openings"):
         assert timings[name] > 0
@@ -239,7 +241,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "rand": 1, "hf": 0}          # (hf: opened, but its evaluation is not sent)
     n_evals = sum(counts[name] for names in opened.values() for name in names)
-    n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 1 + 4 + len(opened)
+    n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 1 + (meta["chunk_len"] + 1) + len(opened)
     assert len(proof) == 32 * (n_points + n_evals)
 
     # ---- the verifier
@@ -268,7 +270,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     commitments["zl"] = absorb(take_points(counts["zl"]))
     commitments["rand"] = absorb(take_points(1))                       # the vanishing argument's random polynomial, before y
     ch["y"] = tr.squeeze()
-    commitments["h"] = absorb(take_points(4))
+    commitments["h"] = absorb(take_points(meta["chunk_len"] + 1))      # degree - 1 pieces, chunk_len = degree - 2
     ch["x"] = tr.squeeze()
     evals = {}
     for rot, names in opened.items():
@@ -463,7 +465,7 @@ def _verify(O, api, proof, vk):
         C["zp"], C["zl"] = points(counts["zp"]), points(counts["zl"])
         C["rand"] = points(1)
         ch["y"] = tr.squeeze()
-        C["h"] = points(4)
+        C["h"] = points(meta["chunk_len"] + 1)              # the quotient's degree - 1 pieces (chunk_len = degree - 2)
         ch["x"] = tr.squeeze()
         evals = {}
         for rot, names in opened.items():
@@ -563,9 +565,10 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
         rep = verify_file.main(os.path.join(d, "kmeans.snark"))
         assert rep["accepted"] and not rep["tampered_byte_accepted"] and rep["columns"] == pr.n_cols
     assert proof_f == proof and _verify(O, api, proof_f, {**vk, "instances": inst_f})
-    n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 1 + 4
+    n_h = vk["meta"]["chunk_len"] + 1
+    n_points = vk["meta"]["n_cols"] + 3 * vk["meta"]["n_lk"] + vk["meta"]["n_sets"] + 1 + n_h
     # a commitment, the random polynomial, h, an evaluation, the last evaluation (the random polynomial's), W1, W2
-    for where in (5, 32 * (n_points - 5) + 3, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 96 + 9, len(proof) - 64 + 7, len(proof) - 20):
+    for where in (5, 32 * (n_points - n_h - 1) + 3, 32 * (n_points - 1) + 3, 32 * n_points + 40, len(proof) - 96 + 9, len(proof) - 64 + 7, len(proof) - 20):
         bad = bytearray(proof)
         bad[where] ^= 4
         assert not _verify(O, api, bytes(bad), vk)

@@ -99,6 +99,10 @@ _SIGNATURES = {
     "vdb_poly_lincomb_dev": [_P, _SZ, _SZ, _P, _P], "vdb_kate_div_dev": [_P, _SZ, _SZ, _P, _P, _P],
     "vdb_permutation_eval_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_eval_range_dev": [_P, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _SZ],
+    "vdb_coeff_to_cosets_dev": [_P, _P, _SZ, _U32, _U32, _P], "vdb_cosets_to_coeff_dev": [_P, _P, _U32, _U32],
+    "vdb_gate_eval_cosets_dev": [_P, _U32, _P, _SZ, _U32, _U32, _P, _P],
+    "vdb_lookup_eval_cosets_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],
+    "vdb_permutation_eval_parts_cosets_dev": [_P, _SZ, _P, _P, _SZ, _P, _P, _SZ, _SZ, _U32, _U32, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _I, _SZ, _SZ, _SZ, _SZ],
     "vdb_lookup_eval_dev": [_P, _P, _P, _P, _P, _SZ, _U32, _U32, _P, _P, _P, _P, _P, _P, _P],
     "vdb_permutation_product_dev": [_P, _P, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_permutation_product_range_dev": [_P, _P, _SZ, _SZ, _U32, _SZ, _SZ, _P, _P, _P, _P], "vdb_permutation_chain_dev": [_P, _SZ, _U32, _SZ],

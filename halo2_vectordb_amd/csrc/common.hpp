@@ -42,8 +42,9 @@ struct Context {
   };
   std::map<TwKey, u256*> twiddles;
   // grow-only scratch buffers
-  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+  static constexpr int N_SCRATCH = 8;
+  void* scratch[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[N_SCRATCH] = {0, 0, 0, 0, 0, 0, 0, 0};
   // device-resident caches owned by other translation units; released through their hooks in vdb_shutdown
   std::map<uint64_t, void*> fp_tables;   // witness.hip: FixedPointChip tables keyed by (P, L)
   void* poseidon_spec = nullptr;          // poseidon.hip: device copy of the Poseidon spec
@@ -157,9 +158,11 @@ struct ProfScope {
 u256 host_root_of_unity(uint32_t k);  // ROOT_OF_UNITY^(2^(28-k)), Montgomery
 u256 host_zeta();                     // halo2curves bn256 Fr::ZETA, Montgomery
 u256 host_fr_from_u64(uint64_t v);
+u256 host_coset_shift(uint32_t k, uint32_t t);  // g_t = zeta w_{4n}^(bitrev2(t)): the shift of slot t of the extended domain taken coset by coset (ntt.hip)
 
 // internal device-level entry points shared between translation units (all on ctx().stream)
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale = nullptr);
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale = nullptr,
+            const u256* const* in_tabs = nullptr, uint32_t vslots = 0);
 
 }  // namespace vdb

@@ -223,7 +223,7 @@ static void shutdown_context(int device) {
   c.msm_out = nullptr;
   for (auto& kv : c.twiddles) (void)hipFree(kv.second);
   c.twiddles.clear();
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < Context::N_SCRATCH; i++) {
     if (c.scratch[i]) (void)hipFree(c.scratch[i]);
     c.scratch[i] = nullptr;
     c.scratch_bytes[i] = 0;
@@ -337,7 +337,7 @@ int vdb_scratch_release(void) {
   VDB_ARG(!c.msm_pending, "a deferred MSM is still open (vdb_msm_batch_end)");
   VDB_HIP(hipStreamSynchronize(c.stream));
   VDB_HIP(hipStreamSynchronize(c.aux));
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < Context::N_SCRATCH; i++) {
     if (c.scratch[i]) VDB_HIP(hipFree(c.scratch[i]));
     c.scratch[i] = nullptr;
     c.scratch_bytes[i] = 0;

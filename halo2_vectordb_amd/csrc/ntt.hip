@@ -33,7 +33,10 @@ struct NttPass {
   uint32_t nprev;                 // last pass: number of previous passes
   uint32_t prevS[NTT_MAX_PASSES]; // their sizes (S_0 .. S_{L-2})
   uint32_t first;                 // this is pass 0 (input staging rules apply)
-  uint32_t coset;                 // 1: multiply input element e by zeta^(e mod 3); 2: by s zeta^(e mod 3) for a scalar s (zeta0 = 32 s)
+  uint32_t coset;                 // 1: multiply input element e by zeta^(e mod 3); 2: by s zeta^(e mod 3) for a scalar s (zeta0 = 32 s);
+                                  // 3: by in_tab[slot][e] (32 g^e for the coset shift g of the column's slot: vdb_coeff_to_cosets_dev)
+  uint32_t vslots;                // > 0: the launch's columns are virtual — column c transforms input column c / vslots for slot c % vslots
+  const u256* in_tab[4];          // coset == 3: the slots' tables of input factors (n entries each)
   uint32_t coset_out;             // last pass: multiply output element e by zeta^-(e mod 3) (extended_to_coeff)
   uint32_t scale;                 // multiply output by n^{-1}
   uint32_t s0;                    // first butterfly stage to run (2 when the top three quarters of every row are zero padding)
@@ -144,7 +147,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     col = grp * p.col_group + r % ncg;
     tile = r / ncg;
   }
-  const u256* cin = in + (size_t)col * p.in_stride;
+  const u256* cin = in + (size_t)((p.first && p.vslots) ? col / p.vslots : col) * p.in_stride;
+  const u256* ctab = nullptr;
+  if (p.first && p.coset == 3) {
+    const uint32_t slot = col % p.vslots;
+    ctab = slot == 0 ? p.in_tab[0] : (slot == 1 ? p.in_tab[1] : (slot == 2 ? p.in_tab[2] : p.in_tab[3]));
+  }
   ColSrc csrc;
   const bool from_src = p.first && p.srcs != nullptr;
   if (from_src) csrc = p.srcs[col];
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   // it into the other three quarters.
   const uint32_t mload = m >> p.s0, Tload = mload * G;
   L9 Z0, Z1, Z2;
-  if (p.coset) {
+  if (p.coset && p.coset != 3) {
     Z1 = l9_split(p.zeta1);
     Z2 = l9_split(p.zeta2);
     if (p.coset == 2) Z0 = l9_split(p.zeta0);
@@ -211,7 +219,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     L9 v;
     if (!p.first || idx < p.in_len) {
       v = l9_split(from_src ? colsrc_fetch(csrc, idx, 1ull << p.log_n, p.n_blind) : ld256(cin + idx));
-      if (p.coset) {
+      if (p.coset == 3) {
+        v = l9_mul(v, l9_split(ld256(ctab + idx)));
+      } else if (p.coset) {
         uint32_t r3 = (uint32_t)(idx % 3);
         if (r3 == 1) v = l9_mul(v, Z1);
         else if (r3 == 2) v = l9_mul(v, Z2);
@@ -525,7 +535,10 @@ static const uint32_t* get_shoup_table(uint32_t log_n, const u256& omega, uint32
 // Plans and runs the passes.  data: n_cols columns (stride in_len when in_len != 0, else n);
 // result goes to out (stride n) or back into data when out == nullptr.
 int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const u256& omega, bool scale_ninv,
-            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale) {
+            bool coset_in, size_t in_len, const ColSrc* srcs, uint32_t n_blind, bool coset_out, const u256* in_scale, const u256* const* in_tabs,
+            uint32_t vslots) {
+  // `in_tabs` / `vslots`: n_cols counts virtual columns — column c is input column c / vslots multiplied element by element by
+  // in_tabs[c % vslots] (the cosets of one polynomial, one after the other in the output)
   Context& c = ctx();
   if (n_cols == 0) return VDB_OK;
   if (log_n > 26) {
@@ -538,6 +551,10 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
   u256* dst = out_or_null ? out_or_null : data;
   if (!out_or_null && in_stride != n) {
     set_error("ntt: in-place transform needs in_len == n");
+    return VDB_ERR_ARG;
+  }
+  if (vslots && (!out_or_null || !in_tabs || vslots > 4 || srcs || coset_in || n_cols % vslots)) {
+    set_error("ntt: virtual columns need an output buffer and their input tables");
     return VDB_ERR_ARG;
   }
   if (srcs && (!out_or_null || in_len != n || log_n <= 10)) {
@@ -590,6 +607,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     size_t max_cols = ((size_t)2 << 30) / (n * sizeof(u256));
     if (max_cols < 1) max_cols = 1;
     if (chunk_cols > max_cols) chunk_cols = max_cols;
+    if (vslots) chunk_cols = chunk_cols / vslots * vslots ? chunk_cols / vslots * vslots : vslots;
     scratch = (u256*)scratch_get(3, chunk_cols * n * sizeof(u256));
     if (!scratch) return VDB_ERR_OOM;
   }
@@ -606,7 +624,9 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       p.log_inner = log_n - done_bits - S[l];
       p.first = (l == 0);
       const bool last = (l == L - 1);
-      p.coset = (l == 0 && coset_in) ? (in_scale ? 2u : 1u) : 0u;
+      p.coset = (l == 0 && coset_in) ? (in_scale ? 2u : 1u) : ((l == 0 && vslots) ? 3u : 0u);
+      p.vslots = vslots;
+      for (uint32_t t = 0; t < vslots; t++) p.in_tab[t] = in_tabs[t];
       p.zeta0 = z0;
       p.in_len = in_len;
       p.srcs = (l == 0 && srcs) ? srcs + c0 : nullptr;
@@ -663,7 +683,7 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
       const u256* src;
       u256* out;
       if (l == 0) {
-        src = srcs ? scratch : data + c0 * in_stride;  // with column sources `in` is not read
+        src = srcs ? scratch : data + (vslots ? c0 / vslots : c0) * in_stride;  // with column sources `in` is not read
         p.in_stride = in_stride;
       } else {
         src = scratch;
@@ -735,6 +755,35 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
     }
   }
   return VDB_OK;
+}
+
+// out[j][i] = sum_t C[j][t] * tab_t[i] * P[t][i]: the pieces of a polynomial of degree below n_slots n from its residues modulo
+// X^n - u_t (what an inverse transform of its values on the coset g_t H gives, once coefficient i is divided by g_t^i)
+struct CosetMix {
+  const u256* tab[4];  // g_t^-i, Montgomery
+  u256 c[4][4];
+};
+__global__ __launch_bounds__(256) void k_cosets_combine(const u256* __restrict__ P, uint64_t n, uint32_t n_slots, CosetMix mx, u256* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 v[4];
+#pragma unroll
+  for (uint32_t t = 0; t < 4; t++)
+    if (t < n_slots) v[t] = fr_mul(ld256(P + t * n + i), ld256(mx.tab[t] + i));
+#pragma unroll
+  for (uint32_t j = 0; j < 4; j++) {
+    if (j >= n_slots) break;
+    u256 acc = fr_mul(v[0], mx.c[j][0]);
+#pragma unroll
+    for (uint32_t t = 1; t < 4; t++)
+      if (t < n_slots) acc = fr_add(acc, fr_mul(v[t], mx.c[j][t]));
+    st256(out + j * n + i, acc);
+  }
+}
+
+u256 host_coset_shift(uint32_t k, uint32_t t) {
+  static const uint32_t rev[4] = {0, 2, 1, 3};
+  return fr_mul(host_zeta(), mont_pow<Fr>(host_root_of_unity(k + 2), u256_from_u64(rev[t & 3])));
 }
 
 static int host_cols_roundtrip(vdb_fr* const* cols, size_t n_cols, size_t n, u256** dbuf, bool upload) {
@@ -816,6 +865,89 @@ int vdb_extended_to_coeff_dev(vdb_fr* ext_dev, size_t n_cols, uint32_t k, uint32
   VDB_ARG(ext_dev && k + ext_k <= 26, "bad argument");
   u256 w = mont_inv<Fr>(host_root_of_unity(k + ext_k));
   return ntt_dev(as_u256(ext_dev), nullptr, n_cols, k + ext_k, w, true, false, 0, nullptr, 0, true, nullptr);
+}
+// The cosets of the extended domain one by one ("slots"): slot t of a column is the polynomial on g_t H, H the 2^k-th roots of unity,
+// g_t = zeta w_{4n}^(bitrev2(t)) — g_0 = zeta, g_1 = zeta w_{2n}, g_2 = zeta w_{4n}, g_3 = zeta w_{4n}^3: together the 4 n points of
+// coeff_to_extended (slot t, row r = point 4 r + bitrev2(t) of the natural order), the first two the coset of 2 n points.  A quotient of
+// degree below 3 n is determined on three of them, one of degree below 2 n on two: a quarter / a half of the transform is not made at all.
+int vdb_coeff_to_cosets_dev(const vdb_fr* coeff_dev, vdb_fr* cosets_dev, size_t n_cols, uint32_t k, uint32_t n_slots, const vdb_fr* scale_or_null) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(coeff_dev && cosets_dev && k + 2 <= 26 && n_slots >= 1 && n_slots <= 4, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  Context& c = ctx();
+  const uint64_t n = 1ull << k;
+  const u256 m32 = host_fr_from_u64(32);
+  const u256* tabs[4] = {nullptr, nullptr, nullptr, nullptr};
+  int err = VDB_OK;
+  if (scale_or_null) {
+    // s p(X) on the cosets: the scalar rides on the input factors — tables of this call alone
+    u256 sv;
+    memcpy(&sv, scale_or_null, 32);
+    u256* buf = (u256*)scratch_get(6, (size_t)n_slots * n * sizeof(u256));
+    if (!buf) return VDB_ERR_OOM;
+    const uint32_t chunk = 16;
+    const uint64_t threads = (n + chunk - 1) / chunk;
+    for (uint32_t t = 0; t < n_slots; t++) {
+      hipLaunchKernelGGL(k_twiddles, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, buf + t * n, host_coset_shift(k, t), fr_mul(m32, sv), n, chunk);
+      tabs[t] = buf + t * n;
+    }
+    VDB_LAUNCH_CHECK();
+  } else {
+    for (uint32_t t = 0; t < n_slots; t++) {
+      tabs[t] = get_twiddles(k, host_coset_shift(k, t), m32, false, &err);
+      if (!tabs[t]) return err;
+    }
+  }
+  return ntt_dev(const_cast<u256*>(as_u256(coeff_dev)), as_u256(cosets_dev), n_cols * n_slots, k, host_root_of_unity(k), false, false, 0, nullptr, 0, false, nullptr,
+                 tabs, n_slots);
+}
+// The way back for ONE polynomial, the quotient: `cosets_dev` holds the numerator's values on the first n_slots cosets ([slot][row];
+// overwritten); they are divided by X^n - 1 (a constant per coset), brought back to the residues modulo X^n - g_t^n, and the n_slots
+// pieces h_0 .. of n coefficients each of h = sum_j X^(n j) h_j — a polynomial of degree below n_slots n, which is what the caller
+// asserts — are solved from the Vandermonde system in u_t = g_t^n (h mod (X^n - u_t) = sum_j u_t^j h_j).
+int vdb_cosets_to_coeff_dev(vdb_fr* cosets_dev, vdb_fr* coeff_dev, uint32_t k, uint32_t n_slots) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(cosets_dev && coeff_dev && k + 2 <= 26 && n_slots >= 1 && n_slots <= 4, "bad argument");
+  Context& c = ctx();
+  const uint64_t n = 1ull << k;
+  int rc = ntt_dev(as_u256(cosets_dev), nullptr, n_slots, k, mont_inv<Fr>(host_root_of_unity(k)), true, false, 0, nullptr, 0, false, nullptr);
+  if (rc) return rc;
+  CosetMix mx;
+  memset(&mx, 0, sizeof(mx));
+  u256 u[4];
+  const u256 one = mont_one<Fr>();
+  int err = VDB_OK;
+  for (uint32_t t = 0; t < n_slots; t++) {
+    const u256 g = host_coset_shift(k, t);
+    // (tables of plain powers: cached under the base g^-1, which no transform uses as its root)
+    mx.tab[t] = get_twiddles(k, mont_inv<Fr>(g), one, false, &err);
+    if (!mx.tab[t]) return err;
+    u[t] = g;
+    for (uint32_t i = 0; i < k; i++) u[t] = fr_mul(u[t], u[t]);
+  }
+  // column t of the inverse Vandermonde matrix = the coefficients of the Lagrange polynomial L_t over the nodes u; times 1 / (u_t - 1)
+  for (uint32_t t = 0; t < n_slots; t++) {
+    u256 poly[5] = {one, u256_zero(), u256_zero(), u256_zero(), u256_zero()};  // prod_{s != t} (X - u_s)
+    uint32_t deg = 0;
+    u256 den = fr_sub(u[t], one);                                               // (u_t - 1) prod_{s != t} (u_t - u_s)
+    for (uint32_t s2 = 0; s2 < n_slots; s2++) {
+      if (s2 == t) continue;
+      for (int d = (int)deg + 1; d >= 0; d--) {
+        u256 lower = d > 0 ? poly[d - 1] : u256_zero();
+        poly[d] = fr_sub(lower, d <= (int)deg ? fr_mul(poly[d], u[s2]) : u256_zero());
+      }
+      deg++;
+      den = fr_mul(den, fr_sub(u[t], u[s2]));
+    }
+    const u256 inv = mont_inv<Fr>(den);
+    for (uint32_t j = 0; j < n_slots; j++) mx.c[j][t] = fr_mul(poly[j], inv);
+  }
+  {
+    VDB_PROF("k_cosets_combine");
+    hipLaunchKernelGGL(k_cosets_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, as_u256(cosets_dev), n, n_slots, mx, as_u256(coeff_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
 }
 int vdb_coeff_to_extended(const vdb_fr* const* coeff_cols, vdb_fr* const* ext_cols, size_t n_cols, uint32_t k, uint32_t ext_k) {
   VDB_REQUIRE_INIT();

@@ -299,16 +299,23 @@ struct GateK {
 };
 // `sub` > 0: the advice cosets live on 2^(log_ne + sub) points and the gate is evaluated on every 2^sub-th of them — the gate
 // has degree 3, so its share of the quotient is determined on the coset of 2 n points inside the 4 n the permutation needs.
+// Coset by coset ("slots", vdb_coeff_to_cosets_dev): blockIdx.y is the slot, every array is offset by slot * ne, and the column strides
+// (adv_cs, sel_cs: slots per column * ne) are no longer the number of points; a caller of the natural-order layout passes adv_cs = ne_a,
+// sel_cs = ne and one slot.
 __global__ __launch_bounds__(256) void k_gate_eval(const u256* __restrict__ adv, const u256* __restrict__ sel, uint64_t n_cols, uint32_t log_ne, uint32_t e,
-                                                   uint32_t sub, u256 y32 /* 32 y */, GateK gk, u256* __restrict__ acc) {
+                                                   uint32_t sub, uint64_t adv_cs, uint64_t sel_cs, u256 y32 /* 32 y */, GateK gk, u256* __restrict__ acc) {
   const uint64_t ne = 1ull << log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
   const uint64_t ne_a = ne << sub, mask = ne_a - 1, r = 1ull << (e + sub), ja = j << sub;
+  const uint64_t so = (uint64_t)blockIdx.y * ne;
+  adv += so;
+  sel += so;
+  acc += so;
   const L9 Y = l9_split(y32);
   L9 h = l9_split(ld256(acc + j));
   for (uint64_t c = 0; c < n_cols; c++) {
-    const u256* a = adv + c * ne_a;
-    const L9 q32 = l9_split32(ld256(sel + c * ne + j));
+    const u256* a = adv + c * adv_cs;
+    const L9 q32 = l9_split32(ld256(sel + c * sel_cs + j));
     const L9 bc = l9_mul<Fr>(l9_split(ld256(a + ((ja + r) & mask))), l9_split32(ld256(a + ((ja + 2 * r) & mask))));
     const L9 g = l9_sub(l9_add(l9_split(ld256(a + ja)), bc), l9_split(ld256(a + ((ja + 3 * r) & mask))), gk.c2);
     h = l9_mul2<Fr>(h, Y, g, q32);
@@ -440,6 +447,7 @@ struct QuotArgs {
   const u256 *l0, *l_last, *l_active;
   u256 beta, gamma, delta, y;  // scaled: 32 * value
   uint32_t log_ne, e;
+  uint64_t cs;        // column stride of the coset arrays: ne in the natural-order layout, slots per column * ne coset by coset (blockIdx.y = slot)
   uint64_t last_rot;  // rows between the last usable row and the end: n - usable_rows
   uint32_t c9[9], c34[9];
 };
@@ -460,14 +468,21 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
                                                    PermParts pp, u256* __restrict__ acc) {
   const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
-  const uint64_t mask = ne - 1, r = 1ull << q.e;
+  const uint64_t mask = ne - 1, r = 1ull << q.e, cs = q.cs, so = (uint64_t)blockIdx.y * ne;
   const uint64_t n_sets = (n_cols + chunk_len - 1) / chunk_len;
   const L9 Y = l9_split(q.y), B = l9_split(q.beta), G = l9_split(q.gamma), D = l9_split(q.delta);
-  const L9 L0 = l9_split32(ld256(q.l0 + j)), LL = l9_split32(ld256(q.l_last + j)), LA = l9_split32(ld256(q.l_active + j));
+  const L9 L0 = l9_split32(ld256(q.l0 + so + j)), LL = l9_split32(ld256(q.l_last + so + j)), LA = l9_split32(ld256(q.l_active + so + j));
+  acc += so;
+  bx += so;
+  sigma += so;
+  pp.z_first += so;
+  pp.z_last += so;
   L9 h = l9_split32(ld256(acc + j));
   (void)n_sets;
-  z -= pp.z_set0 * ne;          // index by global set number from here on (only sets the caller provides are touched)
-  adv -= pp.adv_col0 * ne;
+  z += so;
+  adv += so;
+  z -= pp.z_set0 * cs;          // index by global set number from here on (only sets the caller provides are touched)
+  adv -= pp.adv_col0 * cs;
   if (pp.head & 1) {
     // l0 (1 - z_0)
     h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(mont_one<Fr>()), l9_split32(ld256(pp.z_first + j)), q.c34), L0);
@@ -481,19 +496,19 @@ __global__ __launch_bounds__(256) void k_perm_eval(const u256* __restrict__ adv,
     // l0 (z_i - z_{i-1}(w^-(blinding+1) X)): every set starts where the one before ended
     const uint64_t jb = (j + ne - ((q.last_rot << q.e) & mask)) & mask;
     for (uint64_t i = pp.chain_lo; i < pp.chain_hi; i++)
-      h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(ld256(z + i * ne + j)), l9_split32(ld256(z + (i - 1) * ne + jb)), q.c34), L0);
+      h = l9_mul2<Fr>(h, Y, l9_sub(l9_split32(ld256(z + i * cs + j)), l9_split32(ld256(z + (i - 1) * cs + jb)), q.c34), L0);
   }
   // l_active (z_i(w X) prod (v + beta sigma + gamma) - z_i(X) prod (v + delta^c beta X + gamma))
   L9 cur = l9_mul<Fr>(l9_split32(ld256(bx + j)), l9_split(dstart));
   const uint64_t cb = set_lo * chunk_len;  // first column of the sigma block
   for (uint64_t i = set_lo; i < set_hi; i++) {
     const uint64_t c0 = i * chunk_len, c1 = c0 + chunk_len < n_cols ? c0 + chunk_len : n_cols;
-    L9 left = l9_split32(ld256(z + i * ne + ((j + r) & mask))), right = l9_split32(ld256(z + i * ne + j));
+    L9 left = l9_split32(ld256(z + i * cs + ((j + r) & mask))), right = l9_split32(ld256(z + i * cs + j));
     for (uint64_t c = c0; c < c1; c++) {
-      const L9 v = l9_add(l9_split32(ld256(adv + c * ne + j)), G);
+      const L9 v = l9_add(l9_split32(ld256(adv + c * cs + j)), G);
       // (beta sigma: one product per column and extended row, unless the caller extended beta sigma(X) in the first place —
       //  vdb_coeff_to_extended_scaled_dev: the scalar then costs a third of a product per BASE row)
-      const L9 sg = l9_split32(ld256(sigma + (c - cb) * ne + j));
+      const L9 sg = l9_split32(ld256(sigma + (c - cb) * cs + j));
       left = l9_mul<Fr>(l9_add(v, (pp.head & 2) ? sg : l9_mul<Fr>(sg, B)), left);
       right = l9_mul<Fr>(l9_add(v, cur), right);
       cur = l9_mul<Fr>(cur, D);
@@ -507,15 +522,21 @@ __global__ __launch_bounds__(256) void k_lookup_eval(const u256* __restrict__ a,
                                                      u256* __restrict__ acc) {
   const uint64_t ne = 1ull << q.log_ne, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ne) return;
-  const uint64_t mask = ne - 1, r = 1ull << q.e;
+  const uint64_t mask = ne - 1, r = 1ull << q.e, so = (uint64_t)blockIdx.y * ne;
   const L9 Y = l9_split(q.y), B = l9_split(q.beta);
-  const L9 L0 = l9_split32(ld256(q.l0 + j)), LL = l9_split32(ld256(q.l_last + j)), LA = l9_split32(ld256(q.l_active + j));
+  const L9 L0 = l9_split32(ld256(q.l0 + so + j)), LL = l9_split32(ld256(q.l_last + so + j)), LA = l9_split32(ld256(q.l_active + so + j));
   const L9 ONE = l9_split32(mont_one<Fr>());
+  a += so;
+  tab += so;
+  pa += so;
+  pt += so;
+  z += so;
+  acc += so;
   // second factors of a product must be normalised: sums that serve as one are made in memory form first
   const L9 sg = l9_split32(fr_add(ld256(tab + j), gamma_m));
   L9 h = l9_split32(ld256(acc + j));
   for (uint64_t c = 0; c < n_cols; c++) {
-    const uint64_t o = c * ne;
+    const uint64_t o = c * q.cs;
     const L9 zc = l9_split32(ld256(z + o + j)), zn = l9_split32(ld256(z + o + ((j + r) & mask)));
     const u256 pav_m = ld256(pa + o + j), ptv_m = ld256(pt + o + j);
     const L9 av = l9_split32(ld256(a + o + j)), pav = l9_split32(pav_m), ptv = l9_split32(ptv_m);
@@ -698,7 +719,26 @@ int vdb_gate_eval_sub_dev(const vdb_fr* adv_ext_dev, uint32_t adv_ext_k, const v
     GateK gk;
     l9_offset_limbs<FrParams>(2, gk.c2);
     hipLaunchKernelGGL(k_gate_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(adv_ext_dev), as_u256(sel_ext_dev), (uint64_t)n_cols,
-                     k + ext_k, ext_k, adv_ext_k - ext_k, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
+                     k + ext_k, ext_k, adv_ext_k - ext_k, ne << (adv_ext_k - ext_k), ne, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
+  }
+  VDB_LAUNCH_CHECK();
+  return VDB_OK;
+}
+// the gates coset by coset: advice cosets [column][adv_slots][row], selector cosets and accumulator [..][n_slots][row]; slots 0 .. n_slots - 1
+int vdb_gate_eval_cosets_dev(const vdb_fr* adv_cosets_dev, uint32_t adv_slots, const vdb_fr* sel_cosets_dev, size_t n_cols, uint32_t k, uint32_t n_slots,
+                             const vdb_fr* y, vdb_fr* acc_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(adv_cosets_dev && sel_cosets_dev && y && acc_dev && n_slots >= 1 && n_slots <= adv_slots && adv_slots <= 4 && k <= 26, "bad argument");
+  if (n_cols == 0) return VDB_OK;
+  u256 yv;
+  memcpy(&yv, y, 32);
+  const uint64_t n = 1ull << k;
+  {
+    VDB_PROF("k_gate_eval");
+    GateK gk;
+    l9_offset_limbs<FrParams>(2, gk.c2);
+    hipLaunchKernelGGL(k_gate_eval, dim3((unsigned)((n + 255) / 256), n_slots), dim3(256), 0, ctx().stream, as_u256(adv_cosets_dev), as_u256(sel_cosets_dev),
+                     (uint64_t)n_cols, k, 0u, 0u, (uint64_t)adv_slots * n, (uint64_t)n_slots * n, fr_mul(yv, host_fr_from_u64(32)), gk, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();
   return VDB_OK;
@@ -942,8 +982,10 @@ int vdb_lookup_product_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, con
   return product_columns(num, den, n_cols, n, usable_rows, as_u256(z_dev));
 }
 
+// `n_slots` > 0: coset by coset — every array is [column][n_slots][row] and the kernels run once per slot (blockIdx.y) on 2^k points
+// with rotations by one; 0: the natural order of the 2^(k + ext_k) points, rotations by 2^ext_k
 static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const vdb_fr* l_active, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta,
-                     const vdb_fr* y, uint32_t k, uint32_t ext_k, size_t usable_rows) {
+                     const vdb_fr* y, uint32_t k, uint32_t ext_k, size_t usable_rows, uint32_t n_slots = 0) {
   q.l0 = as_u256(l0);
   q.l_last = as_u256(l_last);
   q.l_active = as_u256(l_active);
@@ -960,8 +1002,9 @@ static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const 
   q.y = fr_mul(t, m32);
   l9_offset_limbs<FrParams>(9, q.c9);
   l9_offset_limbs<FrParams>(34, q.c34);
-  q.log_ne = k + ext_k;
-  q.e = ext_k;
+  q.log_ne = n_slots ? k : k + ext_k;
+  q.e = n_slots ? 0 : ext_k;
+  q.cs = n_slots ? (uint64_t)n_slots << k : 1ull << (k + ext_k);
   q.last_rot = (1ull << k) - usable_rows;
   return VDB_OK;
 }
@@ -969,7 +1012,7 @@ static int quot_args(QuotArgs& q, const vdb_fr* l0, const vdb_fr* l_last, const 
 static int permutation_eval_parts(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
                                   uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
                                   const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
-                                  size_t set_lo, size_t set_hi, PermParts pp);
+                                  size_t set_lo, size_t set_hi, PermParts pp, uint32_t n_slots = 0);
 int vdb_permutation_eval_range_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
                                    uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
                                    const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
@@ -996,10 +1039,24 @@ int vdb_permutation_eval_parts_dev(const vdb_fr* adv_ext_block_dev, size_t adv_c
                                 z_ext_block_dev ? z_ext_block_dev : acc_dev, n_cols, chunk_len, k, ext_k, usable_rows, l0_ext_dev, l_last_ext_dev,
                                 l_active_ext_dev, beta, gamma, delta, y, acc_dev, set_lo, set_hi, pp);
 }
+// the same coset by coset (vdb_coeff_to_cosets_dev): every array [column][n_slots][row], the accumulator and the Lagrange selectors [n_slots][row]
+int vdb_permutation_eval_parts_cosets_dev(const vdb_fr* adv_block_dev, size_t adv_col0, const vdb_fr* sigma_block_dev, const vdb_fr* z_block_dev, size_t z_set0,
+                                          const vdb_fr* z_first_dev, const vdb_fr* z_last_dev, size_t n_cols, size_t chunk_len, uint32_t k, uint32_t n_slots,
+                                          size_t usable_rows, const vdb_fr* l0_dev, const vdb_fr* l_last_dev, const vdb_fr* l_active_dev, const vdb_fr* beta,
+                                          const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev, int head, size_t chain_lo, size_t chain_hi,
+                                          size_t set_lo, size_t set_hi) {
+  VDB_ARG(n_slots >= 1 && n_slots <= 4, "bad argument");
+  VDB_ARG(!(head & 1) || (z_first_dev && z_last_dev), "the head terms read the first and the last product coset");
+  VDB_ARG(chain_lo >= chain_hi || (chain_lo >= 1 && chain_lo - 1 >= z_set0), "the chaining term of set i reads set i - 1");
+  VDB_ARG(set_lo >= set_hi || (set_lo >= z_set0 && set_lo * chunk_len >= adv_col0), "the block buffers start after the first set asked for");
+  PermParts pp{adv_col0, z_set0, chain_lo, chain_hi, as_u256(z_first_dev), as_u256(z_last_dev), head};
+  return permutation_eval_parts(adv_block_dev ? adv_block_dev : acc_dev, sigma_block_dev ? sigma_block_dev : acc_dev, z_block_dev ? z_block_dev : acc_dev, n_cols,
+                                chunk_len, k, 2, usable_rows, l0_dev, l_last_dev, l_active_dev, beta, gamma, delta, y, acc_dev, set_lo, set_hi, pp, n_slots);
+}
 static int permutation_eval_parts(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_block_dev, const vdb_fr* z_ext_dev, size_t n_cols, size_t chunk_len,
                                   uint32_t k, uint32_t ext_k, size_t usable_rows, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
                                   const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* delta, const vdb_fr* y, vdb_fr* acc_dev,
-                                  size_t set_lo, size_t set_hi, PermParts pp) {
+                                  size_t set_lo, size_t set_hi, PermParts pp, uint32_t n_slots) {
   VDB_REQUIRE_INIT();
   VDB_ARG(adv_ext_dev && sigma_ext_block_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta && gamma && delta && y && acc_dev,
           "null pointer");
@@ -1008,22 +1065,26 @@ static int permutation_eval_parts(const vdb_fr* adv_ext_dev, const vdb_fr* sigma
   VDB_ARG(set_lo <= set_hi && set_hi <= (n_cols + chunk_len - 1) / chunk_len, "bad set range");
   Context& cx = ctx();
   QuotArgs q;
-  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, delta, y, k, ext_k, usable_rows);
-  const uint64_t ne = 1ull << (k + ext_k);
-  u256* bx = (u256*)scratch_get(5, ne * sizeof(u256));
+  VDB_ARG(n_slots <= 4 && (n_slots == 0 || ext_k == 2), "bad argument");
+  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, delta, y, k, ext_k, usable_rows, n_slots);
+  const uint64_t ne = 1ull << q.log_ne;     // points per launch row: the whole domain, or one coset of it
+  const uint32_t ny = n_slots ? n_slots : 1;
+  u256* bx = (u256*)scratch_get(5, ny * ne * sizeof(u256));
   if (!bx) return VDB_ERR_OOM;
   u256 beta_m, delta_m;
   memcpy(&beta_m, beta, 32);
   memcpy(&delta_m, delta, 32);
-  hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(k + ext_k), fr_mul(beta_m, host_zeta()), ne,
-                     bx);
+  // bx = beta X on the points: beta zeta w^j in the natural order; beta g_t w_n^r on slot t
+  for (uint32_t t = 0; t < ny; t++)
+    hipLaunchKernelGGL(k_beta_omega_powers, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, host_root_of_unity(q.log_ne),
+                       fr_mul(beta_m, n_slots ? host_coset_shift(k, t) : host_zeta()), ne, bx + t * ne);
   {
     VDB_PROF("k_perm_eval");
     u256 e = u256_zero();
     const uint64_t pw = (uint64_t)set_lo * chunk_len;
     e.w[0] = (uint32_t)pw;
     e.w[1] = (uint32_t)(pw >> 32);
-    hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_block_dev),
+    hipLaunchKernelGGL(k_perm_eval, dim3((unsigned)((ne + 255) / 256), ny), dim3(256), 0, cx.stream, as_u256(adv_ext_dev), as_u256(sigma_ext_block_dev),
                        as_u256(z_ext_dev), (uint64_t)n_cols, (uint32_t)chunk_len, (uint64_t)set_lo, (uint64_t)set_hi, bx,
                        fr_mul(mont_pow<Fr>(delta_m, e), host_fr_from_u64(32)), q, pp, as_u256(acc_dev));
   }
@@ -1037,9 +1098,25 @@ int vdb_permutation_eval_dev(const vdb_fr* adv_ext_dev, const vdb_fr* sigma_ext_
                                         beta, gamma, delta, y, acc_dev, 0, chunk_len ? (n_cols + chunk_len - 1) / chunk_len : 0);
 }
 
+static int lookup_eval(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev, const vdb_fr* perm_input_ext_dev, const vdb_fr* perm_table_ext_dev,
+                       const vdb_fr* z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                       const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* y, vdb_fr* acc_dev, uint32_t n_slots);
 int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev, const vdb_fr* perm_input_ext_dev, const vdb_fr* perm_table_ext_dev,
                         const vdb_fr* z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
                         const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* y, vdb_fr* acc_dev) {
+  return lookup_eval(input_ext_dev, table_ext_dev, perm_input_ext_dev, perm_table_ext_dev, z_ext_dev, n_cols, k, ext_k, l0_ext_dev, l_last_ext_dev, l_active_ext_dev,
+                     beta, gamma, y, acc_dev, 0);
+}
+// coset by coset: every array [column][n_slots][row]
+int vdb_lookup_eval_cosets_dev(const vdb_fr* input_dev, const vdb_fr* table_dev, const vdb_fr* perm_input_dev, const vdb_fr* perm_table_dev, const vdb_fr* z_dev,
+                               size_t n_cols, uint32_t k, uint32_t n_slots, const vdb_fr* l0_dev, const vdb_fr* l_last_dev, const vdb_fr* l_active_dev,
+                               const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* y, vdb_fr* acc_dev) {
+  VDB_ARG(n_slots >= 1 && n_slots <= 4, "bad argument");
+  return lookup_eval(input_dev, table_dev, perm_input_dev, perm_table_dev, z_dev, n_cols, k, 2, l0_dev, l_last_dev, l_active_dev, beta, gamma, y, acc_dev, n_slots);
+}
+static int lookup_eval(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev, const vdb_fr* perm_input_ext_dev, const vdb_fr* perm_table_ext_dev,
+                       const vdb_fr* z_ext_dev, size_t n_cols, uint32_t k, uint32_t ext_k, const vdb_fr* l0_ext_dev, const vdb_fr* l_last_ext_dev,
+                       const vdb_fr* l_active_ext_dev, const vdb_fr* beta, const vdb_fr* gamma, const vdb_fr* y, vdb_fr* acc_dev, uint32_t n_slots) {
   VDB_REQUIRE_INIT();
   VDB_ARG(input_ext_dev && table_ext_dev && perm_input_ext_dev && perm_table_ext_dev && z_ext_dev && l0_ext_dev && l_last_ext_dev && l_active_ext_dev && beta &&
               gamma && y && acc_dev,
@@ -1047,14 +1124,14 @@ int vdb_lookup_eval_dev(const vdb_fr* input_ext_dev, const vdb_fr* table_ext_dev
   VDB_ARG(k + ext_k <= 28, "bad argument");
   if (n_cols == 0) return VDB_OK;
   QuotArgs q;
-  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, nullptr, y, k, ext_k, 0);
+  quot_args(q, l0_ext_dev, l_last_ext_dev, l_active_ext_dev, beta, gamma, nullptr, y, k, ext_k, 0, n_slots);
   u256 beta_m, gamma_m;
   memcpy(&beta_m, beta, 32);
   memcpy(&gamma_m, gamma, 32);
-  const uint64_t ne = 1ull << (k + ext_k);
+  const uint64_t ne = 1ull << q.log_ne;
   {
     VDB_PROF("k_lookup_eval");
-    hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
+    hipLaunchKernelGGL(k_lookup_eval, dim3((unsigned)((ne + 255) / 256), n_slots ? n_slots : 1), dim3(256), 0, ctx().stream, as_u256(input_ext_dev), as_u256(table_ext_dev),
                        as_u256(perm_input_ext_dev), as_u256(perm_table_ext_dev), as_u256(z_ext_dev), (uint64_t)n_cols, q, beta_m, gamma_m, as_u256(acc_dev));
   }
   VDB_LAUNCH_CHECK();

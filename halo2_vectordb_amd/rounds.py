@@ -41,7 +41,12 @@ MAX_DEGREE = 4
 EXT_K = 2                    # extended domain 2^(k + ceil(log2(degree - 1))) = 4 n
 CHUNK_LEN = MAX_DEGREE - 2   # permutation columns per product polynomial (permutation::Argument: chunk_len = cs.degree() - 2)
 N_H = MAX_DEGREE - 1         # pieces of the quotient (quotient_poly_degree: extended_to_coeff truncates to n (degree - 1) coefficients)
-GATE_EXT_K = 1   # the vertical gate q (a + b c - d) has degree 3: its share of the quotient is determined on the coset of 2 n points
+# halo2 evaluates the numerator on all 4 n points of the extended domain; the quotient has degree below N_H n = 3 n, so its values on
+# three of the four cosets of the 2^k-th roots of unity determine it, and the gates' share (degree 3: below 2 n) on two.  The rounds
+# work coset by coset ("slots", vdb_coeff_to_cosets_dev: arrays [column][slot][row]) and never make the fourth: a quarter of every
+# extended transform and of every evaluation kernel is not run, and the quotient that comes out is the same polynomial.
+N_SLOTS = N_H                # cosets the permutation / lookup terms are evaluated on
+GATE_SLOTS = 2               # cosets the gate terms are evaluated on (slots 0, 1 = the coset of 2 n points)
 BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
@@ -134,7 +139,7 @@ class ProverRounds:
         self.comm = comm if comm is not None else LocalComm()
         self.rank, self.world = hp.rank, hp.world
         assert (self.comm.rank, self.comm.world) == (self.rank, self.world), "the hot path's shard and the communicator disagree"
-        self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows << EXT_K
+        self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows * N_SLOTS      # ne: points per column of a coset array
         self.usable = hp.rows - N_BLIND
         self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
         self.n_perm = self.n_cols + 2                # the permutation argument's columns: advice, lookup, the constants' fixed column, the instance column
@@ -203,7 +208,7 @@ class ProverRounds:
 
     def _to_ext(self, coeff_buf, n_cols):
         e = api.DeviceBuffer(max(n_cols, 1) * self.ne * B)
-        check(self.lib.vdb_coeff_to_extended_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, EXT_K))
+        check(self.lib.vdb_coeff_to_cosets_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, N_SLOTS, None))
         return e
 
     def _srs_for(self, n_cols, basis, dense):
@@ -553,7 +558,7 @@ class ProverRounds:
         self.d_ez = api.DeviceBuffer((blk // CHUNK_LEN + 1) * self.ne * B)
         self.d_zf, self.d_zlast = api.DeviceBuffer(self.ne * B), api.DeviceBuffer(self.ne * B)
         self.d_h, self.d_h2, self.d_h3, self.d_h4 = (api.DeviceBuffer(self.ne * B) for _ in range(4))
-        self.d_hg = api.DeviceBuffer((rows << GATE_EXT_K) * B)      # the gates' accumulator, on the coset of 2 n points
+        self.d_hg = api.DeviceBuffer(GATE_SLOTS * rows * B)         # the gates' accumulator, on the coset of 2 n points
         self.d_comb, self.d_quot = api.DeviceBuffer(rows * B), api.DeviceBuffer(rows * B)
         # the instance column: Lagrange form (the public values in rows 0 .. n_instances - 1, zero below), coefficients, coset —
         # made anew for every proof from the values of the statement
@@ -743,13 +748,15 @@ class ProverRounds:
                 inst_host[:ni] = given
                 check(lib.vdb_memcpy_h2d(self.d_inst_lag.ptr, api._p(inst_host), _sz(ni * B)))
         # (the transforms of the advice columns are still running when step returns: the commitments are absorbed meanwhile)
-        adv_local = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=resident, sync=False, after_witness=public_values).copy()
+        adv_local = hp.step(timings, blind_seed=None if seed is None else [int(seed), 0], with_ext=False, sync=False, after_witness=public_values).copy()
+        if resident:        # the cosets of all my columns at once, into the hot path's coset buffer (three of the four it is sized for)
+            stage("ntt", lambda: check(lib.vdb_coeff_to_cosets_dev(hp.d_cols.ptr, hp.d_ext.ptr, _sz(my_cols), k, N_SLOTS, None)))
         adv_commits = self._globalize(adv_local, self.adv_ranges, n_cols)
         instances = [inst_host[i].copy() for i in range(ni)]
         # the instance polynomial in the forms the rounds read (one column: queued behind the advice transforms)
         check(lib.vdb_memcpy_d2d(self.d_inst_coeff.ptr, self.d_inst_lag.ptr, _sz(rows * B)))
         check(lib.vdb_lagrange_to_coeff_dev(self.d_inst_coeff.ptr, _sz(1), k))
-        check(lib.vdb_coeff_to_extended_dev(self.d_inst_coeff.ptr, self.d_inst_ext.ptr, _sz(1), k, EXT_K))
+        check(lib.vdb_coeff_to_cosets_dev(self.d_inst_coeff.ptr, self.d_inst_ext.ptr, _sz(1), k, N_SLOTS, None))
         if resident:
             check(lib.vdb_memcpy_d2d(hp.d_ext.at((my_cols + 1) * ne * B), self.d_inst_ext.ptr, _sz(ne * B)))
         if tr is not None and ni:
@@ -820,9 +827,9 @@ class ProverRounds:
                     if resident:
                         check(lib.vdb_memcpy_d2d(to, hp.d_ext.at(self._col_local(c) * ne * B), _sz(m * ne * B)))
                     else:
-                        check(lib.vdb_coeff_to_extended_dev(hp.d_cols.at(self._col_local(c) * rows * B), to, _sz(m), k, EXT_K))
+                        check(lib.vdb_coeff_to_cosets_dev(hp.d_cols.at(self._col_local(c) * rows * B), to, _sz(m), k, N_SLOTS, None))
                 elif kind == "foreign":
-                    check(lib.vdb_coeff_to_extended_dev(self.d_foreign_coeff.at(foreign_slot[c] * rows * B), to, _sz(m), k, EXT_K))
+                    check(lib.vdb_coeff_to_cosets_dev(self.d_foreign_coeff.at(foreign_slot[c] * rows * B), to, _sz(m), k, N_SLOTS, None))
                 else:
                     check(lib.vdb_memcpy_d2d(to, (fx["cst"].ext if kind == "cst" else self.d_inst_ext).ptr, _sz(ne * B)))
             return d_ea.ptr, c0
@@ -977,7 +984,7 @@ class ProverRounds:
         l0, ll, la = (ctypes.c_void_p(fx["lag"].ext.ptr.value + i * ne * B) for i in range(3))
 
         def to_ext(coeff_ptr, dest_ptr, m):
-            check(lib.vdb_coeff_to_extended_dev(coeff_ptr, dest_ptr, _sz(m), k, EXT_K))
+            check(lib.vdb_coeff_to_cosets_dev(coeff_ptr, dest_ptr, _sz(m), k, N_SLOTS, None))
 
         def quotient():
             # The numerator is sum_i term_i y^(N-1-i) over the terms in halo2's order: gates (one per advice column),
@@ -987,25 +994,26 @@ class ProverRounds:
             # cosets (unless resident), selectors, sigma, product and lookup-argument cosets — and the groups are joined at the end:
             # h = ((Ag y^n2 + A2) y^n3 + A3) y^n4 + A4.  (The public inputs have no term of their own: the instance column is one
             # of the permutation's columns.)
-            # The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on the
-            # coset of 2 n points inside the 4 n (every second point of the advice cosets; the selector cosets are made for 2 n
-            # points only: half the transform), divided and brought back to coefficients there, and joined in coefficient form.
+            # Everything is evaluated coset by coset on N_SLOTS = 3 of the extended domain's four cosets (the quotient has degree below
+            # 3 n).  The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on
+            # two of them (slots 0 and 1 of the advice cosets; the selector cosets are made for those two only), brought back to
+            # coefficients from there, and joined in coefficient form.
             # Sharded: a rank folds the terms of its own columns and sets (the folds skip what other ranks hold: _Fold); every step
             # after that — the joins, the division by X^n - 1, the way back to coefficients — is linear, so each rank ends with a
             # share of h's coefficients and the shares are added (the one bulk exchange of the proof: 2^(k+2) x 32 B per rank).
             ag, a2, a3, a4 = self.d_hg, self.d_h2, self.d_h3, self.d_h4
             for a in (a2, a3, a4):
                 check(lib.vdb_memset_dev(a.ptr, 0, _sz(ne * B)))
-            check(lib.vdb_memset_dev(ag.ptr, 0, _sz((rows << GATE_EXT_K) * B)))
+            check(lib.vdb_memset_dev(ag.ptr, 0, _sz(GATE_SLOTS * rows * B)))
             n2, n3, n4 = 2 + (n_sets - 1), n_sets, 5 * n_lk
-            f_g, f_2, f_3, f_4 = _Fold(ag, rows << GATE_EXT_K, "y", n_adv), _Fold(a2, ne, "y", n2), _Fold(a3, ne, "y", n3), _Fold(a4, ne, "y", n4)
-            perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, EXT_K, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
+            f_g, f_2, f_3, f_4 = _Fold(ag, GATE_SLOTS * rows, "y", n_adv), _Fold(a2, ne, "y", n2), _Fold(a3, ne, "y", n3), _Fold(a4, ne, "y", n4)
+            perm_args = (_sz(n_perm), _sz(CHUNK_LEN), k, N_SLOTS, _sz(usable), l0, ll, la, p["beta"], p["gamma"], api._p(self.delta), p["y"])
             # l0 (1 - z_0), l_last (z_last^2 - z_last): the first two terms of group 2, folded in by the owner of the last set
             if self.map.head_owner() == rank:
                 to_ext(z_coeff(0), d_zf.ptr, 1)
                 to_ext(z_coeff(n_sets - 1), d_zlast.ptr, 1)
                 f_2.skip_to(0, 2)
-                check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
+                check(lib.vdb_permutation_eval_parts_cosets_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
             third = blk // 3
             sigma_scaled = os.environ.get("VDB_SIGMA_SCALED", "1") != "0"      # (0: the A/B baseline — sigma's own cosets, the product by beta per point)
 
@@ -1018,8 +1026,8 @@ class ProverRounds:
                     to_ext(polys["ps"].coeff.at((j0 - l_lo) * rows * B), d_eb.at(third * ne * B), m)
                     to_ext(polys["zl"].coeff.at((j0 - l_lo) * rows * B), d_eb.at(2 * third * ne * B), m)
                     f_4.skip_to(5 * j0, 5 * m)
-                    check(lib.vdb_lookup_eval_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
-                                                  _sz(m), k, EXT_K, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
+                    check(lib.vdb_lookup_eval_cosets_dev(col_ptr(base, col0, n_adv + j0), fx["table"].ext.ptr, d_eb.ptr, d_eb.at(third * ne * B), d_eb.at(2 * third * ne * B),
+                                                         _sz(m), k, N_SLOTS, l0, ll, la, p["beta"], p["gamma"], p["y"], a4.ptr))
             # my lookup columns that complete another rank's set (the head of the lookup columns, at the advice / lookup junction):
             # their lookup argument is mine all the same, and comes first in the order of the terms
             stray_lk = sorted(c for c in self.stray if c >= n_adv)
@@ -1035,15 +1043,15 @@ class ProverRounds:
                     base, col0 = adv_ext_block(c0, nb)
                     g0, g1 = max(c0, a_lo), min(c0 + nb, a_hi)
                     if g0 < g1:                                            # gates of the block's advice columns
-                        check(lib.vdb_coeff_to_extended_dev(fx["sel"].coeff.at((g0 - a_lo) * rows * B), d_eb.ptr, _sz(g1 - g0), k, GATE_EXT_K))
+                        check(lib.vdb_coeff_to_cosets_dev(fx["sel"].coeff.at((g0 - a_lo) * rows * B), d_eb.ptr, _sz(g1 - g0), k, GATE_SLOTS, None))
                         f_g.skip_to(g0, g1 - g0)
-                        check(lib.vdb_gate_eval_sub_dev(col_ptr(base, col0, g0), EXT_K, d_eb.ptr, _sz(g1 - g0), k, GATE_EXT_K, p["y"], ag.ptr))
+                        check(lib.vdb_gate_eval_cosets_dev(col_ptr(base, col0, g0), N_SLOTS, d_eb.ptr, _sz(g1 - g0), k, GATE_SLOTS, p["y"], ag.ptr))
                     # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
                     set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
                     z0 = max(set_lo - 1, 0)
                     # (the cosets of beta sigma: the scalar rides on the transform's coset factors, the evaluation skips a product per point)
                     if sigma_scaled:
-                        check(lib.vdb_coeff_to_extended_scaled_dev(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, _sz(nb), k, EXT_K, p["beta"]))
+                        check(lib.vdb_coeff_to_cosets_dev(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, _sz(nb), k, N_SLOTS, p["beta"]))
                     else:
                         to_ext(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, nb)
                     if z0 < set_lo and (z0 in z_slot or z0 < s_lo):          # the set in front is another rank's (or another range's)
@@ -1053,10 +1061,10 @@ class ProverRounds:
                         to_ext(z_coeff(z0), d_ez.ptr, set_hi - z0)
                     if max(set_lo, 1) < set_hi:
                         f_2.skip_to(max(set_lo, 1) + 1, set_hi - max(set_lo, 1))
-                        check(lib.vdb_permutation_eval_parts_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
+                        check(lib.vdb_permutation_eval_parts_cosets_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
                                                                  _sz(0), _sz(0)))
                     f_3.skip_to(set_lo, set_hi - set_lo)
-                    check(lib.vdb_permutation_eval_parts_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 2 if sigma_scaled else 0, _sz(0), _sz(0), _sz(set_lo),
+                    check(lib.vdb_permutation_eval_parts_cosets_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 2 if sigma_scaled else 0, _sz(0), _sz(0), _sz(set_lo),
                                                              _sz(set_hi)))
                     # lookup argument of the block's lookup columns that are mine
                     j_lo, j_hi = max(c0 - n_adv, l_lo), min(c0 + nb - n_adv, l_hi)
@@ -1067,13 +1075,11 @@ class ProverRounds:
             y_int = _fr_to_int(ch["y"])
             check(lib.vdb_poly_axpy_dev(a3.ptr, api._p(_fr_from_int(pow(y_int, n3, R_MOD))), a2.ptr, _sz(ne)))
             check(lib.vdb_poly_axpy_dev(a4.ptr, api._p(_fr_from_int(pow(y_int, n4, R_MOD))), a3.ptr, _sz(ne)))
-            check(lib.vdb_memcpy_d2d(d_h.ptr, a4.ptr, _sz(ne * B)))
-            check(lib.vdb_divide_by_vanishing_dev(d_h.ptr, k, EXT_K))
-            check(lib.vdb_extended_to_coeff_dev(d_h.ptr, _sz(1), k, EXT_K))
-            # the gates' share: the same on the 2 n points, then h += y^(every later term) * (its 2 n coefficients)
-            check(lib.vdb_divide_by_vanishing_dev(ag.ptr, k, GATE_EXT_K))
-            check(lib.vdb_extended_to_coeff_dev(ag.ptr, _sz(1), k, GATE_EXT_K))
-            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), ag.ptr, _sz(rows << GATE_EXT_K)))
+            # (division by X^n - 1 — a constant per coset —, residues modulo X^n - g_t^n, the Vandermonde system in g_t^n: N_H pieces)
+            check(lib.vdb_cosets_to_coeff_dev(a4.ptr, d_h.ptr, k, N_SLOTS))
+            # the gates' share: the same from its two cosets, then h += y^(every later term) * (its 2 n coefficients)
+            check(lib.vdb_cosets_to_coeff_dev(ag.ptr, a2.ptr, k, GATE_SLOTS))
+            check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), a2.ptr, _sz(GATE_SLOTS * rows)))
             comm.sum_field_dev(d_h.ptr, ne)                      # every rank's share of h (nothing to do on one rank)
         stage("quotient", quotient)
         n_h = N_H                                             # h(X) = sum_i X^(n i) h_i(X): degree below (MAX_DEGREE - 1) n, the top quarter of the 4 n coefficients is zero

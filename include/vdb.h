@@ -401,6 +401,34 @@ int vdb_gate_eval_sub_dev(const vdb_fr *adv_ext_dev, uint32_t adv_ext_k, const v
                           const vdb_fr *y, vdb_fr *acc_dev);
 /* EvaluationDomain::divide_by_vanishing_poly: h[j] /= (X^n - 1) at the j-th point of the extended coset, in place. */
 int vdb_divide_by_vanishing_dev(vdb_fr *h_ext_dev, uint32_t k, uint32_t ext_k);
+/* ---- The extended domain coset by coset (round 3).  halo2 evaluates the quotient's numerator on all 2^(k+2) points of the extended
+ *      domain (EvaluationDomain::coeff_to_extended, reached from src/scaffold/mod.rs:296) although the quotient of the reference's
+ *      circuits has degree below 3 n (constraint degree 4: three pieces) and the gates' share degree below 2 n: three of the four
+ *      cosets g_t H of the 2^k-th roots of unity H determine it, two the gates' share.  "Slot" t of a polynomial is its image on
+ *      g_t H, g_t = zeta w_{4n}^(bitrev2(t)): slot t, row r is point 4 r + bitrev2(t) of vdb_coeff_to_extended_dev's output, slots
+ *      0 and 1 together the coset of 2 n points.  Arrays are [column][slot][row]; a rotation by one row is one step inside a slot.
+ *      The quotient that comes out is the same polynomial, coefficient for coefficient.
+ * vdb_coeff_to_cosets_dev: n_slots (1..4) cosets of each of n_cols polynomials of 2^k coefficients, times *scale_or_null if given
+ *      (the scalar rides on the transform's input factors); one 2^k-point transform per slot instead of a 2^(k+2)-point one.
+ * vdb_cosets_to_coeff_dev: the way back for ONE polynomial and the division by the vanishing polynomial in one: cosets_dev
+ *      ([n_slots][2^k], overwritten) holds numerator values; coeff_dev receives the n_slots pieces of 2^k coefficients of
+ *      numerator / (X^n - 1), which the caller asserts to have degree below n_slots 2^k (residues modulo X^n - g_t^n, then the
+ *      Vandermonde system in g_t^n).
+ * vdb_gate_eval_cosets_dev / vdb_lookup_eval_cosets_dev / vdb_permutation_eval_parts_cosets_dev: vdb_gate_eval_sub_dev /
+ *      vdb_lookup_eval_dev / vdb_permutation_eval_parts_dev on such arrays — n_slots where those take ext_k; the advice cosets of the
+ *      gate call may hold more slots per column (adv_slots) than the selectors' and the accumulator's n_slots. */
+int vdb_coeff_to_cosets_dev(const vdb_fr *coeff_dev, vdb_fr *cosets_dev, size_t n_cols, uint32_t k, uint32_t n_slots, const vdb_fr *scale_or_null);
+int vdb_cosets_to_coeff_dev(vdb_fr *cosets_dev, vdb_fr *coeff_dev, uint32_t k, uint32_t n_slots);
+int vdb_gate_eval_cosets_dev(const vdb_fr *adv_cosets_dev, uint32_t adv_slots, const vdb_fr *sel_cosets_dev, size_t n_cols, uint32_t k, uint32_t n_slots,
+                             const vdb_fr *y, vdb_fr *acc_dev);
+int vdb_lookup_eval_cosets_dev(const vdb_fr *input_dev, const vdb_fr *table_dev, const vdb_fr *perm_input_dev, const vdb_fr *perm_table_dev, const vdb_fr *z_dev,
+                               size_t n_cols, uint32_t k, uint32_t n_slots, const vdb_fr *l0_dev, const vdb_fr *l_last_dev, const vdb_fr *l_active_dev,
+                               const vdb_fr *beta, const vdb_fr *gamma, const vdb_fr *y, vdb_fr *acc_dev);
+int vdb_permutation_eval_parts_cosets_dev(const vdb_fr *adv_block_dev, size_t adv_col0, const vdb_fr *sigma_block_dev, const vdb_fr *z_block_dev, size_t z_set0,
+                                          const vdb_fr *z_first_dev, const vdb_fr *z_last_dev, size_t n_cols, size_t chunk_len, uint32_t k, uint32_t n_slots,
+                                          size_t usable_rows, const vdb_fr *l0_dev, const vdb_fr *l_last_dev, const vdb_fr *l_active_dev, const vdb_fr *beta,
+                                          const vdb_fr *gamma, const vdb_fr *delta, const vdb_fr *y, vdb_fr *acc_dev, int head, size_t chain_lo, size_t chain_hi,
+                                          size_t set_lo, size_t set_hi);
 /* column-layout image of the gate selectors as field elements (keygen side; flags as for vdb_layout_const_mask_dev, bit 0):
  * q_dev: (n_bp + 1) x 2^k, one where a gate starts. */
 int vdb_layout_selectors_dev(const uint8_t *flags_dev, uint64_t n_cells, const uint64_t *break_points, uint64_t n_bp, uint32_t k, vdb_fr *q_dev);

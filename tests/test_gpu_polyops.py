@@ -658,3 +658,163 @@ def test_scaled_coset_extension_and_prescaled_sigma(api, O):
         be.free()
     for b in (d_c, d_e1, d_e2, d_sc, d_sig_b):
         b.free()
+
+
+REV2 = (0, 2, 1, 3)          # slot t of the extended domain taken coset by coset = points 4 r + REV2[t] of the natural order
+
+
+def _to_slots(ext, n_slots):
+    """(cols, 4 n, 4) in natural order -> (cols, n_slots, n, 4) coset by coset"""
+    return np.stack([ext[:, REV2[t]::4] for t in range(n_slots)], axis=1)
+
+
+@pytest.mark.parametrize("k", [3, 9, 10, 11, 12, 16])
+def test_cosets_of_the_extended_domain_one_by_one(api, O, k):
+    """vdb_coeff_to_cosets_dev: slot t, row r == point 4 r + bitrev2(t) of vdb_coeff_to_extended_dev, bit for bit, for 1..4 slots, with
+    and without a scalar (single-pass and multi-pass sizes)"""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    sz = ctypes.c_size_t
+    rng = np.random.default_rng(100 + k)
+    n, ne = 1 << k, 4 << k
+    n_cols = 5 if k <= 12 else 3
+    coeff = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    s = O.random_fr(rng, 1)[0]
+    d_c, d_e, d_s = api.DeviceBuffer(coeff.nbytes), api.DeviceBuffer(n_cols * ne * 32), api.DeviceBuffer(n_cols * ne * 32)
+    d_c.upload(coeff)
+    try:
+        for scale in (None, s):
+            if scale is None:
+                check(lib.vdb_coeff_to_extended_dev(d_c.ptr, d_e.ptr, sz(n_cols), k, 2))
+            else:
+                check(lib.vdb_coeff_to_extended_scaled_dev(d_c.ptr, d_e.ptr, sz(n_cols), k, 2, api._p(scale)))
+            ext = d_e.download((n_cols, ne, 4))
+            for n_slots in (1, 2, 3, 4):
+                check(lib.vdb_memset_dev(d_s.ptr, 0xEE, sz(n_cols * ne * 32)))
+                check(lib.vdb_coeff_to_cosets_dev(d_c.ptr, d_s.ptr, sz(n_cols), k, n_slots, None if scale is None else api._p(scale)))
+                got = d_s.download((n_cols, n_slots, n, 4))
+                assert np.array_equal(got, _to_slots(ext, n_slots)), (k, n_slots, scale is not None)
+        assert lib.vdb_coeff_to_cosets_dev(d_c.ptr, d_s.ptr, sz(n_cols), k, 5, None) == -3
+        check(lib.vdb_coeff_to_cosets_dev(d_c.ptr, d_s.ptr, sz(0), k, 3, None))
+    finally:
+        for b in (d_c, d_e, d_s):
+            b.free()
+
+
+@pytest.mark.parametrize("k,n_slots", [(4, 3), (9, 2), (9, 3), (11, 3), (12, 4), (16, 3)])
+def test_quotient_back_from_its_cosets(api, O, k, n_slots):
+    """vdb_cosets_to_coeff_dev: for a polynomial h of degree below n_slots n, the values of h (X^n - 1) on the first n_slots cosets give
+    back h's pieces exactly — and they are what the 4 n route (divide_by_vanishing + extended_to_coeff) gives"""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    sz = ctypes.c_size_t
+    rng = np.random.default_rng(7 * k + n_slots)
+    n, ne = 1 << k, 4 << k
+    h = np.zeros((ne, 4), dtype=np.uint64)
+    h[: n_slots * n] = O.random_fr(rng, n_slots * n)
+    # the numerator h (X^n - 1) on the extended domain: coeff_to_extended of each piece, joined with (X^n)^j and multiplied point by point
+    pieces = h[: n_slots * n].reshape(n_slots, n, 4)
+    d_p, d_e = api.DeviceBuffer(pieces.nbytes), api.DeviceBuffer(n_slots * ne * 32)
+    d_p.upload(pieces)
+    check(lib.vdb_coeff_to_extended_dev(d_p.ptr, d_e.ptr, sz(n_slots), k, 2))
+    pe = d_e.download((n_slots, ne, 4))
+    R = O.R_MOD
+    zeta = O.fr_to_ints(np.asarray(O.zeta()).reshape(1, 4))[0]
+    w4n = O.fr_to_ints(np.asarray(api.root_of_unity(k + 2)).reshape(1, 4))[0]
+    vals = [O.fr_to_ints(pe[j]) for j in range(n_slots)]
+    xns = [pow(zeta * pow(w4n, c, R) % R, n, R) for c in range(4)]          # X^n depends on the point's coset only
+    out = []
+    for j4 in range(ne):
+        xn = xns[j4 & 3]
+        hv = sum(vals[j][j4] * pow(xn, j, R) for j in range(n_slots)) % R
+        out.append(hv * (xn - 1) % R)
+    num = O.fr_from_ints(out)
+    slots = np.ascontiguousarray(np.stack([num[REV2[t]::4] for t in range(n_slots)]))
+    d_s, d_out, d_n = api.DeviceBuffer(slots.nbytes), api.DeviceBuffer(n_slots * n * 32), api.DeviceBuffer(ne * 32)
+    d_s.upload(slots)
+    check(lib.vdb_cosets_to_coeff_dev(d_s.ptr, d_out.ptr, k, n_slots))
+    got = d_out.download((n_slots, n, 4))
+    assert np.array_equal(got, pieces)
+    d_n.upload(num)
+    check(lib.vdb_divide_by_vanishing_dev(d_n.ptr, k, 2))
+    check(lib.vdb_extended_to_coeff_dev(d_n.ptr, sz(1), k, 2))
+    assert np.array_equal(d_n.download((ne, 4)), h)
+    for b in (d_p, d_e, d_s, d_out, d_n):
+        b.free()
+
+
+def test_quotient_terms_coset_by_coset_are_the_natural_order_ones(api, O):
+    """the permutation, lookup and gate parts of the numerator on arrays laid out coset by coset (three slots; the gates two) against
+    the same kernels on the natural order of the 4 n points: equal accumulators, point for point"""
+    import ctypes
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    sz = ctypes.c_size_t
+    rng = np.random.default_rng(90210)
+    k, chunk = 9, 2
+    n, ne = 1 << k, 4 << k
+    n_cols, n_sets, n_lk = 7, 4, 2
+    usable = n - 7
+    beta, gamma, y = O.random_fr(rng, 3)
+
+    def make(m):
+        c = O.random_fr(rng, m * n).reshape(m, n, 4)
+        bc, be, bs = api.DeviceBuffer(c.nbytes), api.DeviceBuffer(m * ne * 32), api.DeviceBuffer(m * 3 * n * 32)
+        bc.upload(c)
+        check(lib.vdb_coeff_to_extended_dev(bc.ptr, be.ptr, sz(m), k, 2))
+        check(lib.vdb_coeff_to_cosets_dev(bc.ptr, bs.ptr, sz(m), k, 3, None))
+        return bc, be, bs
+    B = {name: make(m) for name, m in (("adv", n_cols), ("sig", n_cols), ("z", n_sets), ("lag", 3), ("tab", 1), ("pa", n_lk), ("ps", n_lk), ("zl", n_lk), ("sel", n_cols))}
+    acc0 = O.random_fr(rng, ne)
+    slots0 = np.ascontiguousarray(np.stack([acc0[REV2[t]::4] for t in range(3)]))
+
+    def lag(which, i):
+        buf = B["lag"][which]
+        return ctypes.c_void_p(buf.ptr.value + i * (ne if which == 1 else 3 * n) * 32)
+    d_a, d_s = api.DeviceBuffer(ne * 32), api.DeviceBuffer(3 * n * 32)
+    try:
+        # permutation: head terms, chaining, product terms in one call each
+        d_a.upload(acc0)
+        d_s.upload(slots0)
+        zl_ptr = lambda which, i: ctypes.c_void_p(B["z"][which].ptr.value + i * (ne if which == 1 else 3 * n) * 32)
+        check(lib.vdb_permutation_eval_parts_dev(B["adv"][1].ptr, sz(0), B["sig"][1].ptr, B["z"][1].ptr, sz(0), zl_ptr(1, 0), zl_ptr(1, n_sets - 1), sz(n_cols), sz(chunk), k, 2,
+                                                 sz(usable), lag(1, 0), lag(1, 1), lag(1, 2), api._p(beta), api._p(gamma), api._p(api.fr_delta()), api._p(y), d_a.ptr, 1,
+                                                 sz(1), sz(n_sets), sz(0), sz(n_sets)))
+        check(lib.vdb_permutation_eval_parts_cosets_dev(B["adv"][2].ptr, sz(0), B["sig"][2].ptr, B["z"][2].ptr, sz(0), zl_ptr(2, 0), zl_ptr(2, n_sets - 1), sz(n_cols), sz(chunk),
+                                                        k, 3, sz(usable), lag(2, 0), lag(2, 1), lag(2, 2), api._p(beta), api._p(gamma), api._p(api.fr_delta()), api._p(y),
+                                                        d_s.ptr, 1, sz(1), sz(n_sets), sz(0), sz(n_sets)))
+        nat, got = d_a.download((ne, 4)), d_s.download((3, n, 4))
+        assert not np.array_equal(nat, acc0)
+        for t in range(3):
+            assert np.array_equal(got[t], nat[REV2[t]::4]), t
+        # lookup argument
+        check(lib.vdb_lookup_eval_dev(B["adv"][1].ptr, B["tab"][1].ptr, B["pa"][1].ptr, B["ps"][1].ptr, B["zl"][1].ptr, sz(n_lk), k, 2, lag(1, 0), lag(1, 1), lag(1, 2),
+                                      api._p(beta), api._p(gamma), api._p(y), d_a.ptr))
+        check(lib.vdb_lookup_eval_cosets_dev(B["adv"][2].ptr, B["tab"][2].ptr, B["pa"][2].ptr, B["ps"][2].ptr, B["zl"][2].ptr, sz(n_lk), k, 3, lag(2, 0), lag(2, 1), lag(2, 2),
+                                             api._p(beta), api._p(gamma), api._p(y), d_s.ptr))
+        nat2, got2 = d_a.download((ne, 4)), d_s.download((3, n, 4))
+        assert not np.array_equal(nat2, nat)
+        for t in range(3):
+            assert np.array_equal(got2[t], nat2[REV2[t]::4]), t
+        # gates: two slots = the coset of 2 n points; selectors made for two slots only
+        d_sel2, d_g, d_gs = api.DeviceBuffer(n_cols * 2 * n * 32), api.DeviceBuffer(2 * n * 32), api.DeviceBuffer(2 * n * 32)
+        d_sel_nat = api.DeviceBuffer(n_cols * 2 * n * 32)
+        check(lib.vdb_coeff_to_cosets_dev(B["sel"][0].ptr, d_sel2.ptr, sz(n_cols), k, 2, None))
+        check(lib.vdb_coeff_to_extended_dev(B["sel"][0].ptr, d_sel_nat.ptr, sz(n_cols), k, 1))
+        g0 = O.random_fr(rng, 2 * n)
+        d_g.upload(g0)
+        d_gs.upload(np.ascontiguousarray(np.stack([g0[0::2], g0[1::2]])))
+        check(lib.vdb_gate_eval_sub_dev(B["adv"][1].ptr, 2, d_sel_nat.ptr, sz(n_cols), k, 1, api._p(y), d_g.ptr))
+        check(lib.vdb_gate_eval_cosets_dev(B["adv"][2].ptr, 3, d_sel2.ptr, sz(n_cols), k, 2, api._p(y), d_gs.ptr))
+        natg, gotg = d_g.download((2 * n, 4)), d_gs.download((2, n, 4))
+        assert np.array_equal(gotg[0], natg[0::2]) and np.array_equal(gotg[1], natg[1::2]) and not np.array_equal(natg, g0)
+        for b in (d_sel2, d_g, d_gs, d_sel_nat):
+            b.free()
+    finally:
+        for bufs in B.values():
+            for b in bufs:
+                b.free()
+        d_a.free()
+        d_s.free()

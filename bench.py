@@ -155,7 +155,7 @@ def cpu_proof_estimate(units, cores, shape):
     """What create_proof costs the CPU port for a circuit of `shape` (cells, n_adv, n_lk, n_sets, n_evals, rows), from the unit
     costs cpu_baseline measured on this host: a count of halo2's steps ([UPSTREAM-RECALL] create_proof: per committed column one
     MSM, one lagrange_to_coeff and one coset transform; per lookup column a sort, two commitments and a grand product; per
-    permutation set a grand product over three columns; the quotient's terms on the 4 n points; one Horner pass per evaluation;
+    permutation set (degree - 2 = 2 columns) a grand product; the quotient's terms on the 4 n points (what halo2 evaluates — the GPU path's three cosets are its own economy); one Horner pass per evaluation;
     SHPLONK's two linear combinations of every polynomial) times those unit costs, work that is parallel over columns divided by
     the cores.  An estimate of the port, kind "port": the reference's Rust prover cannot run here."""
     n, n_adv, n_lk, n_sets = shape["rows"], shape["n_adv"], shape["n_lk"], shape["n_sets"]

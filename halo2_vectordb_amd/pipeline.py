@@ -81,7 +81,13 @@ def balanced_column_shards(var_adv, var_lk, world, msm_share=0.22):
     return list(zip(adv, lk))
 
 
-SET_COLS = 2   # columns per product polynomial of the permutation argument (rounds.CHUNK_LEN): block boundaries fall on sets
+def set_cols(n_lk_cols):
+    """columns per product polynomial of the permutation argument, halo2's chunk_len = cs.degree() - 2 (rounds.constraint_degree: 4 for a
+    circuit with lookup columns, 3 without): block boundaries of a sharded job fall on sets"""
+    return 2 if n_lk_cols else 1
+
+
+SET_COLS = 2
 
 
 def align_column_shards(shards, n_adv, n_lk, chunk=SET_COLS):
@@ -280,7 +286,7 @@ class KmeansHotPath:
             self.msm_entries = (var_adv, var_lk[: self.n_lk_cols])
             self.shards = balanced_column_shards(var_adv, var_lk[: self.n_lk_cols], self.world)
         if self.world > 1:
-            self.shards = align_column_shards(self.shards, self.n_adv_cols, self.n_lk_cols)
+            self.shards = align_column_shards(self.shards, self.n_adv_cols, self.n_lk_cols, set_cols(self.n_lk_cols))
         (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = self.shards[self.rank]
         self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
         self.my_cols = self.my_adv + self.my_lk

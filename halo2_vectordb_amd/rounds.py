@@ -34,20 +34,23 @@ B = 32
 DERIVED = ("hf",)   # opened polynomials whose evaluation is not in the proof: the verifier computes it (h folded at x, from the quotient identity)
 FIXED = ("sel", "sigma", "cst", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
 # The constraint system's degree, halo2 ConstraintSystem::degree() [UPSTREAM-RECALL; SURVEY App. C.4 / C.5]: the maximum of the
-# permutation argument's required degree (3), the lookup argument's (max(4, 2 + input degree + table degree) = 4: halo2-base's "lookup wo
+# permutation argument's required degree (3), the lookup arguments' (max(4, 2 + input degree + table degree) = 4: halo2-base's "lookup wo
 # selector" reads one lookup-advice column against the table column, both of degree 1) and the gates' (the vertical gate
-# q (a + b c - d): 3) = 4.  Everything below follows from it the way halo2 derives it.
-MAX_DEGREE = 4
-EXT_K = 2                    # extended domain 2^(k + ceil(log2(degree - 1))) = 4 n
-CHUNK_LEN = MAX_DEGREE - 2   # permutation columns per product polynomial (permutation::Argument: chunk_len = cs.degree() - 2)
-N_H = MAX_DEGREE - 1         # pieces of the quotient (quotient_poly_degree: extended_to_coeff truncates to n (degree - 1) coefficients)
-# halo2 evaluates the numerator on all 4 n points of the extended domain; the quotient has degree below N_H n = 3 n, so its values on
-# three of the four cosets of the 2^k-th roots of unity determine it, and the gates' share (degree 3: below 2 n) on two.  The rounds
-# work coset by coset ("slots", vdb_coeff_to_cosets_dev: arrays [column][slot][row]) and never make the fourth: a quarter of every
-# extended transform and of every evaluation kernel is not run, and the quotient that comes out is the same polynomial.
-N_SLOTS = N_H                # cosets the permutation / lookup terms are evaluated on
+# q (a + b c - d): 3).  A circuit with lookup columns has degree 4; one without (merkle_commitment alone: the builder's auto-config
+# gives it no lookup-advice column, so RangeConfig creates no lookup argument) degree 3.  Everything below follows from it the way
+# halo2 derives it:
+#   chunk_len = degree - 2   columns per product polynomial of the permutation argument (permutation::Argument)
+#   n_h       = degree - 1   pieces of the quotient (quotient_poly_degree; extended domain 2^(k + ceil(log2(degree - 1))))
+# halo2 evaluates the numerator on every point of the extended domain; the quotient has degree below n_h n, so its values on n_h of the
+# cosets of the 2^k-th roots of unity determine it, and the gates' share (degree 3: below 2 n) on two.  The rounds work coset by coset
+# ("slots", vdb_coeff_to_cosets_dev: arrays [column][slot][row]) on n_slots = n_h of them and never make the rest: with degree 4 a
+# quarter of every extended transform and of every evaluation kernel is not run, and the quotient that comes out is the same polynomial.
+def constraint_degree(n_lookup_columns):
+    return 4 if n_lookup_columns else 3
+
+
 GATE_SLOTS = 2               # cosets the gate terms are evaluated on (slots 0, 1 = the coset of 2 n points)
-BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of CHUNK_LEN; 4.3 GB at 2^16 rows)
+BLOCK_COLS = 510 # fixed-polynomial cosets are produced this many columns at a time (a multiple of every chunk_len; 3.2 GB at 2^16 rows)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
@@ -133,18 +136,21 @@ class ProverRounds:
     def __init__(self, hp, block_cols=BLOCK_COLS, comm=None):
         from .dist import LocalComm
         from .shardmap import ShardMap
-        assert block_cols % CHUNK_LEN == 0
+        self.degree = constraint_degree(hp.n_lk_cols)
+        self.chunk_len, self.n_h = self.degree - 2, self.degree - 1
+        self.n_slots = self.n_h
+        assert block_cols % self.chunk_len == 0
         self.block_cols = block_cols
         self.hp, self.lib = hp, hp.lib
         self.comm = comm if comm is not None else LocalComm()
         self.rank, self.world = hp.rank, hp.world
         assert (self.comm.rank, self.comm.world) == (self.rank, self.world), "the hot path's shard and the communicator disagree"
-        self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows * N_SLOTS      # ne: points per column of a coset array
+        self.k, self.rows, self.ne = hp.k, hp.rows, hp.rows * self.n_slots      # ne: points per column of a coset array
         self.usable = hp.rows - N_BLIND
         self.n_adv, self.n_lk, self.n_cols = hp.n_adv_cols, hp.n_lk_cols, hp.n_cols
         self.n_perm = self.n_cols + 2                # the permutation argument's columns: advice, lookup, the constants' fixed column, the instance column
-        self.n_sets = -(-self.n_perm // CHUNK_LEN)
-        self.map = ShardMap(hp.shards, self.n_adv, self.n_lk, CHUNK_LEN)
+        self.n_sets = -(-self.n_perm // self.chunk_len)
+        self.map = ShardMap(hp.shards, self.n_adv, self.n_lk, self.chunk_len)
         (self.a_lo, self.a_hi), (self.l_lo, self.l_hi) = hp.shards[self.rank]
         self.my_adv, self.my_lk = self.a_hi - self.a_lo, self.l_hi - self.l_lo
         self.set_ranges = self.map.set_ranges(self.rank)                       # the sets whose running products this rank computes
@@ -208,7 +214,7 @@ class ProverRounds:
 
     def _to_ext(self, coeff_buf, n_cols):
         e = api.DeviceBuffer(max(n_cols, 1) * self.ne * B)
-        check(self.lib.vdb_coeff_to_cosets_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, N_SLOTS, None))
+        check(self.lib.vdb_coeff_to_cosets_dev(coeff_buf.ptr, e.ptr, _sz(n_cols), self.k, self.n_slots, None))
         return e
 
     def _srs_for(self, n_cols, basis, dense):
@@ -535,7 +541,7 @@ class ProverRounds:
                 d_flags.free()
 
     def _alloc_working_set(self):
-        lib, rows = self.lib, self.rows
+        lib, rows, CHUNK_LEN = self.lib, self.rows, self.chunk_len
         # The working set of prove(), allocated once (device allocations of tens of GB take seconds): the derived columns
         # [pa | ps | zp | zl] (Lagrange, then coefficient form in place), the lookup columns laid out, and block buffers of
         # `block_cols` columns — two in Lagrange form (the permutation's columns and their sigma columns), two of extended
@@ -577,7 +583,7 @@ class ProverRounds:
         setup the reference's gen_srs uses (a verifier derives [tau]_2 from it; a ceremony SRS would carry the G2 point instead), and
         — when a proof's `opened` map is given — which polynomial is opened at which rotation.  io.read_verifying_key reads it."""
         from .io import write_verifying_key
-        meta = dict(rows=self.rows, k=self.k, n_adv=self.n_adv, n_lk=self.n_lk, n_cols=self.n_cols, n_sets=self.n_sets, chunk_len=CHUNK_LEN,
+        meta = dict(rows=self.rows, k=self.k, n_adv=self.n_adv, n_lk=self.n_lk, n_cols=self.n_cols, n_sets=self.n_sets, chunk_len=self.chunk_len,
                     n_blind=N_BLIND, delta=str(_fr_to_int(self.delta)), n_instances=len(self.instance_cells), tau=str(self.hp.tau),
                     vk_digest=str(_fr_to_int(self.vk_digest())))
         if opened is not None:
@@ -592,7 +598,7 @@ class ProverRounds:
         if self.world > 1:
             raise NotImplementedError("the proving-key file holds the whole key: write it from a one-rank run")
         api.sync()
-        doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, CHUNK_LEN, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
+        doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, self.chunk_len, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
         doc["instance_cells"] = np.asarray(self.instance_cells, dtype=np.int64)
         for name, q in self.fixed.items():
             doc[name + "_coeff"] = q.coeff.download((max(q.n_cols, 1), self.rows, 4))
@@ -608,7 +614,7 @@ class ProverRounds:
             raise NotImplementedError("the proving-key file holds the whole key: load it in a one-rank run")
         with np.load(path, allow_pickle=False) as doc:
             meta = [int(v) for v in doc["meta"]]
-            if meta != [k, self.n_adv, self.n_lk, hp.L, CHUNK_LEN, N_BLIND] or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
+            if meta != [k, self.n_adv, self.n_lk, hp.L, self.chunk_len, N_BLIND] or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
                 raise ValueError("proving key does not describe this circuit (shape or break points differ)")
             self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
             self.srs_few = api.Srs(k, hp.g_monomial, None)
@@ -655,6 +661,7 @@ class ProverRounds:
         Sharded (world > 1, SHPLONK only): every rank calls prove() with the same arguments; each works on its own columns and
         sets and all end with the same proof bytes (see the class docstring and shardmap.py)."""
         hp, lib, rows, k, ne = self.hp, self.lib, self.rows, self.k, self.ne
+        CHUNK_LEN, N_H, N_SLOTS = self.chunk_len, self.n_h, self.n_slots
         comm, world, rank = self.comm, self.world, self.rank
         if world > 1 and multiopen != "shplonk":
             raise ValueError("the sharded rounds open with SHPLONK")
@@ -995,7 +1002,7 @@ class ProverRounds:
             # h = ((Ag y^n2 + A2) y^n3 + A3) y^n4 + A4.  (The public inputs have no term of their own: the instance column is one
             # of the permutation's columns.)
             # Everything is evaluated coset by coset on N_SLOTS = 3 of the extended domain's four cosets (the quotient has degree below
-            # 3 n).  The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on
+            # 3 n; 2 of 2 for a circuit of degree 3).  The gates have degree 3: their share of the quotient, Ag / (X^n - 1), has degree below 2 n, so Ag is evaluated on
             # two of them (slots 0 and 1 of the advice cosets; the selector cosets are made for those two only), brought back to
             # coefficients from there, and joined in coefficient form.
             # Sharded: a rank folds the terms of its own columns and sets (the folds skip what other ranks hold: _Fold); every step
@@ -1082,7 +1089,7 @@ class ProverRounds:
             check(lib.vdb_poly_axpy_dev(d_h.ptr, api._p(_fr_from_int(pow(y_int, n2 + n3 + n4, R_MOD))), a2.ptr, _sz(GATE_SLOTS * rows)))
             comm.sum_field_dev(d_h.ptr, ne)                      # every rank's share of h (nothing to do on one rank)
         stage("quotient", quotient)
-        n_h = N_H                                             # h(X) = sum_i X^(n i) h_i(X): degree below (MAX_DEGREE - 1) n, the top quarter of the 4 n coefficients is zero
+        n_h = N_H                                             # h(X) = sum_i X^(n i) h_i(X), degree below (degree - 1) n
         polys["h"] = _Poly("h", n_h, coeff=d_h, commits=stage("commit_h", lambda: self._commit(d_h, n_h, 0)), replicated=True)
         write_points(polys["h"].commits)
         squeeze("x")
@@ -1429,7 +1436,7 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     cur = b * x % R
     for i in range(n_sets):
         left, right = z1[i], z0[i]
-        for c in range(i * CHUNK_LEN, min((i + 1) * CHUNK_LEN, n_cols)):
+        for c in range(i * pr.chunk_len, min((i + 1) * pr.chunk_len, n_cols)):
             left = left * (pcols[c] + b * sg[c] + g) % R
             right = right * (pcols[c] + cur + g) % R
             cur = cur * delta % R

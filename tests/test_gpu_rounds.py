@@ -152,9 +152,9 @@ def check_openings(O, v_int, commitments, evals, openings):
 
 
 def _meta(pr):
-    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND
+    from halo2_vectordb_amd.rounds import N_BLIND
     import halo2_vectordb_amd.rounds as rounds
-    return dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=CHUNK_LEN, n_blind=N_BLIND,
+    return dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=pr.chunk_len, n_blind=N_BLIND,
                 delta=rounds._fr_to_int(pr.delta), n_instances=len(pr.instance_cells))
 
 
@@ -163,8 +163,8 @@ def test_round_outputs_have_the_expected_shape(circuit, proved):
     ch, out, timings = proved
     assert pr.n_adv >= 2 and pr.n_lk >= 1
     c = out["commitments"]
-    from halo2_vectordb_amd.rounds import CHUNK_LEN
-    assert CHUNK_LEN == 2            # cs.degree() = 4 for the vertical gate + single-column lookups (d - 2 = 2)
+    CHUNK_LEN = pr.chunk_len
+    assert CHUNK_LEN == 2 and pr.degree == 4   # cs.degree() = 4 for the vertical gate + single-column lookups (d - 2 = 2)
     assert c["adv"].shape == (pr.n_cols, 8) and c["zp"].shape == (pr.n_sets, 8) and c["h"].shape == (CHUNK_LEN + 1, 8) and c["rand"].shape == (1, 8) and c["hf"].shape == (1, 8) and c["pa"].shape == (pr.n_lk, 8)
     assert len(out["openings"]) == 6 and out["proof"] is None
     for name in ("witness", "commit_msm", "ntt", "lookup_permute", "products", "quotient", "evaluations", "openings"):
@@ -641,6 +641,10 @@ def test_merkle_copy_map_matches_the_witness_and_closes_the_permutation(O):
         flat = (mapping >> np.uint64(32)).astype(np.int64) * pr.rows + (mapping & np.uint64(0xFFFFFFFF)).astype(np.int64)
         assert mapping.shape[0] == pr.n_cols + 2 and np.array_equal(np.sort(flat.reshape(-1)), np.arange((pr.n_cols + 2) * pr.rows))
         out = pr.prove(None, seed=8)
+        # no lookup columns, so no lookup argument: cs.degree() = 3 — one column per permutation product, two quotient pieces, and the
+        # extended domain of 2 n points (the two cosets the rounds evaluate on are all of it)
+        assert pr.n_lk == 0 and pr.degree == 3 and pr.chunk_len == 1 and pr.n_sets == pr.n_cols + 2 and pr.n_slots == 2
+        assert out["commitments"]["h"].shape == (2, 8) and out["commitments"]["zp"].shape == (pr.n_cols + 2, 8)
         assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
         assert out["instances"] == [O.fr_to_ints(api.poseidon_merkle_root(hp.qvec).reshape(1, 4))[0]]                # the public input is the root
         vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED},

@@ -58,8 +58,8 @@ def test_sharded_streamed_proof_and_the_verifier(tmp_path, O):
     with np.load(str(tmp_path / "p1.bin") + ".vk.npz", allow_pickle=False) as doc:
         for name in fixed:                       # the sharded keygen gathers the same verifying key
             assert np.array_equal(fixed[name], doc["fixed_" + name]), name
-    from halo2_vectordb_amd.rounds import CHUNK_LEN, N_BLIND, _fr_to_int
-    vk = dict(meta=dict(rows=meta["rows"], k=meta["k"], n_adv=meta["n_adv"], n_lk=meta["n_lk"], n_cols=meta["n_cols"], n_sets=meta["n_sets"], chunk_len=CHUNK_LEN,
+    from halo2_vectordb_amd.rounds import N_BLIND, _fr_to_int
+    vk = dict(meta=dict(rows=meta["rows"], k=meta["k"], n_adv=meta["n_adv"], n_lk=meta["n_lk"], n_cols=meta["n_cols"], n_sets=meta["n_sets"], chunk_len=meta["chunk_len"],
                         n_blind=N_BLIND, delta=_fr_to_int(api.fr_delta()), n_instances=len(instances)),
               opened={int(r): v for r, v in meta["opened"].items()}, fixed=fixed, tau_h=PR.pt_mul(PR.G2, TAU), instances=instances)
     assert _verify(O, api, proof, vk)

@@ -100,7 +100,7 @@ def main():
             with open(args.out, "wb") as f:
                 f.write(proof)
             np.savez(args.out + ".vk.npz", **{"fixed_" + name: pr.fixed[name].commits for name in pr.fixed}, instances=np.array([str(v) for v in out["instances"]]),
-                     meta=np.frombuffer(json.dumps(dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets,
+                     meta=np.frombuffer(json.dumps(dict(rows=pr.rows, k=pr.k, n_adv=pr.n_adv, n_lk=pr.n_lk, n_cols=pr.n_cols, n_sets=pr.n_sets, chunk_len=pr.chunk_len,
                                                         opened={str(r): v for r, v in out["opened"].items()})).encode(), dtype=np.uint8))
         print(json.dumps({"circuit": args.circuit, "world": world, "columns": pr.n_cols, "sets": pr.n_sets, "proof_bytes": len(proof),
                           "sha256": digest.hex(), "every_rank_wrote_the_same_bytes": same, "quotient_identity_at_x_holds": ok,

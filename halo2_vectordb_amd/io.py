@@ -131,7 +131,7 @@ def read_snark(path):
 
 
 # ---------------------------------------------------------------- verifying key file (the reference writes data/{name}.vk, src/scaffold/mod.rs:276-281)
-VK_FIXED = ("sel", "sigma", "cst", "table", "lag")
+VK_FIXED = ("sel", "sigma", "cst", "table")
 
 
 def write_verifying_key(path, meta, fixed):
@@ -159,7 +159,7 @@ def read_verifying_key(path):
         meta["n_instances"] = int(meta["n_instances"])
         if "opened" in meta:
             meta["opened"] = {int(rot): list(names) for rot, names in meta["opened"].items()}
-        shape = (meta["n_adv"], meta["n_cols"] + 2, 1, 1, 3)     # sigma: advice, lookup, the constants' column, the instance column
+        shape = (meta["n_adv"], meta["n_cols"] + 2, 1, 1)        # sigma: advice, lookup, the constants' column, the instance column
     except (KeyError, TypeError, ValueError) as e:
         raise ValueError(f"verifying key: bad description: {e}") from e
     if tuple(len(fixed[name]) for name in VK_FIXED) != shape:

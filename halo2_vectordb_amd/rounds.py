@@ -32,7 +32,10 @@ from .pipeline import N_BLIND
 
 B = 32
 DERIVED = ("hf",)   # opened polynomials whose evaluation is not in the proof: the verifier computes it (h folded at x, from the quotient identity)
-FIXED = ("sel", "sigma", "cst", "table", "lag")     # the fixed polynomials, in the order the transcript absorbs their commitments
+FIXED = ("sel", "sigma", "cst", "table")     # the committed fixed polynomials, in the order the verifying key's digest absorbs their commitments
+# (the Lagrange selectors l_0, l_last, l_active = 1 - l_last - l_blind the quotient multiplies by are not polynomials of the key: halo2
+#  neither commits nor opens them, its verifier evaluates them at x from the domain — lagrange_evals below; the prover keeps their
+#  cosets as key material, self.fixed["lag"])
 # The constraint system's degree, halo2 ConstraintSystem::degree() [UPSTREAM-RECALL; SURVEY App. C.4 / C.5]: the maximum of the
 # permutation argument's required degree (3), the lookup arguments' (max(4, 2 + input degree + table degree) = 4: halo2-base's "lookup wo
 # selector" reads one lookup-advice column against the table column, both of degree 1) and the gates' (the vertical gate
@@ -1105,7 +1108,7 @@ class ProverRounds:
         # round 5 (x): evaluations.  Which polynomial is read at which rotation: the gate reads the advice at rows 0..3, the
         # products one row ahead, the permuted input one row back, the chained product N_BLIND rows back.
         allp = {**polys, **fx}
-        opened = {0: ["adv", "sel", "sigma", "cst", "table", "lag", "pa", "ps", "zp", "zl", "hf", "rand"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
+        opened = {0: ["adv", "sel", "sigma", "cst", "table", "pa", "ps", "zp", "zl", "hf", "rand"], 1: ["advg", "zp", "zl"], 2: ["advg"], 3: ["advg"], -1: ["pa"],
                   -N_BLIND: ["zp"]}
         opened = {rot: [name for name in names if allp[name].n_total] for rot, names in opened.items()}    # a circuit without lookups
         opened = {rot: names for rot, names in opened.items() if names}                                   # opens nothing at w^-1 x
@@ -1412,6 +1415,18 @@ def instance_eval(instances, x, k):
     return acc * xn1 % R_MOD * pow(n, -1, R_MOD) % R_MOD
 
 
+def lagrange_evals(x, k, usable):
+    """(l_0(x), l_last(x), l_active(x)) as a verifier computes them (halo2 EvaluationDomain::l_i_range): l_i(x) = w^i (x^n - 1) / (n (x - w^i));
+    l_last = l_usable, l_active = 1 - l_last - l_blind with l_blind the sum over the rows behind `usable`"""
+    R, n = R_MOD, 1 << k
+    w = _fr_to_int(api.root_of_unity(k))
+    zn = (pow(x, n, R) - 1) * pow(n, -1, R) % R
+    li = lambda i: pow(w, i, R) * zn % R * pow((x - pow(w, i, R)) % R, -1, R) % R
+    l_last = li(usable)
+    l_blind = sum(li(i) for i in range(usable + 1, n)) % R
+    return li(0), l_last, (1 - l_last - l_blind) % R
+
+
 def quotient_identity_holds(pr, challenges, evals, instances=None):
     """What a verifier checks first: the gate, permutation and lookup expressions recombined from the evaluations at x (and the
     rotated points) equal h(x) (x^n - 1).  `pr`: the ProverRounds that produced them (for the circuit's shape); `challenges`,
@@ -1424,7 +1439,7 @@ def quotient_identity_holds(pr, challenges, evals, instances=None):
     a0, a1, a2, a3, q = ev("adv"), ev("advg", 1), ev("advg", 2), ev("advg", 3), ev("sel")
     for c in range(n_adv):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
-    l0, ll, la = ev("lag")
+    l0, ll, la = lagrange_evals(x, pr.k, pr.usable)
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -N_BLIND)
     # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (evaluated from the public values)
     pcols = list(a0) + list(ev("cst")) + [instance_eval(list(instances) if instances is not None else [], x, pr.k)]

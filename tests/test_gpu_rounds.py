@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TAU = 0x1234567890ABCDEF1234567
-FIXED = ("sel", "sigma", "cst", "table", "lag")
+FIXED = ("sel", "sigma", "cst", "table")
 
 
 def _vk_digest(api, fixed):
@@ -102,7 +102,13 @@ def quotient_numerator(O, meta, ch, evals, instances=()):
         acc = (acc * yv + q[c] * (a0[c] + a1[c] * a2[c] - a3[c])) % R
     if len(instances) != meta["n_instances"]:
         return None
-    l0, ll, la = ev("lag")
+    # l_0, l_last, l_active = 1 - l_last - l_blind at x: not in the proof, a verifier computes them from the domain
+    w_n = O.fr_to_ints(np.asarray(O.root_of_unity(meta["k"])).reshape(1, 4))[0]
+    zn = (pow(x, n, R) - 1) * pow(n, -1, R) % R
+    l_at = lambda i: pow(w_n, i, R) * zn % R * pow((x - pow(w_n, i, R)) % R, -1, R) % R
+    usable = n - n_blind
+    l0, ll = l_at(0), l_at(usable)
+    la = (1 - ll - sum(l_at(i) for i in range(usable + 1, n))) % R
     sg, z0, z1, zb = ev("sigma"), ev("zp"), ev("zp", 1), ev("zp", -n_blind)
     # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (from the public values)
     pcols = list(a0) + list(ev("cst")) + [instance_poly_at(O, instances, x, meta["k"])]
@@ -238,7 +244,7 @@ def test_proof_bytes_verify_from_the_fixed_commitments_alone(circuit, O):
     pr.block_cols = 510
     proof, meta, opened = out["proof"], _meta(pr), out["opened"]
     fixed = {name: pr.fixed[name].commits for name in FIXED}
-    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "rand": 1, "hf": 0}          # (hf: opened, but its evaluation is not sent)
     n_evals = sum(counts[name] for names in opened.values() for name in names)
     n_points = meta["n_cols"] + 2 * meta["n_lk"] + meta["n_sets"] + meta["n_lk"] + 1 + (meta["chunk_len"] + 1) + len(opened)
@@ -434,7 +440,7 @@ def _verify(O, api, proof, vk):
     and the one pairing equation.  Returns True / False (malformed points or scalars: False)."""
     from oracle import pairing as PR
     R, meta, opened = O.R_MOD, vk["meta"], vk["opened"]
-    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "lag": 3, "pa": meta["n_lk"], "ps": meta["n_lk"],
+    counts = {"adv": meta["n_cols"], "advg": meta["n_adv"], "sel": meta["n_adv"], "sigma": meta["n_cols"] + 2, "cst": 1, "table": 1, "pa": meta["n_lk"], "ps": meta["n_lk"],
               "zp": meta["n_sets"], "zl": meta["n_lk"], "rand": 1, "hf": 0}
     pos = 0
     tr = api.Transcript()

@@ -107,7 +107,7 @@ def test_verifying_key_file_round_trip(tmp_path):
     from halo2_vectordb_amd.io import VK_FIXED, read_verifying_key, write_verifying_key
     rng = np.random.default_rng(3)
     n_adv, n_cols = 5, 7
-    counts = dict(sel=n_adv, sigma=n_cols + 2, cst=1, table=1, lag=3)
+    counts = dict(sel=n_adv, sigma=n_cols + 2, cst=1, table=1)
     fixed = {name: rng.integers(0, 1 << 63, size=(counts[name], 8), dtype=np.uint64) for name in VK_FIXED}
     meta = dict(rows=64, k=6, n_adv=n_adv, n_lk=2, n_cols=n_cols, n_sets=3, chunk_len=3, n_blind=5, delta=str(7 ** 40), n_instances=2,
                 tau=str(2 ** 200 + 5), vk_digest=str(3 ** 150), opened={"0": ["adv", "sel"], "-1": ["pa"]})

@@ -576,6 +576,22 @@ class ProverRounds:
         check(lib.vdb_memset_dev(self.d_inst_lag.ptr, 0, _sz(rows * B)))
         self._vk_digest = None
         self.vk_digest()            # part of the key, made here so that no proof pays for it
+        # The cosets of the fixed polynomials that every proof would otherwise transform again — the sigma columns (n_slots cosets
+        # each) and the selectors (two) — stay in HBM when they fit beside everything above with room to spare for the MSM's work space:
+        # halo2's ProvingKey holds them too (fixed_cosets, permutation cosets).  They fit on a rank of a multi-GPU job and for circuits
+        # up to a few thousand columns; BASELINE C4' on one card (20,969 columns: 126 + 36 GB) streams them block by block as before.
+        self.fixed_cosets_resident = False
+        need = (self.my_sig * self.ne + self.my_adv * GATE_SLOTS * rows) * B
+        free, _total = api.mem_info()
+        reserve = int(os.environ.get("VDB_FIXED_COSETS_RESERVE_GB", "48")) << 30
+        if os.environ.get("VDB_FIXED_COSETS", "1") != "0" and free - need >= reserve:
+            sig, sel = self.fixed["sigma"], self.fixed["sel"]
+            sig.ext = api.DeviceBuffer(max(self.my_sig * self.ne, 1) * B)
+            check(lib.vdb_coeff_to_cosets_dev(sig.coeff.ptr, sig.ext.ptr, _sz(self.my_sig), self.k, self.n_slots, None))
+            sel.ext = api.DeviceBuffer(max(self.my_adv * GATE_SLOTS * rows, 1) * B)
+            check(lib.vdb_coeff_to_cosets_dev(sel.coeff.ptr, sel.ext.ptr, _sz(self.my_adv), self.k, GATE_SLOTS, None))
+            api.sync()
+            self.fixed_cosets_resident = True
         return self
 
     # ------------------------------------------------------------------ the proving key on disk
@@ -1026,6 +1042,7 @@ class ProverRounds:
                 check(lib.vdb_permutation_eval_parts_cosets_dev(None, _sz(0), None, None, _sz(0), d_zf.ptr, d_zlast.ptr, *perm_args, a2.ptr, 1, _sz(0), _sz(0), _sz(0), _sz(0)))
             third = blk // 3
             sigma_scaled = os.environ.get("VDB_SIGMA_SCALED", "1") != "0"      # (0: the A/B baseline — sigma's own cosets, the product by beta per point)
+            fixed_resident = getattr(self, "fixed_cosets_resident", False)
 
             def lookup_terms(base, col0, j_lo, j_hi):
                 """the lookup argument of my lookup columns j_lo .. j_hi, whose input cosets are in the block at `base`:
@@ -1053,17 +1070,26 @@ class ProverRounds:
                     base, col0 = adv_ext_block(c0, nb)
                     g0, g1 = max(c0, a_lo), min(c0 + nb, a_hi)
                     if g0 < g1:                                            # gates of the block's advice columns
-                        check(lib.vdb_coeff_to_cosets_dev(fx["sel"].coeff.at((g0 - a_lo) * rows * B), d_eb.ptr, _sz(g1 - g0), k, GATE_SLOTS, None))
+                        if fixed_resident:
+                            sel_ptr = fx["sel"].ext.at((g0 - a_lo) * GATE_SLOTS * rows * B)
+                        else:
+                            check(lib.vdb_coeff_to_cosets_dev(fx["sel"].coeff.at((g0 - a_lo) * rows * B), d_eb.ptr, _sz(g1 - g0), k, GATE_SLOTS, None))
+                            sel_ptr = d_eb.ptr
                         f_g.skip_to(g0, g1 - g0)
-                        check(lib.vdb_gate_eval_cosets_dev(col_ptr(base, col0, g0), N_SLOTS, d_eb.ptr, _sz(g1 - g0), k, GATE_SLOTS, p["y"], ag.ptr))
+                        check(lib.vdb_gate_eval_cosets_dev(col_ptr(base, col0, g0), N_SLOTS, sel_ptr, _sz(g1 - g0), k, GATE_SLOTS, p["y"], ag.ptr))
                     # permutation: the block's sets with their sigma cosets and product cosets (one set more in front for the chaining)
                     set_lo, set_hi = c0 // CHUNK_LEN, -(-(c0 + nb) // CHUNK_LEN)
                     z0 = max(set_lo - 1, 0)
                     # (the cosets of beta sigma: the scalar rides on the transform's coset factors, the evaluation skips a product per point)
-                    if sigma_scaled:
+                    # resident sigma cosets (keygen): no transform, the evaluation multiplies by beta itself
+                    if fixed_resident:
+                        sig_ptr, sig_head = fx["sigma"].ext.at(self._sig_local(c0) * ne * B), 0
+                    elif sigma_scaled:
                         check(lib.vdb_coeff_to_cosets_dev(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, _sz(nb), k, N_SLOTS, p["beta"]))
+                        sig_ptr, sig_head = d_eb.ptr, 2
                     else:
                         to_ext(fx["sigma"].coeff.at(self._sig_local(c0) * rows * B), d_eb.ptr, nb)
+                        sig_ptr, sig_head = d_eb.ptr, 0
                     if z0 < set_lo and (z0 in z_slot or z0 < s_lo):          # the set in front is another rank's (or another range's)
                         to_ext(z_coeff(z0), d_ez.ptr, 1)
                         to_ext(z_coeff(set_lo), d_ez.at(ne * B), set_hi - set_lo)
@@ -1074,7 +1100,7 @@ class ProverRounds:
                         check(lib.vdb_permutation_eval_parts_cosets_dev(None, _sz(0), None, d_ez.ptr, _sz(z0), None, None, *perm_args, a2.ptr, 0, _sz(max(set_lo, 1)), _sz(set_hi),
                                                                  _sz(0), _sz(0)))
                     f_3.skip_to(set_lo, set_hi - set_lo)
-                    check(lib.vdb_permutation_eval_parts_cosets_dev(base, _sz(col0), d_eb.ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, 2 if sigma_scaled else 0, _sz(0), _sz(0), _sz(set_lo),
+                    check(lib.vdb_permutation_eval_parts_cosets_dev(base, _sz(col0), sig_ptr, d_ez.ptr, _sz(z0), None, None, *perm_args, a3.ptr, sig_head, _sz(0), _sz(0), _sz(set_lo),
                                                              _sz(set_hi)))
                     # lookup argument of the block's lookup columns that are mine
                     j_lo, j_hi = max(c0 - n_adv, l_lo), min(c0 + nb - n_adv, l_hi)

@@ -276,6 +276,12 @@ def test_streamed_rounds_give_the_resident_proof(api, O):
                       instances=out["instances"])
             assert _verify(O, api, out["proof"], vk), label
             proofs[label] = out["proof"]
+            # the sigma and selector cosets stay in HBM when they fit (they do here); made block by block inside the quotient instead
+            # — what a circuit the size of BASELINE C4' does on one card — the proof is the same, byte for byte
+            assert pr.fixed_cosets_resident and pr.fixed["sigma"].ext is not None
+            pr.fixed_cosets_resident = False
+            assert pr.prove(None, seed=9)["proof"] == out["proof"], label
+            pr.fixed_cosets_resident = True
         finally:
             pr.free()
             hp.free()

@@ -14,6 +14,8 @@
 //  * k_msm_sort: one workgroup per column does a counting sort of the (digit -> table index) pairs
 //    entirely in LDS (histogram, scan, scatter) and cuts the sorted list into ranges of LCAP entries; bucket
 //    changes inside a range open new segments (one partial sum each), which removes the skew of witness columns.
+//    With wide windows (thousands of buckets, dense scalars) the scatter goes in two phases: entries to the 256 runs of coarse bins
+//    here, k_msm_scatter2 orders each bin in place through LDS — four-byte stores to 8,192 open runs per column do not merge in L2.
 //  * k_msm_accum: one thread per range (every lane does exactly LCAP mixed additions), XYZZ accumulator in VGPRs.
 //  * k_msm_combine: segmented tree reduction of the partials of every bucket.
 //  * k_msm_reduce: one wavefront per column; each lane folds its slice of buckets with the running-sum
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
                                                                const uint8_t* __restrict__ skip_mask /* optional: n per column */,
                                                                uint32_t lcap /* range length, a power of two */,
                                                                uint32_t* __restrict__ longq /* n per column: queue of the long scalars */,
-                                                               unsigned long long* __restrict__ recs /* n per column: short-scalar records */) {
+                                                               unsigned long long* __restrict__ recs /* n per column: short-scalar records */,
+                                                               uint32_t fine_bits, uint32_t idx_bits, uint32_t bin_cap) {
   extern __shared__ uint32_t sh[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = sh;            // B
@@ -369,10 +372,93 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   }
   __syncthreads();
   uint32_t* ent = entries + (size_t)col * ent_cap;
+  // Two-phase scatter (fine_bits > 0): 1.2 M four-byte stores to 8,192 open bucket runs per column never merge in L2 (a workgroup per CU,
+  // every one with thousands of partly written lines) and cost two thirds of this kernel.  Here the entries go to the few hundred runs of
+  // the coarse bins — bucket >> fine_bits, contiguous because a bin is a range of buckets — carrying their fine bucket number above the
+  // table index; k_msm_scatter2 then orders every bin in place through LDS.
+  if (fine_bits) {
+    const uint32_t n_bins = B >> fine_bits;
+    for (uint32_t q = tid; q < n_bins; q += MSM_SORT_THREADS) {
+      const uint32_t lo = cursor[q << fine_bits], hi = q + 1 < n_bins ? cursor[(q + 1) << fine_bits] : total_cnt;
+      ucnt[q] = lo;                          // the bins' cursors (ucnt is free: the range descriptors are written)
+      hist[q] = hi - lo > bin_cap ? 1u : 0u; // a bin too large for a workgroup of the second phase (the top window's few small digits;
+                                             // one value repeated down a witness column) is scattered directly: its runs are few
+    }
+    __syncthreads();
+    const uint32_t fmask = (1u << fine_bits) - 1u;
+    walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
+      const uint32_t b = d - 1, bin = b >> fine_bits;
+      const uint32_t payload = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
+      if (hist[bin]) {
+        ent[atomicAdd(&cursor[b], 1u)] = payload;
+      } else {
+        ent[atomicAdd(&ucnt[bin], 1u)] = payload | ((b & fmask) << idx_bits);
+      }
+    });
+    return;
+  }
   walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {
     uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
     ent[pos] = (uint32_t)(j * table_n + i) | (neg ? 0x80000000u : 0u);
   });
+}
+
+// second phase of the two-phase scatter: one workgroup per (bin, column) loads the bin's entries (coarse order) into LDS and writes
+// them back bucket by bucket — 2^fine_bits open runs per workgroup, which L2 merges into whole lines
+#define MSM_SCATTER2_THREADS 256
+#define MSM_BIN_CAP (6 * 1024)   // entries of a bin a workgroup holds (24 registers per thread, 24 KB of LDS)
+__global__ __launch_bounds__(MSM_SCATTER2_THREADS) void k_msm_scatter2(uint32_t* __restrict__ entries, size_t ent_cap, const uint32_t* __restrict__ bucket_off,
+                                                                       uint32_t B, uint32_t fine_bits, uint32_t idx_bits, uint32_t bin_cap,
+                                                                       const uint32_t* __restrict__ counters) {
+  extern __shared__ uint32_t sh2[];
+  if (counters[1]) return;
+  const uint32_t col = blockIdx.y, tid = threadIdx.x;
+  const uint32_t* bo = bucket_off + (size_t)col * (B + 1);
+  const uint32_t nf = 1u << fine_bits, n_bins = B >> fine_bits;
+  uint32_t* outb = sh2;           // bin_cap: the bin in bucket order, written back in whole lines
+  uint32_t* fcur = sh2 + bin_cap; // nf
+  uint32_t* ent = entries + (size_t)col * ent_cap;
+  const uint32_t fmask = nf - 1u, imask = (1u << idx_bits) - 1u;
+  const uint32_t lane = tid & 63u;
+  for (uint32_t bin = blockIdx.x; bin < n_bins; bin += gridDim.x) {   // (uniform per workgroup: the barriers below are reached by all)
+    const uint32_t b0 = bin << fine_bits;
+    const uint32_t lo = bo[b0], hi = bo[b0 + nf];
+    const uint32_t S = hi - lo;
+    if (S == 0 || S > bin_cap) continue;   // (a larger bin was scattered to its buckets directly)
+    // the bin as it lies (coarse order), in registers: every load of the thread in flight at once (a loop of unknown length would
+    // wait for each one: ~20 round trips to HBM per bin)
+    uint32_t r[MSM_BIN_CAP / MSM_SCATTER2_THREADS];
+#pragma unroll
+    for (uint32_t q = 0; q < MSM_BIN_CAP / MSM_SCATTER2_THREADS; q++) {
+      const uint32_t i = tid + q * MSM_SCATTER2_THREADS;
+      r[q] = i < S ? ent[lo + i] : 0u;
+    }
+    for (uint32_t f = tid; f < nf; f += MSM_SCATTER2_THREADS) fcur[f] = bo[b0 + f] - lo;
+    __syncthreads();
+    // positions by wavefront-level ranking: the lanes that hold the same bucket are found with one ballot per bucket bit, their
+    // leader draws the run of positions with one atomic, the others take theirs by rank
+#pragma unroll
+    for (uint32_t q = 0; q < MSM_BIN_CAP / MSM_SCATTER2_THREADS; q++) {
+      const uint32_t i = tid + q * MSM_SCATTER2_THREADS;
+      if (q * MSM_SCATTER2_THREADS >= S) break;        // uniform
+      const bool active = i < S;
+      const uint32_t e = r[q];
+      const uint32_t f = (e >> idx_bits) & fmask;
+      unsigned long long peers = __ballot(active);
+      for (uint32_t bit = 0; bit < fine_bits; bit++) {
+        const unsigned long long m = __ballot(active && ((f >> bit) & 1u));
+        peers &= ((f >> bit) & 1u) ? m : ~m;
+      }
+      uint32_t base = 0;
+      const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+      if (active && rank == 0) base = atomicAdd(&fcur[f], (uint32_t)__popcll(peers));
+      base = (uint32_t)__shfl((int)base, active ? (int)__ffsll((long long)peers) - 1 : (int)lane, 64);
+      if (active) outb[base + rank] = (e & 0x80000000u) | (e & imask);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < S; i += MSM_SCATTER2_THREADS) ent[lo + i] = outb[i];
+    __syncthreads();
+  }
 }
 
 // ---- accumulation in nine-limb form ------------------------------------------------------------------------------
@@ -721,6 +807,20 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   // large batches keep thousands of independent column reductions in flight
   size_t per_col = ent_cap * 4 + range_cap_col * sizeof(MsmRange) + seg_cap_col * (sizeof(MsmSegInfo) + sizeof(XYZZ) + MSM_RAW_WORDS * 4) + 2 * (B + 1) * 4 +
                    n * 12;
+  // two-phase scatter of the sort: bins of 2^fine_bits buckets; the table index and the fine bucket number share an entry's 31 bits
+  static const bool two_phase_on = !(getenv("VDB_MSM_TWO_PHASE") && getenv("VDB_MSM_TWO_PHASE")[0] == '0');
+  uint32_t idx_bits = 1;
+  while (((uint64_t)1 << idx_bits) < (uint64_t)W * srs->n) idx_bits++;
+  uint32_t fine_bits = 0;
+  const uint32_t bin_cap = MSM_BIN_CAP;
+  // (only where the direct scatter is what the sort waits for: thousands of buckets per column and dense scalars — the 14-bit windows
+  //  of the product / quotient / fixed columns; with the 11-bit windows of the witness columns, 1,024 buckets and mostly short scalars,
+  //  the second phase costs more than it saves: 15.4 + 4.2 against 15.2 ms per C4 step)
+  if (two_phase_on && c >= 13) {
+    fine_bits = c - 1 - 8;              // 256 bins
+    if (fine_bits + idx_bits > 31) fine_bits = idx_bits < 31 ? 31 - idx_bits : 0;
+    if (fine_bits < 2) fine_bits = 0;
+  }
   // budget: half of what is free on the card (counting the slot this buffer already holds), between 8 and 96 GiB —
   // on a 288 GB MI355X the 8,146 columns of the kmeans k = 16 job go through in ONE batch (76 GB), so the whole
   // bucket-folding tail can run beside the NTTs (defer_tail)
@@ -762,7 +862,14 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
       hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)nc), dim3(MSM_SORT_THREADS), lds, cx.stream, scalars_dev ? scalars_dev + c0 * n : nullptr, srcs ? srcs + c0 : nullptr,
                        n_blind, n, srs->n, c, W, entries,
                        ent_cap, seg_off, bucket_off, ranges, counters, seg_cap, range_cap, skip_mask ? skip_mask + c0 * n : nullptr,
-                       lcap, longq, recs);
+                       lcap, longq, recs, fine_bits, idx_bits, bin_cap);
+    }
+    VDB_LAUNCH_CHECK();
+    if (fine_bits) {
+      VDB_PROF("k_msm_scatter2");
+      const unsigned bins_x = (B >> fine_bits) < 64u ? (B >> fine_bits) : 64u;   // (16 .. 256 workgroups per column measure the same)
+      hipLaunchKernelGGL(k_msm_scatter2, dim3(bins_x, (unsigned)nc), dim3(MSM_SCATTER2_THREADS), (bin_cap + (1u << fine_bits)) * sizeof(uint32_t), cx.stream,
+                       entries, ent_cap, bucket_off, B, fine_bits, idx_bits, bin_cap, counters);
     }
     VDB_LAUNCH_CHECK();
     {

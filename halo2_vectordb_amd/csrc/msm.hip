@@ -157,10 +157,24 @@ __device__ __forceinline__ void emit_digits32(uint32_t mag, bool neg, uint32_t n
 template <class F>
 __device__ __forceinline__ void walk_scalars(const u256* __restrict__ sc, const ColSrc* __restrict__ cs, uint32_t n_blind, const uint8_t* __restrict__ mk,
                                              size_t n, uint32_t c, uint32_t W, uint32_t* __restrict__ queue, unsigned long long* __restrict__ rec,
-                                             uint32_t* s_qcnt, bool first, F&& f) {
+                                             uint32_t* s_qcnt, bool first, F&& f, bool dense = false) {
   ColSrc src;
   if (cs) src = *cs;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (dense) {
+    // columns of full-width scalars (products, quotient pieces, fixed columns: the wide-window tables): no short / long sorting, every
+    // scalar is reduced and decomposed where it is met — one Montgomery reduction per visit instead of two on the first
+    for (size_t i0 = 0; i0 < n; i0 += MSM_SORT_THREADS) {
+      const size_t i = i0 + tid;
+      if (i >= n || (mk && mk[i])) continue;
+      u256 s = cs ? colsrc_fetch(src, i, n, n_blind) : ld256(sc + i);
+      if (u256_is_zero(s)) continue;
+      s = from_mont<Fr>(s);
+      const bool neg = fold_scalar(s);
+      emit_digits(s, neg, u256_bits(s), c, W, f, i);
+    }
+    return;
+  }
   const uint32_t short_bits = 3 * c - 1 < 32 ? 3 * c - 1 : 32;
   if (first) {
     if (tid == 0) *s_qcnt = 0;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
   __syncthreads();
   uint32_t* queue = longq + (size_t)col * n;
   unsigned long long* rec = recs + (size_t)col * n;
-  walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); });
+  walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, true, [&](uint32_t, uint32_t d, bool, size_t) { atomicAdd(&hist[d - 1], 1u); }, fine_bits != 0);
   __syncthreads();
   // scan: thread owns buckets [tid*ipt, (tid+1)*ipt)
   const uint32_t ipt = (B + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS;
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_sort(const u256* __res
       } else {
         ent[atomicAdd(&ucnt[bin], 1u)] = payload | ((b & fmask) << idx_bits);
       }
-    });
+    }, true);
     return;
   }
   walk_scalars(sc, cs, n_blind, mk, n, c, W, queue, rec, &s_qcnt, false, [&](uint32_t j, uint32_t d, bool neg, size_t i) {

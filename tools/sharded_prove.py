@@ -7,7 +7,7 @@ must not depend on the number of ranks (tests/test_gpu_sharded.py).
         tools/sharded_prove.py --circuit kmeans --out /tmp/p2.bin
 
 Circuits: "kmeans" (a small cosine k-means), "nearest" (small), "c2" (BASELINE configs[1]: nearest_vector over 64 x 128, k = 14),
-"merkle" (small, no lookup columns), "query" (small: nearest_vector and merkle_commitment in one circuit), "mid" (cosine k-means over 128 x 64 vectors, K = 4, I = 4, at 2^16 rows).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
+"merkle" (small, no lookup columns), "distances" (examples/distances.rs, small), "query" (small: nearest_vector and merkle_commitment in one circuit), "mid" (cosine k-means over 128 x 64 vectors, K = 4, I = 4, at 2^16 rows).  Rank 0 writes the proof bytes to --out and prints one JSON line; every rank checks that its
 own transcript ended with the same bytes (sha256 exchanged)."""
 import argparse
 import hashlib
@@ -71,6 +71,9 @@ def main():
         hp = KmeansHotPath(n=256, dim=128, K=4, I=4, k=16, P=48, L=15, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "merkle":
         hp = MerkleHotPath(n=6, dim=5, k=11, tau=TAU, col_shard=shard)
+    elif args.circuit == "distances":   # examples/distances.rs: three distances of two vectors, each public (a dozen columns at 2^10 rows)
+        from halo2_vectordb_amd.pipeline import DistancesHotPath
+        hp = DistancesHotPath(dim=6, k=10, L=9, tau=TAU, col_shard=shard)
     else:
         raise SystemExit("unknown circuit")
     hp.ext_block_cols = args.ext_block_cols

@@ -110,3 +110,36 @@ def test_c1_euclid_proves(api, O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_poseidon_example_proves_with_inputs_and_hash_public(api, O):
+    """examples/poseidon.rs:26-36 on data/poseidon.in: two loaded field elements, update([x, y]); squeeze — merkle_commitment over ONE
+    two-word vector is exactly that (one leaf, no tree level) —, x, y and the hash public (make_public.extend([x, y]); push(hash)).  The
+    inputs are raw field elements here, not quantized numbers: the hot path's input buffer takes them as they are."""
+    from halo2_vectordb_amd.pipeline import MerkleHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    r = E.oracle_poseidon(O)
+    hp = MerkleHotPath(n=1, dim=2, k=10, tau=TAU).setup()
+    pr = None
+    try:
+        hp.qvec = np.ascontiguousarray(r["xy"].reshape(1, 2, 4))
+        hp.d_vec.upload(hp.qvec)
+        pr = ProverRounds(hp).keygen()                       # the default statement: the hash alone
+        root_cell = int(pr.root_cell)
+        pr.free()
+        pr = ProverRounds(hp).keygen(instance_cells=[0, 1, root_cell])
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        out = pr.prove(None)
+        x, y = O.fr_to_ints(r["xy"])
+        h = O.fr_to_ints(np.asarray(r["hash"]).reshape(1, 4))[0]
+        assert out["instances"] == [x, y, h] and (x, y) == (6, 100)
+        assert np.array_equal(hp.results(), r["hash"])
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
+        assert not _verify(O, api, out["proof"], {**vk, "instances": [x, y + 1, h]})
+        assert not _verify(O, api, out["proof"], {**vk, "instances": [x, y, (h + 1) % O.R_MOD]})
+    finally:
+        if pr is not None:
+            pr.free()
+        hp.free()

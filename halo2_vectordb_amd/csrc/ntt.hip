@@ -113,7 +113,9 @@ __device__ __forceinline__ void lds_put(const L9Planes& P, uint32_t idx, const L
 // per block, w = omega_m^(bitrev(block)).  Stage 0 has w = 1 everywhere (no product).  Values stay lazy: a product
 // is normalised and below 1.2 r, sums and differences just add limbs; every third stage starts with a carry pass so
 // multiplier inputs stay below 6 * 2^29 per limb and nothing reaches 2^32.  Values stay below 22 r over ten stages.
-template <bool LAST>
+// `VS`: the first pass of vdb_coeff_to_cosets_dev (virtual columns, the slot's table of input factors) — an instantiation of its own,
+// so that the step's transforms carry none of its branches
+template <bool LAST, bool VS = false>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict__ in, u256* __restrict__ out,
                                                          const u256* __restrict__ tw, const u256* __restrict__ tw_inter, NttPass p,
                                                          uint32_t tiles_per_col) {
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     col = grp * p.col_group + r % ncg;
     tile = r / ncg;
   }
-  const u256* cin = in + (size_t)((p.first && p.vslots) ? col / p.vslots : col) * p.in_stride;
+  const u256* cin = in + (size_t)(VS ? col / p.vslots : col) * p.in_stride;
   const u256* ctab = nullptr;
-  if (p.first && p.coset == 3) {
+  if constexpr (VS) {
     const uint32_t slot = col % p.vslots;
     ctab = slot == 0 ? p.in_tab[0] : (slot == 1 ? p.in_tab[1] : (slot == 2 ? p.in_tab[2] : p.in_tab[3]));
   }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   // it into the other three quarters.
   const uint32_t mload = m >> p.s0, Tload = mload * G;
   L9 Z0, Z1, Z2;
-  if (p.coset && p.coset != 3) {
+  if (!VS && p.coset) {
     Z1 = l9_split(p.zeta1);
     Z2 = l9_split(p.zeta2);
     if (p.coset == 2) Z0 = l9_split(p.zeta0);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     L9 v;
     if (!p.first || idx < p.in_len) {
       v = l9_split(from_src ? colsrc_fetch(csrc, idx, 1ull << p.log_n, p.n_blind) : ld256(cin + idx));
-      if (p.coset == 3) {
+      if constexpr (VS) {
         v = l9_mul(v, l9_split(ld256(ctab + idx)));
       } else if (p.coset) {
         uint32_t r3 = (uint32_t)(idx % 3);
@@ -736,18 +738,22 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
         if (!raised) {
           VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
           VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          VDB_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
           raised = true;
         }
       }
       if (last) {
         {
           VDB_PROF("k_ntt_pass");
-          hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
+          if (l == 0 && vslots) hipLaunchKernelGGL((k_ntt_pass<true, true>), grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
+          else hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
         }
       } else {
         {
           VDB_PROF("k_ntt_pass");
-          hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, l == 0 ? tw_scaled : tw, p, tiles);
+          if (l == 0 && vslots) hipLaunchKernelGGL((k_ntt_pass<false, true>), grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw_scaled, p, tiles);
+          else hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, l == 0 ? tw_scaled : tw, p, tiles);
         }
       }
       VDB_LAUNCH_CHECK();

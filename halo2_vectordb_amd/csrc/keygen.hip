@@ -48,7 +48,8 @@ struct PmShape {
 // record t -> (root, col << 32 | row); starts[c] = stream offset of row 0 of advice column c (n_adv + 1 entries, the last = n_cells)
 __global__ __launch_bounds__(256) void k_pm_records(PmShape s, const int64_t* __restrict__ root, const uint64_t* __restrict__ starts,
                                                    const uint64_t* __restrict__ bp, const int64_t* __restrict__ lookup_src,
-                                                   const int64_t* __restrict__ inst_cells, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+                                                   const int64_t* __restrict__ inst_cells, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
+                                                   int* __restrict__ err) {
   const uint64_t total = s.n_cells + s.n_dup + s.n_lookup + s.n_consts + s.n_inst;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -72,7 +73,13 @@ __global__ __launch_bounds__(256) void k_pm_records(PmShape s, const int64_t* __
       const uint64_t j = t - s.n_cells - s.n_dup;
       col = s.n_adv + j / s.lookup_rows;
       row = j % s.lookup_rows;
-      key = (uint64_t)root[lookup_src[j]];
+      const int64_t src = lookup_src[j];
+      if (src < 0 || (uint64_t)src >= s.n_cells) {  // a lookup cell that copies nothing inside the stream: refused by the caller
+        *err = 1;
+        key = s.n_cells + s.n_consts;
+      } else {
+        key = (uint64_t)root[src];
+      }
     } else if (t < s.n_cells + s.n_dup + s.n_lookup + s.n_consts) {
       const uint64_t r = t - s.n_cells - s.n_dup - s.n_lookup;
       col = s.fixed_col;
@@ -82,7 +89,13 @@ __global__ __launch_bounds__(256) void k_pm_records(PmShape s, const int64_t* __
       const uint64_t r = t - s.n_cells - s.n_dup - s.n_lookup - s.n_consts;
       col = s.fixed_col + 1;
       row = r;
-      key = (uint64_t)root[inst_cells[r]];
+      const int64_t cell = inst_cells[r];
+      if (cell < 0 || (uint64_t)cell >= s.n_cells) {  // a public cell outside the stream
+        *err = 1;
+        key = s.n_cells + s.n_consts;
+      } else {
+        key = (uint64_t)root[cell];
+      }
     }
     keys[t] = key;
     vals[t] = (col << 32) | row;
@@ -132,8 +145,13 @@ __global__ __launch_bounds__(256) void k_map_place(const int64_t* __restrict__ b
       continue;
     }
     int64_t val = (int64_t)idx;
-    if (src >= 0) val = b + src;
-    else if (src <= MAP_EXT0) {
+    if (src >= 0) {
+      if ((uint64_t)src >= n_blk) {  // a block cell that copies a cell outside its block
+        *err = 1;
+        continue;
+      }
+      val = b + src;
+    } else if (src <= MAP_EXT0) {
       const uint64_t e = (uint64_t)(MAP_EXT0 - src);
       if (e >= n_ext) {
         *err = 1;
@@ -231,7 +249,7 @@ extern "C" int vdb_copymap_place_dev(const int64_t* blk_src_dev, const int64_t* 
   VDB_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
   VDB_HIP(hipStreamSynchronize(cx.stream));   // also: the caller's small host arrays may be reused after the call
   if (herr) {
-    set_error("copy map: a block instance lies outside the stream, or names an external input it was not given");
+    set_error("copy map: a block instance lies outside the stream, names an external input it was not given, or copies a cell outside its block");
     return VDB_ERR_ARG;
   }
   return VDB_OK;
@@ -324,9 +342,19 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   }
   {
     VDB_PROF("k_pm_records");
-    hipLaunchKernelGGL(k_pm_records, dim3(grid), dim3(256), 0, cx.stream, s, parent_dev, d_starts, d_bp, lookup_src_dev, instance_cells_dev, keys, vals);
+    VDB_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), cx.stream));
+    hipLaunchKernelGGL(k_pm_records, dim3(grid), dim3(256), 0, cx.stream, s, parent_dev, d_starts, d_bp, lookup_src_dev, instance_cells_dev, keys, vals, d_flag);
   }
   VDB_LAUNCH_CHECK();
+  {
+    int bad = 0;
+    VDB_HIP(hipMemcpyAsync(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+    VDB_HIP(hipStreamSynchronize(cx.stream));
+    if (bad) {
+      set_error("permutation mapping: a public cell or a lookup cell's source lies outside the stream");
+      return VDB_ERR_ARG;
+    }
+  }
   // 3. sort by root
   unsigned end_bit = 1;
   while (end_bit < 64 && ((n_cells + n_consts) >> end_bit)) end_bit++;

@@ -167,6 +167,9 @@ class ProverRounds:
         self.fixed = {}
         self._vk_digest = None
         self.d_map32 = None
+        self.d_inst_cells = None
+        self.public_cells = []          # the circuit's default public cells (circuit_map); a key loaded from a file brings its own
+        self.instance_cells = []
 
     # ------------------------------------------------------------------ local positions of global things
     def _set_local(self, i):
@@ -306,9 +309,6 @@ class ProverRounds:
             cm, outs = CS.trace_distances(hp.metrics, hp.dim, hp.P, hp.L)
             self.public_cells = [int(c) for c in outs] if hp.public else []      # examples/distances.rs:44-59 make_public.push(dist)
             return cm
-        from .pipeline import MerkleHotPath, NearestHotPath, QueryHotPath
-        hp = self.hp
-        on_device = getattr(self, "map_on_device", True)
 
         def fetch(lo, hi):
             c = api.fr_to_canonical(hp.d_stream.download((hi - lo, 4), offset=lo * B))
@@ -486,6 +486,8 @@ class ProverRounds:
 
     def _upload_instance_cells(self):
         cells = np.asarray(self.instance_cells, dtype=np.int64)
+        if getattr(self, "d_inst_cells", None) is not None:      # a second keygen / key load on the same object
+            self.d_inst_cells.free()
         self.d_inst_cells = api.DeviceBuffer(max(cells.nbytes, 32))
         if cells.nbytes:
             self.d_inst_cells.upload(cells)
@@ -542,6 +544,24 @@ class ProverRounds:
                 b.free()
             if own:
                 d_flags.free()
+
+    def mock_check_instances(self, instances):
+        """The `instances` argument of MockProver::run alone, on the witness in HBM (vdb_mock_check_instances_dev): public cell i of
+        keygen must hold instances[i] (canonical integers).  Needs no constraint map, so it also serves after keygen released the
+        map of a BASELINE-size circuit.  api.MockReport with only the instance fields filled."""
+        if len(instances) != len(self.instance_cells):
+            raise ValueError("one value per public cell")
+        rep = api.MockReport()
+        if not len(instances):
+            return rep
+        vals = np.stack([_fr_from_int(int(v)) for v in instances])
+        d_vals = api.DeviceBuffer(vals.nbytes)
+        try:
+            d_vals.upload(vals)
+            api.mock_check_instances_dev(rep, self.hp.d_stream.ptr, self.hp.n_cells, self.d_inst_cells.ptr, d_vals.ptr, len(instances))
+        finally:
+            d_vals.free()
+        return rep
 
     def _alloc_working_set(self):
         lib, rows, CHUNK_LEN = self.lib, self.rows, self.chunk_len

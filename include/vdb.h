@@ -471,7 +471,9 @@ int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t ca
  *      columns; the fixed column is column n_cols, the INSTANCE column is column n_cols + 1: instance_cells_dev[i] is the
  *      stream cell the circuit makes public i-th (the closure's make_public vector, src/scaffold/mod.rs:378-400:
  *      RangeWithInstanceCircuitBuilder ties assigned_instances[i] to row i of its one instance column), n_instances <= 2^k.
- *      mapping_dev: (n_cols + 2) x 2^k words col << 32 | row, the input of vdb_permutation_sigma_dev. ------------------ */
+ *      mapping_dev: (n_cols + 2) x 2^k words col << 32 | row, the input of vdb_permutation_sigma_dev.
+ *      VDB_ERR_ARG (checked on the device, nothing is read out of bounds): an instance cell or a lookup source < 0 or >= n_cells,
+ *      a copy map that holds a cycle. -------------------------------------------------------------------------------------- */
 int vdb_permutation_mapping_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
                                 const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
                                 const int64_t *instance_cells_dev, uint64_t n_instances, uint64_t *mapping_dev);

@@ -37,7 +37,18 @@ for kind in ("fetch", "write"):
         agg[k][2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     for k, (n, v, ms) in agg.items():
         rows.append((kind, k, n, v, ms))
+# the source the counters were measured on (tools/profile_round.sh records it on the GPU box, from the snapshot it profiled):
+# kernel -> SHA-256 of its .hip file and the headers that file includes (profiles/srchash.py); bench.py refuses a summary whose
+# hash for the dominant kernel is not the running tree's
+import json
+import os
+hashes = {}
+if os.path.exists(f"{src}_srchash.json"):
+    hashes = json.load(open(f"{src}_srchash.json"))
 with open(f"profiles/{tag}{suffix}_pmc_summary.csv", "w") as f:
+    if hashes:
+        kernels = sorted({k.replace("void ", "").replace("vdb::", "").split("<")[0] for _kind, k, *_ in rows})
+        f.write("# source_sha256 " + " ".join(f"{k}={hashes[k]}" for k in kernels if k in hashes) + "\n")
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-proof (tools/profile_round.sh)\n")
     f.write("# Counter_Value is in KiB as reported; gfx950 correction (MI355X_MICROARCH.md §HBM): HBM read bytes = 2 * FETCH_SIZE * 1024\n")
     f.write("# for wide coalesced 16 B/lane streams, HBM write bytes = WRITE_SIZE * 1024.\n")

@@ -1,0 +1,66 @@
+"""bench.py's host-side bookkeeping that needs no GPU: `roofline.traffic` is reported from a committed rocprofv3 counter summary only
+when that summary was measured on the kernel source the bench runs from (profiles/srchash.py)."""
+import importlib
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tree(tmp_path):
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "include").mkdir()
+    csrc = tmp_path / "halo2_vectordb_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "profiles", "srchash.py"), tmp_path / "profiles" / "srchash.py")
+    (csrc / "field.hpp").write_text("// field\n")
+    (csrc / "ntt.hip").write_text('#include "field.hpp"\nnamespace vdb {\n__global__ __launch_bounds__(256) void k_ntt_pass(int* a) { a[0] = 1; }\n}\n')
+    (csrc / "msm.hip").write_text('__global__ void k_msm_accum(int* a) { a[0] = 2; }\n')
+    return csrc
+
+
+def _summary(path, hashes):
+    with open(path, "w") as f:
+        if hashes is not None:
+            f.write("# source_sha256 " + " ".join(f"{k}={v}" for k, v in hashes.items()) + "\n")
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE\n")
+        f.write("counter,kernel,launches,sum_counter_KiB,per_launch_KiB,sum_ms\n")
+        f.write("fetch,void vdb::k_ntt_pass<true>,4,4000.0,1000.0,1.0\nfetch,vdb::k_ntt_pass,4,4000.0,1000.0,1.0\nwrite,vdb::k_ntt_pass,8,16000.0,2000.0,1.0\n")
+
+
+def test_traffic_is_withheld_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    csrc = _tree(tmp_path)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    sys.modules.pop("srchash", None)
+    sys.path.insert(0, str(tmp_path / "profiles"))
+    from srchash import kernel_source_hashes
+    h = kernel_source_hashes(str(tmp_path))
+    assert set(h) == {"k_ntt_pass", "k_msm_accum"} and h["k_ntt_pass"] != h["k_msm_accum"]
+    # no summary at all: nothing to report, nothing stale
+    assert bench.pmc_traffic_per_launch("k_ntt_pass") == (None, None, False)
+    # a summary without the header (rounds 1-3): withheld
+    _summary(tmp_path / "profiles" / "r01_pmc_summary.csv", None)
+    assert bench.pmc_traffic_per_launch("k_ntt_pass") == (None, "r01_pmc_summary.csv", True)
+    # measured on this very source: 2 x FETCH + WRITE per launch, KiB -> bytes
+    _summary(tmp_path / "profiles" / "r02_pmc_summary.csv", h)
+    traffic, src, stale = bench.pmc_traffic_per_launch("k_ntt_pass")
+    assert (src, stale) == ("r02_pmc_summary.csv", False) and traffic == (2.0 * 8000.0 / 8 + 16000.0 / 8) * 1024.0
+    # another kernel's file changes: this kernel's counters still stand
+    (csrc / "msm.hip").write_text('__global__ void k_msm_accum(int* a) { a[0] = 3; }\n')
+    assert bench.pmc_traffic_per_launch("k_ntt_pass")[2] is False
+    # a header the kernel includes changes: the counters no longer describe what runs
+    (csrc / "field.hpp").write_text("// field, edited\n")
+    assert bench.pmc_traffic_per_launch("k_ntt_pass") == (None, "r02_pmc_summary.csv", True)
+
+
+def test_every_kernel_of_the_library_has_a_source_hash():
+    sys.modules.pop("srchash", None)
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from srchash import kernel_source_hashes
+    h = kernel_source_hashes(ROOT)
+    for kernel in ("k_ntt_pass", "k_msm_accum", "k_msm_sort", "k_dist_head", "k_dist_tail", "k_perm_eval", "k_gate_eval"):
+        assert len(h[kernel]) == 64
+    assert h["k_ntt_pass"] != h["k_msm_accum"]

@@ -329,7 +329,14 @@ def test_a_failing_rank_of_the_sharded_proof_does_not_cost_the_bench_line(tmp_pa
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and "error" in out["proof"]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "error" in out["proof"] and out["proof_abandoned"] is True
+    assert "the sharded proof was abandoned" in res.stderr
+    # ... and with VDB_BENCH_STRICT_EXIT=1 the launcher sees the failure as a non-zero exit code, the line still printed first
+    cmd[cmd.index("29519")] = "29520"
+    res = subprocess.run(cmd, env=dict(env, VDB_BENCH_STRICT_EXIT="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["value"] > 0 and out["proof_abandoned"] is True
 
 
 def test_extended_cosets_in_column_blocks(api, O):

@@ -59,14 +59,18 @@ def rel_close(a, b, eps=1e-6):
 
 
 class GpuDemoZKDB:
-    def __init__(self, api, O, database, K, I):
+    def __init__(self, api, O, database, K, I, kmeans=None):
+        """`kmeans`: dict(centroids, indicators) of a k-means run made elsewhere (the resident hot path, for circuits whose
+        stream is too large to bring to the host); None = vdb_wit_kmeans here, its cells compared with the oracle's"""
         self.api, self.O, self.db = api, O, database
         self.qdb = api.quantize(database, P)
-        km = api.wit_kmeans("euclidean", self.qdb, K, I, P=P, L=L)
-        # the same cells as the CPU restatement, bit for bit
-        c = O.Ctx(store=True)
-        c.kmeans("euclidean", self.qdb, K, I, P=P, L=L)
-        assert np.array_equal(km["stream"], c.advice())
+        km = kmeans
+        if km is None:
+            km = api.wit_kmeans("euclidean", self.qdb, K, I, P=P, L=L)
+            # the same cells as the CPU restatement, bit for bit
+            c = O.Ctx(store=True)
+            c.kmeans("euclidean", self.qdb, K, I, P=P, L=L)
+            assert np.array_equal(km["stream"], c.advice())
         self.centroids_q = km["centroids"]
         self.centroids = api.dequantize(km["centroids"].reshape(-1, 4), P).reshape(K, -1)
         ind = api.dequantize(km["indicators"].reshape(-1, 4), P).reshape(len(database), K)
@@ -133,3 +137,50 @@ def test_siftsmall_shaped_pipeline(api, O, tmp_path):
     cid, _ = f64_nearest(q, np.array(cent))
     _, want = f64_nearest(q, db[[i for i, c in enumerate(ids) if c == cid]])
     assert rel_close(zk.ann(q), want)
+
+
+def test_random_large_shape_through_the_resident_hot_path(api, O):
+    """The reference's own large case, tests/demo_test.rs:36-56 `test_random_large`: DIM 128, 100 vectors, K = 10, I = 10,
+    uniform [0, 1) components (tests/common/mod.rs:34-40), Euclidean, P = 48, LOOKUP_BITS = 13 (tests/vectordb/mod.rs:3-4).
+    kmeans::<10, 10> is a circuit of 600 M advice + 126 M lookup cells: it runs through the HBM-resident hot path at 2^16 rows
+    (KmeansHotPath: witness -> break points -> commitments), its results come back, the first iteration's 73 M cells are held to
+    the oracle's bit for bit; the rest of DemoZKDB — Merkle roots of the database, the centroids and every cluster, both
+    nearest_vector circuits of `ann` with their root checks — runs as in the small cases.  Compared as the reference compares:
+    the result vector against the f64 DemoDB at relative 1e-6, cluster ids exact, roots equal between indexing and query.
+    The seed is fixed (the reference draws from the OS): one for which every cluster stays non-empty in f64."""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    dim, n, K, I = 128, 100, 10, 10
+    rng = np.random.default_rng(1004)
+    db = rng.random((n, dim))
+    cent, ids = f64_kmeans(db, K, I)
+    assert len(set(ids)) == K
+    hp = KmeansHotPath(n=n, dim=dim, K=K, I=I, k=16, P=P, L=L, vectors=db)
+    hp.ext_block_cols = 256
+    hp.setup()
+    try:
+        assert (hp.n_cells, hp.n_lookup) == (n * dim + 600_414_002, 125_918_400)
+        commitments = hp.step()
+        assert commitments.shape == (hp.n_cols, 8) and commitments.any(axis=1).all()
+        gc, gi = hp.results()
+        # first iteration: [assign_witnesses(vectors)] [kmeans cells] against the oracle
+        qv = O.quantize(db, P)
+        assert np.array_equal(qv, hp.qvec)
+        c = O.Ctx(store=True)
+        c.assign_witnesses(qv)
+        c.kmeans("euclidean", qv, K, 1, P=P, L=L)
+        adv, lk = c.advice(), c.lookup()
+        del c
+        assert len(adv) + len(lk) > 72_000_000
+        assert np.array_equal(hp.d_stream.download((len(adv), 4)), adv) and np.array_equal(hp.d_lookup.download((len(lk), 4)), lk)
+        del adv, lk
+    finally:
+        hp.free()
+    zk = GpuDemoZKDB(api, O, db, K, I, kmeans=dict(centroids=gc, indicators=gi))
+    assert zk.cluster_ids == ids                                   # exact
+    assert rel_close(zk.centroids, np.array(cent))                 # assert_float_relative_eq!'s 1e-6
+    for _ in range(3):
+        q = rng.random(dim)
+        cid, _ = f64_nearest(q, np.array(cent))
+        _, want = f64_nearest(q, db[[i for i, c in enumerate(ids) if c == cid]])
+        assert rel_close(zk.ann(q), want)                          # `ann` asserts root == root at both steps
+    assert len({bytes(r) for r in zk.cluster_roots} | {bytes(zk.database_root), bytes(zk.centroids_root)}) == K + 2

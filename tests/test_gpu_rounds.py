@@ -579,6 +579,13 @@ def test_a_verifier_accepts_the_proof_bytes_and_rejects_tampered_ones(circuit, O
         bad[where] ^= 4
         assert not _verify(O, api, bytes(bad), vk)
     assert not _verify(O, api, proof[:-32], vk) and not _verify(O, api, proof + bytes(32), vk)
+    # a verifying key that states another constraint degree than the circuit's (chunk_len = degree - 2 columns per product polynomial,
+    # degree - 1 quotient pieces; [UPSTREAM-RECALL] for halo2's value, rounds.constraint_degree): the proof is not a proof under it
+    for wrong in (1, 3):
+        n_sets = -(-(vk["meta"]["n_cols"] + 2) // wrong)
+        assert not _verify(O, api, proof, {**vk, "meta": {**vk["meta"], "chunk_len": wrong}})
+        assert not _verify(O, api, proof, {**vk, "meta": {**vk["meta"], "chunk_len": wrong, "n_sets": n_sets}})
+    assert not _verify(O, api, proof, {**vk, "meta": {**vk["meta"], "n_blind": vk["meta"]["n_blind"] - 1}})
 
 
 def test_every_proof_draws_fresh_blinding_scalars(circuit, O):

@@ -165,7 +165,75 @@ def cpu_baseline(hp, cols_sample, commitments_sample):
     }
 
 
-def cpu_proof_estimate(units, cores, shape):
+def measured_cpu_proof(cores):
+    """One RUN of a whole CPU proof, to calibrate the estimate below: the oracle's prover (oracle/prover.py — create_proof composed from
+    the same C bricks the unit costs time; the prover the GPU's proof bytes are compared with in tests/test_gpu_cpu_prover.py) on the
+    cosine k-means circuit at 2^12 rows (n=8, dim=4, K=2, I=1: 235 columns), timed, next to cpu_proof_estimate's figure for the same
+    shape from unit costs measured at that size.  The prover runs its commitments on `cores` threads and everything else on one."""
+    from oracle import oracle as O, prover as PV
+    from halo2_vectordb_amd import circuit_sym as CS
+    from halo2_vectordb_amd.pipeline import sift_like_vectors
+    n, dim, K, I, k, P, L = 8, 4, 2, 1, 12, 48, 11
+    vec, _ = sift_like_vectors(20260004, n, dim, K)
+    qv = O.quantize(vec, P)
+    t0 = time.perf_counter()
+    c = O.Ctx(store=True, keygen=True, plan_k=k)
+    c.assign_witnesses(qv)
+    c.kmeans("cosine", qv, K, I, P=P, L=L)
+    stream, lookup = c.advice(), c.lookup()
+    t_wit = time.perf_counter() - t0
+    cm, (cent, _ind) = CS.build_kmeans("cosine", n, dim, K, I, P, L, builder=None)
+    cs = PV.Circuit(k, L, c.break_points(), c.selectors(), len(lookup), cm.copy_of, cm.const_idx, cm.consts, cm.lookup_src, [int(x) for x in np.asarray(cent).reshape(-1)])
+    g, gl = O.srs_from_tau(k, 0x1234567890ABCDEF1234567)
+    t0 = time.perf_counter()
+    pk = PV.keygen(cs, g, gl, threads=cores)
+    t_keygen = time.perf_counter() - t0
+    stages = {}
+    t0 = time.perf_counter()
+    out = PV.prove(pk, stream, lookup, PV.seeded_blinds(cs, 1), timings=stages)
+    t_prove = time.perf_counter() - t0
+    # unit costs at this size, as cpu_baseline measures them at 2^16
+    rows = cs.rows
+    cols = PV.layout_advice(cs, stream)[:32]
+    t0 = time.perf_counter()
+    O.msm_batch(cols, gl, threads=cores)
+    t_msm = (time.perf_counter() - t0) / len(cols)
+    t0 = time.perf_counter()
+    O.lde_batch(cols, ext=2, threads=cores)
+    t_ntt = (time.perf_counter() - t0) / len(cols)
+    rng = np.random.default_rng(2)
+    dense = O.random_fr(rng, 16 * rows).reshape(16, rows, 4)
+    t0 = time.perf_counter()
+    O.msm_batch(dense, gl, threads=cores)
+    t_dense = (time.perf_counter() - t0) / 16
+    t0 = time.perf_counter()
+    O.grand_product(dense[:8], dense[8:])
+    t_gp = (time.perf_counter() - t0) / 8
+    t0 = time.perf_counter()
+    O.eval_polys(dense, dense[0, 0])
+    t_eval = (time.perf_counter() - t0) / 16
+    t0 = time.perf_counter()
+    O.fr_mul(dense.reshape(-1, 4)[: 8 * rows], dense.reshape(-1, 4)[8 * rows:])
+    t_mul = (time.perf_counter() - t0) / (8 * rows)
+    units = {"witness_s_per_cell": t_wit / (len(stream) + len(lookup)), "msm_witness_col_s": t_msm, "ntt_pair_col_s": t_ntt, "msm_dense_col_s": t_dense,
+             "grand_product_col_s_1thread": t_gp, "eval_poly_s_1thread": t_eval, "fr_mul_s_1thread": t_mul, "sort_col_s_1thread": 0.0}
+    shape = {"cells": len(stream) + len(lookup), "rows": rows, "n_adv": cs.n_adv, "n_lk": cs.n_lk, "n_sets": cs.n_sets,
+             "n_evals": int(sum(len(v) for v in out["evals"].values()))}
+    est, parts = cpu_proof_estimate(units, cores, shape)
+    est1, parts1 = cpu_proof_estimate(units, cores, shape, cores_other=1)
+    witness_part = parts["witness (one thread)"]
+    return {"circuit": "cosine k-means n=8 dim=4 K=2 I=1, P=48, LOOKUP_BITS=11, k=12", "shape": shape,
+            "measured_prove_s": round(t_prove, 2), "measured_stage_s": {k_: round(v, 2) for k_, v in stages.items()}, "measured_witness_s": round(t_wit, 2),
+            "measured_keygen_s": round(t_keygen, 2), "proof_bytes": len(out["proof"]),
+            "model_s_without_witness": round(est - witness_part, 2), "model_s_without_witness_serial_except_commitments": round(est1 - witness_part, 2),
+            "model_parts_s_serial_except_commitments": parts1,
+            "measured_over_model": round(t_prove / max(est1 - witness_part, 1e-9), 2),
+            "note": "one run of oracle/prover.py (Python around the C bricks; commitments on `cores` threads, transforms and the quotient on one) "
+                    "against cpu_proof_estimate for the same shape with unit costs measured at 2^12 rows: how far the step-count model is from a "
+                    "prover that actually runs.  The model with everything parallel (model_s_without_witness) is what est_full_proof_s assumes."}
+
+
+def cpu_proof_estimate(units, cores, shape, cores_other=None):
     """What create_proof costs the CPU port for a circuit of `shape` (cells, n_adv, n_lk, n_sets, n_evals, rows), from the unit
     costs cpu_baseline measured on this host: a count of halo2's steps ([UPSTREAM-RECALL] create_proof: per committed column one
     MSM, one lagrange_to_coeff and one coset transform; per lookup column a sort, two commitments and a grand product; per
@@ -174,15 +242,20 @@ def cpu_proof_estimate(units, cores, shape):
     the cores.  An estimate of the port, kind "port": the reference's Rust prover cannot run here."""
     n, n_adv, n_lk, n_sets = shape["rows"], shape["n_adv"], shape["n_lk"], shape["n_sets"]
     n_cols, n_perm = n_adv + n_lk, n_adv + n_lk + 2
-    u, par = units, float(cores)
+    u, par = units, float(cores if cores_other is None else cores_other)
     mul = u["fr_mul_s_1thread"] / par
+    # (`cores_other`: the threads everything but the commitments runs on — measured_cpu_proof's prover transforms on one; the
+    #  per-column transform cost was measured on `cores` threads)
+    ntt = u["ntt_pair_col_s"] * (1.0 if cores_other is None else float(cores) / float(cores_other))
     parts = {
         "witness (one thread)": u["witness_s_per_cell"] * shape["cells"],
-        "advice: commit + transforms": n_cols * (u["msm_witness_col_s"] + u["ntt_pair_col_s"]),
-        "lookup: permute, 2 commits + transforms": n_lk * (u["sort_col_s_1thread"] / par + 2 * (u["msm_witness_col_s"] + u["ntt_pair_col_s"])),
+        "advice: commit + transforms": n_cols * (u["msm_witness_col_s"] + ntt),
+        "lookup: permute, 2 commits + transforms": n_lk * (u["sort_col_s_1thread"] / par + 2 * (u["msm_witness_col_s"] + ntt)),
         "products: terms + grand products": (n_perm * n * 4 + n_lk * n * 4) * mul + (n_sets + n_lk) * u["grand_product_col_s_1thread"] / par,
-        "products: commits + transforms": (n_sets + n_lk) * (u["msm_dense_col_s"] + u["ntt_pair_col_s"]),
-        "quotient on 4 n points": 4 * n * (3 * n_adv + 8 * n_perm + 14 * n_lk) * mul + 5 * u["ntt_pair_col_s"],
+        "products: commits + transforms": (n_sets + n_lk) * (u["msm_dense_col_s"] + ntt),
+        # every polynomial entering the quotient is extended to the 4 n points (the advice cosets above; the fixed, permuted and product
+        # polynomials here), then the terms' products
+        "quotient on 4 n points": 4 * n * (3 * n_adv + 8 * n_perm + 14 * n_lk) * mul + (n_adv + n_perm + n_sets + 3 * n_lk + 5) * ntt,
         "evaluations": shape["n_evals"] * u["eval_poly_s_1thread"] / par,
         "multi-open": 2 * (3 * n_cols + n_adv + n_perm + n_sets * 3 + n_lk * 4) * n * mul + 6 * u["msm_dense_col_s"],
     }
@@ -419,6 +492,10 @@ def main():
             idx = list(range(0, hp.n_cols, max(1, hp.n_cols // ns)))[:ns]
             cols = hp.download_columns(idx)
             cpu = cpu_baseline(hp, cols, commitments[idx])
+            try:
+                cpu["measured_small_proof"] = measured_cpu_proof(cpu["cores"])
+            except Exception as e:      # the calibration run must not cost the line
+                cpu["measured_small_proof"] = {"error": repr(e)[:300]}
 
     proof = None
     abandoned = False

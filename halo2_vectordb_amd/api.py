@@ -742,6 +742,20 @@ def mem_info():
     return f.value, t.value
 
 
+def scratch_held():
+    """bytes the library's cached work buffers hold (what vdb_scratch_release would give back)"""
+    b = ctypes.c_size_t()
+    check(_lib.init().vdb_scratch_held(ctypes.byref(b)))
+    return b.value
+
+
+KEYGEN_SCRATCH_CAP = 16 << 30      # bound of the MSM's work space while setup / keygen allocate the proving key (vdb_msm_set_scratch_cap)
+
+
+def msm_scratch_cap(nbytes):
+    check(_lib.init().vdb_msm_set_scratch_cap(_sz(nbytes)))
+
+
 def sync():
     check(_lib.init().vdb_sync())
 

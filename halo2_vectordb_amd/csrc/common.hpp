@@ -45,6 +45,7 @@ struct Context {
   static constexpr int N_SCRATCH = 8;
   void* scratch[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes[N_SCRATCH] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t msm_scratch_cap = 0;   // vdb_msm_set_scratch_cap: upper bound of the MSM's work space (0: half of the free HBM, 8 .. 96 GiB)
   // device-resident caches owned by other translation units; released through their hooks in vdb_shutdown
   std::map<uint64_t, void*> fp_tables;   // witness.hip: FixedPointChip tables keyed by (P, L)
   void* poseidon_spec = nullptr;          // poseidon.hip: device copy of the Poseidon spec

@@ -331,6 +331,20 @@ int vdb_mem_info(size_t* free_bytes, size_t* total_bytes) {
   VDB_HIP(hipMemGetInfo(free_bytes, total_bytes));
   return VDB_OK;
 }
+int vdb_msm_set_scratch_cap(size_t bytes) {
+  VDB_REQUIRE_INIT();
+  ctx().msm_scratch_cap = bytes;
+  return VDB_OK;
+}
+int vdb_scratch_held(size_t* bytes) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(bytes, "null pointer");
+  Context& c = ctx();
+  size_t sum = 0;
+  for (int i = 0; i < Context::N_SCRATCH; i++) sum += c.scratch_bytes[i];
+  *bytes = sum;
+  return VDB_OK;
+}
 int vdb_scratch_release(void) {
   VDB_REQUIRE_INIT();
   Context& c = ctx();

@@ -843,6 +843,9 @@ int msm_batch_dev(const vdb_srs* srs, int basis, const u256* scalars_dev, size_t
   size_t budget = (free_b + cx.scratch_bytes[2]) / 2;
   if (budget < ((size_t)8 << 30)) budget = (size_t)8 << 30;
   if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+  // a caller that is about to allocate tens of GB of its own (keygen) bounds the work space: growing it to half of a still empty
+  // card and releasing it again costs seconds of page mapping (vdb_msm_set_scratch_cap)
+  if (cx.msm_scratch_cap && budget > cx.msm_scratch_cap) budget = cx.msm_scratch_cap > cx.scratch_bytes[2] ? cx.msm_scratch_cap : cx.scratch_bytes[2];
   size_t nb = budget / per_col;
   if (nb < 1) nb = 1;
   if (nb > n_cols) nb = n_cols;

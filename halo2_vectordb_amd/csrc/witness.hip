@@ -293,12 +293,15 @@ __device__ void block_inner_product(const Streams& st, const FpTables* T, const 
 // head of a distance: everything before the sequential tail.  One block per instance.
 __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTables* __restrict__ T, DistLayout dl, InstMap im,
                                                        const u256* __restrict__ A, const u256* __restrict__ Bv, u256* __restrict__ mid /* 3 per inst */,
-                                                       u256* __restrict__ result) {
+                                                       u256* __restrict__ result, int have_values) {
   __shared__ u256 sh[HEAD_TB + 1];
   const uint32_t t = blockIdx.x, tid = threadIdx.x, D = dl.D;
   const u256* a = A + (size_t)(t % im.a_mod) * D;
   const u256* b = Bv + (size_t)(t / im.b_div) * D;
   const uint64_t base = im.adv(t, dl), lbase = im.lk(t, dl);
+  // sharded run: k_dist_values has left this instance's sums in `mid` already, so a block none of whose cells lie in the rank's
+  // window has nothing to do (without it every rank walked every instance's head in value-only mode)
+  if (have_values && !st.touches(base, base + dl.head_cells, lbase, lbase + dl.head_lk)) return;
   if (dl.metric == M_EUCLID) {  // distance.rs:97-119
     for (uint32_t i = tid; i < D; i += HEAD_TB) {
       WCtx c = make_ctx(st, T, base + 4ull * i, lbase);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTable
 
 // sequential tail of a distance, cut into `gridDim.y` position windows; lanes = instances
 __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __restrict__ T, DistLayout dl, InstMap im, uint32_t n_inst,
-                                                  const u256* __restrict__ mid, u256* __restrict__ result) {
+                                                  const u256* __restrict__ mid, u256* __restrict__ result, int have_values) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   const bool live = t < n_inst;
   if (!live) t = n_inst - 1;
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __
   const uint64_t tb = im.adv(t, dl) + dl.head_cells, tlb = im.lk(t, dl) + dl.head_lk;
   // segment S-1 carries the result every rank needs; the other segments only emit cells and leave at once
   // when none of the wavefront's instances lies in this rank's window
-  if (s != S - 1 && !__any((int)(live && st.touches(tb, tb + dl.tail_cells, tlb, tlb + dl.tail_lk)))) return;
+  // (`have_values`: k_dist_tail_values has computed every result already — the last segment leaves like the others)
+  if ((s != S - 1 || have_values) && !__any((int)(live && st.touches(tb, tb + dl.tail_cells, tlb, tlb + dl.tail_lk)))) return;
   WCtx c = make_ctx(st, T, tb, tlb);
   c.lo = tb + dl.tail_cells * s / S;
   c.hi = tb + dl.tail_cells * (s + 1) / S;
@@ -385,6 +389,87 @@ __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __
     r = g.g_sub(one, sim);
   }
   if (live && s == S - 1) {
+    result[t] = r;
+    if (c.err) atomicOr(st.err, c.err);
+  }
+}
+
+// ---- the distances' VALUES alone, for sharded runs (every rank needs every distance — assignments and centroids follow
+// from them — but stores only the cells of its own columns).  One wavefront per instance: lane i takes dimensions i, i + 64, ...
+// through the gadgets' value-only helpers, the sums are folded across the wavefront (field addition: the order is free), lane 0
+// writes what the head would have left in `mid` (Manhattan: the result itself).  No emission context, no stores of cells.
+__device__ __forceinline__ u256 wave_sum_fr(u256 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    u256 o;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o.w[k] = __shfl_xor(v.w[k], off, 64);
+    v = fr_add(v, o);
+  }
+  return v;
+}
+__global__ __launch_bounds__(64) void k_dist_values(const FpTables* __restrict__ T, DistLayout dl, InstMap im, const u256* __restrict__ A,
+                                                    const u256* __restrict__ Bv, u256* __restrict__ mid, u256* __restrict__ result) {
+  const uint32_t t = blockIdx.x, lane = threadIdx.x, D = dl.D;
+  const u256* a = A + (size_t)(t % im.a_mod) * D;
+  const u256* b = Bv + (size_t)(t / im.b_div) * D;
+  WCtx c{};
+  c.T = T;
+  Gadgets g(c);
+  u256 s0 = u256_zero(), s1 = u256_zero(), s2 = u256_zero();
+  for (uint32_t i = lane; i < D; i += 64) {
+    const u256 x = a[i], y = b[i];
+    if (dl.metric == M_EUCLID) {
+      const u256 d = fr_sub(x, y);
+      s0 = fr_add(s0, g.v_qmul(d, d));
+    } else if (dl.metric == M_COSINE) {
+      s0 = fr_add(s0, g.v_qmul(x, y));
+      s1 = fr_add(s1, g.v_qmul(x, x));
+      s2 = fr_add(s2, g.v_qmul(y, y));
+    } else {
+      s0 = fr_add(s0, g.v_qabs(fr_sub(x, y)));
+    }
+  }
+  s0 = wave_sum_fr(s0);
+  if (dl.metric == M_COSINE) {
+    s1 = wave_sum_fr(s1);
+    s2 = wave_sum_fr(s2);
+  }
+  if (lane == 0) {
+    if (dl.metric == M_MANHATTAN) {
+      result[t] = s0;
+    } else {
+      mid[3 * (size_t)t] = s0;
+      if (dl.metric == M_COSINE) {
+        mid[3 * (size_t)t + 1] = s1;
+        mid[3 * (size_t)t + 2] = s2;
+      }
+    }
+  }
+}
+// ... and the sequential tails' values: lanes = instances, the tail's own code with an emission window that holds no position
+// (every sub-gadget takes its value-only path; domain errors — a division by zero — are reported as the emitting walk reports them)
+__global__ __launch_bounds__(64) void k_dist_tail_values(Streams st, const FpTables* __restrict__ T, DistLayout dl, uint32_t n_inst,
+                                                         const u256* __restrict__ mid, u256* __restrict__ result) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  const bool live = t < n_inst;
+  if (!live) t = n_inst - 1;
+  WCtx c = make_ctx(st, T, 1, 0);
+  c.lo = c.hi = 0;
+  Gadgets g(c);
+  u256 r;
+  if (dl.metric == M_EUCLID) {
+    r = g.fp_qsqrt(mid[3 * (size_t)t]);
+  } else {
+    u256 ab = mid[3 * (size_t)t], aa = mid[3 * (size_t)t + 1], bb = mid[3 * (size_t)t + 2];
+    u256 as = g.fp_qsqrt(aa);
+    u256 bs = g.fp_qsqrt(bb);
+    u256 den = g.fp_qmul(as, bs);
+    u256 sim = g.fp_qdiv(ab, den);
+    u256 one = g.load_constant(T->c_one_q);
+    r = g.g_sub(one, sim);
+  }
+  if (live) {
     result[t] = r;
     if (c.err) atomicOr(st.err, c.err);
   }
@@ -450,16 +535,36 @@ static uint32_t tail_segments(uint32_t n_inst) {
 static int run_distances(const Streams& st, FpEntry* fp, const DistLayout& dl, const InstMap& im, uint32_t n_inst, const u256* A,
                          const u256* Bv, u256* mid, u256* result) {
   if (n_inst == 0) return VDB_OK;
+  // a rank that stores only a window of the streams first computes every distance's value with the value-only kernels; the emitting
+  // kernels then leave at once wherever none of their cells lie in the window (VDB_WIT_VALUES=0: the walk of rounds 1-3, every rank
+  // running every head and the last tail segment in value-only mode)
+  static const bool values_on = !(getenv("VDB_WIT_VALUES") && getenv("VDB_WIT_VALUES")[0] == '0');
+  const bool windowed = !(st.rlo == 0 && st.rhi == ~0ull && st.rllo == 0 && st.rlhi == ~0ull);
+  const int have_values = (windowed && values_on && st.sel == nullptr) ? 1 : 0;
+  if (have_values) {
+    {
+      VDB_PROF("k_dist_values");
+      hipLaunchKernelGGL(k_dist_values, dim3(n_inst), dim3(64), 0, ctx().stream, fp->dev, dl, im, A, Bv, mid, result);
+    }
+    VDB_LAUNCH_CHECK();
+    if (dl.tail_cells) {
+      {
+        VDB_PROF("k_dist_tail_values");
+        hipLaunchKernelGGL(k_dist_tail_values, dim3((n_inst + 63) / 64), dim3(64), 0, ctx().stream, st, fp->dev, dl, n_inst, mid, result);
+      }
+      VDB_LAUNCH_CHECK();
+    }
+  }
   {
     VDB_PROF("k_dist_head");
-    hipLaunchKernelGGL(k_dist_head, dim3(n_inst), dim3(HEAD_TB), 0, ctx().stream, st, fp->dev, dl, im, A, Bv, mid, result);
+    hipLaunchKernelGGL(k_dist_head, dim3(n_inst), dim3(HEAD_TB), 0, ctx().stream, st, fp->dev, dl, im, A, Bv, mid, result, have_values);
   }
   VDB_LAUNCH_CHECK();
   if (dl.tail_cells) {
     {
       VDB_PROF("k_dist_tail");
       hipLaunchKernelGGL(k_dist_tail, dim3((n_inst + 63) / 64, tail_segments(n_inst)), dim3(64), 0, ctx().stream, st, fp->dev, dl, im, n_inst,
-                       mid, result);
+                       mid, result, have_values);
     }
     VDB_LAUNCH_CHECK();
   }

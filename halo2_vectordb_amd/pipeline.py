@@ -220,6 +220,10 @@ class KmeansHotPath:
         points are used as they are — the Prove arm of the reference (src/scaffold/mod.rs:285-287) — after checking that
         they describe this circuit; otherwise they are derived from the keygen-style run, like the Keygen arm."""
         lib, n, dim, K, I = self.lib, self.n, self.dim, self.K, self.I
+        # the MSMs of setup and keygen (constant points, fixed columns) work in a bounded work space: on a still empty card the default
+        # (half of the free HBM) would map up to 96 GiB for a two-second MSM, and mapping fresh HBM costs ~30 ms / GiB; step() lifts it
+        api.msm_scratch_cap(api.KEYGEN_SCRATCH_CAP)
+        self._cap_lifted = False
         vec, self.seed = self._input_vectors() if self.given_vectors is None else (self.given_vectors, self.seed)
         assert vec.shape == (self.n_input_rows(), self.dim), "input rows do not match the circuit's shape"
         self.vectors_f64 = vec
@@ -314,27 +318,28 @@ class KmeansHotPath:
                                                   self.d_src.at(self.my_adv * 24)))
         # keygen-time factoring of the constant cells: column-layout mask of the QuantumCell::Constant cells and the
         # per-column MSM of exactly those cells (data independent, so computed once like the rest of the proving key)
-        # (lookup columns hold no constants: their mask stays zero and their constant point is the identity)
+        # (lookup columns hold no constants: their mask stays zero and their constant point is the identity).
+        # Only this rank's advice columns, laid out in the column buffer the step overwrites anyway: no second buffer of the
+        # columns' size (33.7 GiB at C4') is allocated and handed back.
         n_el = self.n_adv_cols * self.rows
-        d_fmask = api.DeviceBuffer(n_el)
+        d_fmask = api.DeviceBuffer(n_el)                    # one byte per cell of ALL advice columns (1.1 GiB at C4')
         check(lib.vdb_layout_const_mask_dev(d_sel.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k, d_fmask.ptr))
         d_sel.free()
-        d_full = api.DeviceBuffer(n_el * B)
-        check(lib.vdb_layout_columns_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
-                                         d_full.ptr, None, 0))
-        check(lib.vdb_mask_select_dev(d_full.ptr, d_fmask.ptr, ctypes.c_uint64(n_el), 1, d_full.ptr))
-        const_pts = np.zeros((self.n_cols, 8), dtype=np.uint64)
-        check(lib.vdb_msm_batch_dev(self.srs.h, 1, d_full.ptr, ctypes.c_size_t(self.n_adv_cols), ctypes.c_size_t(self.rows), api._p(const_pts)))
-        d_full.free()
-        self.const_points = const_pts
-        mine = np.concatenate([const_pts[self.a_lo:self.a_hi], const_pts[self.n_adv_cols + self.l_lo: self.n_adv_cols + self.l_hi]])
-        self.d_cpts = api.DeviceBuffer(max(mine.nbytes, 64))
-        if mine.nbytes:
-            self.d_cpts.upload(np.ascontiguousarray(mine))
         self.d_mask = api.DeviceBuffer(max(self.my_cols, 1) * self.rows)
         check(lib.vdb_memset_dev(self.d_mask.ptr, 0, ctypes.c_size_t(max(self.my_cols, 1) * self.rows)))
+        const_mine = np.zeros((self.my_cols, 8), dtype=np.uint64)
         if self.my_adv:
             check(lib.vdb_memcpy_d2d(self.d_mask.ptr, d_fmask.at(self.a_lo * self.rows), ctypes.c_size_t(self.my_adv * self.rows)))
+            check(lib.vdb_layout_columns_range_dev(self.d_stream.ptr, ctypes.c_uint64(self.n_cells), api._p(self.bp), ctypes.c_uint64(len(self.bp)), self.k,
+                                                   ctypes.c_uint64(self.a_lo), ctypes.c_uint64(self.a_hi), self.d_cols.ptr, None, 0))
+            check(lib.vdb_mask_select_dev(self.d_cols.ptr, self.d_mask.ptr, ctypes.c_uint64(self.my_adv * self.rows), 1, self.d_cols.ptr))
+            pts = np.zeros((self.my_adv, 8), dtype=np.uint64)
+            check(lib.vdb_msm_batch_dev(self.srs.h, 1, self.d_cols.ptr, ctypes.c_size_t(self.my_adv), ctypes.c_size_t(self.rows), api._p(pts)))
+            const_mine[: self.my_adv] = pts
+        self.const_points = const_mine                      # [my advice | my lookup] order, like d_cols
+        self.d_cpts = api.DeviceBuffer(max(const_mine.nbytes, 64))
+        if const_mine.nbytes:
+            self.d_cpts.upload(np.ascontiguousarray(const_mine))
         self.const_cell_fraction = float(d_fmask.download((n_el,), dtype=np.uint8).mean()) if n_el <= (1 << 28) else None
         d_fmask.free()
         api.sync()
@@ -344,11 +349,11 @@ class KmeansHotPath:
         # Two columns more than this rank holds: the prover rounds keep the cosets of the constants' fixed column and of the
         # instance column behind the advice cosets, so that the permutation argument reads its columns from one contiguous
         # block (rounds.py).
-        check(lib.vdb_scratch_release())
         per_col = self.rows * 4 * B
         want = max(self.my_cols, 1) + 2
         if self.ext_block_cols is None:
             free, _ = api.mem_info()
+            free += api.scratch_held()       # (the bounded work space stays allocated: it is part of what ext_reserve_bytes leaves the MSM)
             fit = (free - self.ext_reserve_bytes) // per_col
             self.ext_cols = want if fit >= want else int(max(min(want, 256), fit // 256 * 256))
         else:
@@ -438,6 +443,9 @@ class KmeansHotPath:
         queues next is ordered behind them).  `after_witness`: called once the witness kernels are queued and before the
         commitments are (the prover rounds read the public cells out of the stream there)."""
         lib, B = self.lib, 32
+        if not getattr(self, "_cap_lifted", True):      # the prover's MSM takes the work space its default policy gives it
+            api.msm_scratch_cap(0)
+            self._cap_lifted = True
         self.refresh_blinds(blind_seed)
 
         def stage(name, fn):

@@ -361,6 +361,9 @@ class ProverRounds:
         `check`: run the device-side MockProver on the keygen witness with the whole map (vdb_mock_check_dev); the report is
         kept in self.keygen_report (a circuit the witness does not satisfy can still be set up — the proof will not verify)."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
+        # the fixed columns' commitments work in the bounded MSM work space of setup (pipeline.setup); the first step() lifts the bound
+        api.msm_scratch_cap(api.KEYGEN_SCRATCH_CAP)
+        hp._cap_lifted = False
         # the derived columns (products, quotient, opening quotients) and the fixed sigma columns hold full-width scalars
         self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
         self.srs_few = api.Srs(k, hp.g_monomial, None)     # a handful of columns: the bucket folding dominates, fewer buckets win
@@ -570,7 +573,8 @@ class ProverRounds:
         # `block_cols` columns — two in Lagrange form (the permutation's columns and their sigma columns), two of extended
         # cosets, one of product cosets — through which every per-column stage streams.  The library's MSM scratch is released
         # first so that it is re-sized to what is left.
-        check(lib.vdb_scratch_release())
+        if api.scratch_held() > 2 * api.KEYGEN_SCRATCH_CAP:      # a hot path that has proved already holds the prover's big work space
+            check(lib.vdb_scratch_release())
         n_der = 3 * self.my_lk + self.my_sets
         blk = max(2 * CHUNK_LEN, min(self.block_cols, -(-max(self.my_sig, 1) // (2 * CHUNK_LEN)) * (2 * CHUNK_LEN)) // (2 * CHUNK_LEN) * (2 * CHUNK_LEN))
         self.blk_alloc = blk
@@ -603,6 +607,7 @@ class ProverRounds:
         self.fixed_cosets_resident = False
         need = (self.my_sig * self.ne + self.my_adv * GATE_SLOTS * rows) * B
         free, _total = api.mem_info()
+        free += api.scratch_held()          # the work space already allocated counts towards the reserve kept for it
         reserve = int(os.environ.get("VDB_FIXED_COSETS_RESERVE_GB", "48")) << 30
         if os.environ.get("VDB_FIXED_COSETS", "1") != "0" and free - need >= reserve:
             sig, sel = self.fixed["sigma"], self.fixed["sel"]
@@ -629,39 +634,51 @@ class ProverRounds:
             meta["opened"] = {str(rot): list(names) for rot, names in opened.items()}
         write_verifying_key(path, meta, {name: self.fixed[name].commits for name in FIXED})
 
+    def _key_header(self):
+        """what a proving-key file must agree on with the run that loads it: the circuit's shape and, for a sharded key, this rank's
+        place in the partition (rank, world, every rank's column blocks)"""
+        shards = np.asarray([[a[0], a[1], l[0], l[1]] for a, l in self.hp.shards], dtype=np.int64)
+        return (np.array([self.k, self.n_adv, self.n_lk, self.hp.L, self.chunk_len, N_BLIND, self.rank, self.world], dtype=np.uint64), shards)
+
     def save_proving_key(self, path):
         """What the reference's Keygen arm leaves for the Prove arm (src/scaffold/mod.rs:272-281: pinning + pk), in this
         build's own container: an .npz (numpy.load with allow_pickle=False reads it) holding the circuit's shape, the break
-        points, and per fixed polynomial — gate selectors, sigma columns, range table, Lagrange selectors — its coefficient
-        form and its commitments.  Upstream's pk file format (SerdeFormat::RawBytes) is not reproduced: parity unpinned."""
-        if self.world > 1:
-            raise NotImplementedError("the proving-key file holds the whole key: write it from a one-rank run")
+        points, and per fixed polynomial — gate selectors, sigma columns, constants, range table, Lagrange selectors — its coefficient
+        form and its commitments.  Upstream's pk file format (SerdeFormat::RawBytes) is not reproduced: parity unpinned.
+        Sharded (world > 1): every rank writes a file of its own (the caller names it per rank) with the selectors of its advice
+        columns and the sigma columns of its sets, beside the whole set's commitments and the replicated small polynomials; the
+        header records the partition, and load_proving_key refuses a file written for another rank or other column blocks."""
         api.sync()
-        doc = {"meta": np.array([self.k, self.n_adv, self.n_lk, self.hp.L, self.chunk_len, N_BLIND], dtype=np.uint64), "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
+        meta, shards = self._key_header()
+        doc = {"meta": meta, "shards": shards, "break_points": np.asarray(self.hp.bp, dtype=np.uint64)}
         doc["instance_cells"] = np.asarray(self.instance_cells, dtype=np.int64)
+        doc["instance_cells_are_the_default"] = np.array([int(self.instance_cells == [int(c) for c in self.public_cells])], dtype=np.int64)
         for name, q in self.fixed.items():
-            doc[name + "_coeff"] = q.coeff.download((max(q.n_cols, 1), self.rows, 4))
+            doc[name + "_coeff"] = q.coeff.download((max(q.n_cols, 1), self.rows, 4))[: q.n_cols]
             doc[name + "_commits"] = q.commits
         np.savez(path, **doc)
 
     def load_proving_key(self, path):
         """The Prove arm's side: the fixed polynomials from a file written by save_proving_key instead of a keygen run (no
         flag-recording witness pass, no permutation construction).  The Lagrange forms the rounds read (sigma, table) are
-        recovered with a forward transform; raises ValueError when the file describes another circuit."""
+        recovered with a forward transform; raises ValueError when the file describes another circuit, another rank or another
+        partition of the columns."""
         hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
-        if self.world > 1:
-            raise NotImplementedError("the proving-key file holds the whole key: load it in a one-rank run")
         with np.load(path, allow_pickle=False) as doc:
-            meta = [int(v) for v in doc["meta"]]
-            if meta != [k, self.n_adv, self.n_lk, hp.L, self.chunk_len, N_BLIND] or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
-                raise ValueError("proving key does not describe this circuit (shape or break points differ)")
+            meta, shards = self._key_header()
+            if not np.array_equal(doc["meta"], meta) or not np.array_equal(doc["shards"], shards) \
+                    or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
+                raise ValueError("proving key does not describe this circuit (shape, break points, rank or column blocks differ)")
             self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
             self.srs_few = api.Srs(k, hp.g_monomial, None)
             omega = api.root_of_unity(k)
-            for name, n_cols, need_lag, keep_ext in (("sel", self.n_adv, False, False), ("sigma", self.n_perm, False, False), ("cst", 1, True, True),
-                                                     ("table", 1, True, True), ("lag", 3, False, True)):
+            # (name, polynomials held here, their place in the whole set, size of the whole set, Lagrange form kept, cosets kept)
+            plan = (("sel", self.my_adv, [(self.a_lo, self.a_hi)], self.n_adv, False, False), ("sigma", self.my_sig, self.sig_ranges, self.n_perm, False, False),
+                    ("cst", 1, None, 1, True, True), ("table", 1, None, 1, True, True), ("lag", 3, None, 3, False, True))
+            for name, n_cols, ranges, n_total, need_lag, keep_ext in plan:
                 coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
-                if coeff_h.shape != (n_cols, rows, 4):
+                commits = np.ascontiguousarray(doc[name + "_commits"])
+                if coeff_h.shape != (n_cols, rows, 4) or commits.shape != (n_total, 8):
                     raise ValueError("proving key: wrong shape for " + name)
                 coeff = api.DeviceBuffer(max(coeff_h.nbytes, 32))
                 if coeff_h.nbytes:
@@ -671,12 +688,14 @@ class ProverRounds:
                     lag = api.DeviceBuffer(coeff_h.nbytes)
                     check(lib.vdb_memcpy_d2d(lag.ptr, coeff.ptr, _sz(coeff_h.nbytes)))
                     check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
-                self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None,
-                                         commits=np.ascontiguousarray(doc[name + "_commits"]))
+                self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=commits,
+                                         ranges=ranges, n_total=n_total, replicated=ranges is None)
             self.instance_cells = [int(c) for c in doc["instance_cells"]]      # the public cells come with the key
+            if int(doc["instance_cells_are_the_default"][0]):
+                self.public_cells = list(self.instance_cells)
         self._upload_instance_cells()
-        if hp.ext_cols >= self.n_cols + 2:
-            check(lib.vdb_memcpy_d2d(hp.d_ext.at(self.n_cols * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
+        if hp.ext_cols >= self.my_adv + self.my_lk + 2:
+            check(lib.vdb_memcpy_d2d(hp.d_ext.at((self.my_adv + self.my_lk) * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         api.sync()
         return self._alloc_working_set()
 

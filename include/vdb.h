@@ -74,6 +74,12 @@ int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 /* Frees the library's cached work buffers (MSM buckets and sort records — up to half of the free HBM —, NTT staging); they
  * are re-created on demand.  For callers that need the memory between two phases.  Waits for queued work. */
 int vdb_scratch_release(void);
+/* Bytes the cached work buffers hold at the moment (what vdb_scratch_release would give back). */
+int vdb_scratch_held(size_t *bytes);
+/* Upper bound for the MSM's work space from now on (0 = the default: half of the free HBM, between 8 and 96 GiB — one batch for
+ * the whole k = 16 job).  A keygen that commits the fixed columns while the card is still empty sets a bound first: mapping 96 GiB
+ * of fresh HBM for a two-second MSM and handing it back costs more than the MSM (keygen). */
+int vdb_msm_set_scratch_cap(size_t bytes);
 int vdb_mem_info(size_t *free_bytes, size_t *total_bytes); /* HBM of the calling thread's device (hipMemGetInfo) */
 int vdb_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous on the library stream */
 int vdb_memset_dev(void *dst_dev, int value, size_t bytes);

@@ -236,19 +236,32 @@ void orc_eval_poly(fr_t *out, const fr_t *a, size_t n, const fr_t *x) {
  * way halo2's batch_invert does: a zero stays zero, so the product is zero from there on.  One column of n entries. */
 void orc_grand_product(fr_t *z, const fr_t *num, const fr_t *den, size_t n) {
   if (n == 0) return;
-  fr_t acc, inv, t;
+  /* the n - 1 denominators inverted with ONE field inversion (Montgomery's trick, what halo2's batch_invert does), zeros skipped */
+  fr_t *pre = (fr_t *)malloc(sizeof(fr_t) * n);
+  fr_t acc, t;
+  fr_from_u64(&acc, 1);
+  for (size_t i = 0; i + 1 < n; i++) {
+    pre[i] = acc;
+    if (!fr_is_zero(&den[i])) fr_mul(&acc, &acc, &den[i]);
+  }
+  fr_inv(&acc, &acc);
+  for (size_t i = n - 1; i-- > 0;) {
+    if (fr_is_zero(&den[i])) {
+      memset(&pre[i], 0, sizeof(fr_t));
+    } else {
+      fr_mul(&t, &acc, &pre[i]);
+      fr_mul(&acc, &acc, &den[i]);
+      pre[i] = t; /* 1 / den[i] */
+    }
+  }
   fr_from_u64(&acc, 1);
   for (size_t i = 0; i < n; i++) {
     z[i] = acc;
     if (i + 1 == n) break;
-    if (fr_is_zero(&den[i])) {
-      memset(&acc, 0, sizeof(acc));
-    } else {
-      fr_inv(&inv, &den[i]);
-      fr_mul(&t, &num[i], &inv);
-      fr_mul(&acc, &acc, &t);
-    }
+    fr_mul(&t, &num[i], &pre[i]);
+    fr_mul(&acc, &acc, &t);
   }
+  free(pre);
 }
 void orc_fr_from_canonical_batch(fr_t *o, const u256 *a, size_t n) {
   for (size_t i = 0; i < n; i++) fr_from_canonical(&o[i], &a[i]);

@@ -90,7 +90,15 @@ def check_quotient_identity(O, meta, ch, evals, instances=()):
 
 
 def quotient_numerator(O, meta, ch, evals, instances=()):
-    """gates + permutation + lookup expressions recombined from the evaluations (None: wrong number of public values)"""
+    """gates + permutation + lookup expressions recombined from the evaluations (None: wrong number of public values, or evaluations
+    missing where this key's shape asks for them — a key that does not describe the proof's circuit)"""
+    try:
+        return _quotient_numerator(O, meta, ch, evals, instances)
+    except IndexError:
+        return None
+
+
+def _quotient_numerator(O, meta, ch, evals, instances=()):
     R = O.R_MOD
     to_int = lambda a: O.fr_to_ints(np.asarray(a).reshape(1, 4))[0]
     b, g, yv, x = (to_int(ch[n]) for n in ("beta", "gamma", "y", "x"))
@@ -113,7 +121,8 @@ def quotient_numerator(O, meta, ch, evals, instances=()):
     # the permutation's columns: advice, lookup, the constants' fixed column, the instance column (from the public values)
     pcols = list(a0) + list(ev("cst")) + [instance_poly_at(O, instances, x, meta["k"])]
     n_cols, n_sets = len(pcols), len(z0)
-    assert n_cols == meta["n_cols"] + 2 and len(sg) == n_cols
+    if n_cols != meta["n_cols"] + 2 or len(sg) != n_cols:
+        return None
     acc = (acc * yv + l0 * (1 - z0[0])) % R
     acc = (acc * yv + ll * (z0[-1] * z0[-1] - z0[-1])) % R
     for i in range(1, n_sets):

@@ -67,6 +67,34 @@ def test_sharded_streamed_proof_and_the_verifier(tmp_path, O):
     assert one["sha256"] == two["sha256"]
 
 
+@pytest.mark.parametrize("circuit", ["kmeans", "merkle"])
+def test_sharded_proving_key_round_trip(tmp_path, circuit):
+    """The Keygen arm's files for a sharded deployment (src/scaffold/mod.rs:267-283 writes pk + pinning once, :290-291 reads them for
+    every proof): two ranks keygen and each writes its share of the proving key (ProverRounds.save_proving_key: its selectors, the
+    sigma columns of its sets, the whole set's commitments); a second launch loads the shares instead of running keygen and writes the
+    same proof bytes — which are the one-rank proof's.  A share is refused by another rank and by a run with another partition."""
+    one = _run(1, circuit, str(tmp_path / "p1.bin"), 0)
+    key = str(tmp_path / "key")
+    made = _run(2, circuit, str(tmp_path / "p2a.bin"), 29551, extra=("--save-key", key))
+    for r in (0, 1):
+        assert os.path.exists(f"{key}.rank{r}of2.npz")
+    loaded = _run(2, circuit, str(tmp_path / "p2b.bin"), 29552, extra=("--load-key", key))
+    assert loaded["key_loaded_from_file"] and not made["key_loaded_from_file"] and loaded["every_rank_wrote_the_same_bytes"]
+    assert open(tmp_path / "p2b.bin", "rb").read() == open(tmp_path / "p2a.bin", "rb").read() == open(tmp_path / "p1.bin", "rb").read()
+    assert loaded["sha256"] == one["sha256"]
+    # the verifying key gathered from the loaded shares is the keygen run's
+    with np.load(str(tmp_path / "p2b.bin") + ".vk.npz", allow_pickle=False) as a, np.load(str(tmp_path / "p1.bin") + ".vk.npz", allow_pickle=False) as b:
+        for name in a.files:
+            if name.startswith("fixed_"):
+                assert np.array_equal(a[name], b[name]), name
+    # a one-rank run cannot take rank 0's share of a two-rank key
+    os.replace(f"{key}.rank0of2.npz", f"{key}.rank0of1.npz")
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_prove.py"), "--circuit", circuit, "--load-key", key], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode != 0 and "proving key does not describe this circuit" in res.stderr
+
+
 def test_comm_over_rccl_on_the_device():
     """dist.Comm with the nccl (RCCL) backend, as many ranks as the box has GPUs (one here): the collectives' tensors live in HBM
     and the field sum moves the library's own device allocations through torch tensors — the interop the multi-GPU run depends on"""

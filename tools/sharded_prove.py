@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--block-cols", type=int, default=510)
     ap.add_argument("--ext-block-cols", type=int, default=None, help="hold this many coset columns (forces the streamed rounds)")
     ap.add_argument("--timed", type=int, default=0, help="also time this many proofs with fresh blinds")
+    ap.add_argument("--save-key", default=None, help="after keygen every rank writes its share of the proving key to <path>.rank<r>of<w>.npz")
+    ap.add_argument("--load-key", default=None, help="no keygen: every rank reads its share of the proving key from <path>.rank<r>of<w>.npz")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,8 +81,14 @@ def main():
     hp.ext_block_cols = args.ext_block_cols
     t0 = time.perf_counter()
     hp.setup()
-    pr = ProverRounds(hp, block_cols=args.block_cols, comm=comm).keygen()
+    key_file = lambda base: f"{base}.rank{rank}of{world}.npz"
+    if args.load_key:
+        pr = ProverRounds(hp, block_cols=args.block_cols, comm=comm).load_proving_key(key_file(args.load_key))
+    else:
+        pr = ProverRounds(hp, block_cols=args.block_cols, comm=comm).keygen()
     keygen_s = time.perf_counter() - t0
+    if args.save_key:
+        pr.save_proving_key(key_file(args.save_key))
     out = pr.prove(None, seed=args.seed)
     proof = out["proof"]
     digest = hashlib.sha256(proof).digest()
@@ -107,7 +115,8 @@ def main():
                                                         opened={str(r): v for r, v in out["opened"].items()})).encode(), dtype=np.uint8))
         print(json.dumps({"circuit": args.circuit, "world": world, "columns": pr.n_cols, "sets": pr.n_sets, "proof_bytes": len(proof),
                           "sha256": digest.hex(), "every_rank_wrote_the_same_bytes": same, "quotient_identity_at_x_holds": ok,
-                          "mock_prover_violations": pr.keygen_report.violations(), "n_instances": len(out["instances"]),
+                          "mock_prover_violations": pr.keygen_report.violations() if hasattr(pr, "keygen_report") else None, "key_loaded_from_file": bool(args.load_key),
+                          "n_instances": len(out["instances"]),
                           "shards": [[list(a), list(l)] for a, l in hp.shards], "my_set_ranges": pr.set_ranges, "foreign": pr.foreign, "stray": pr.stray,
                           "keygen_s": round(keygen_s, 2), "proof_ms": [round(w, 1) for w in wall]}), flush=True)
     assert same and ok

@@ -63,12 +63,13 @@ struct NttPass {
 
 __device__ __forceinline__ uint32_t bitrev_s(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// limbs after l9_renorm, value below 2^261 -> canonical eight words without a multiplication: subtract q r with
-// q = floor(top limb / (r_8 + 1)) (never too large, at most 2 too small), then two conditional subtractions
+// limbs below 2^32, value below 2^259 -> canonical eight words without a multiplication and without a carry pass of its own:
+// subtract q r with q = floor(top / (r_8 + 1)), top = l_8 + (l_7 >> 29) — the value's true top limb or one less (what limbs 0..6
+// and the low 29 bits of l_7 carry into bit 232 is at most 1) — so q is never too large and at most 3 too small; the subtraction's
+// 64-bit column accumulator propagates every carry on the way, and two conditional subtractions (2 r, then r) finish below 4 r
 __device__ __forceinline__ u256 l9_canon_wide(L9 x) {
-  l9_carry(x);
   constexpr uint32_t MU = 2840127191u;  // floor(2^53 / (0x30644e + 1))
-  const uint32_t q = __umulhi(x.l[8] << 3, MU) >> 24;
+  const uint32_t q = __umulhi((x.l[8] + (x.l[7] >> 29)) << 3, MU) >> 24;
   // x + q (2^261 - r) mod 2^261
   uint64_t acc = 0;
 #pragma unroll

@@ -116,19 +116,37 @@ __device__ __forceinline__ void lds_put(const L9Planes& P, uint32_t idx, const L
 // multiplier inputs stay below 6 * 2^29 per limb and nothing reaches 2^32.  Values stay below 22 r over ten stages.
 // `VS`: the first pass of vdb_coeff_to_cosets_dev (virtual columns, the slot's table of input factors) — an instantiation of its own,
 // so that the step's transforms carry none of its branches
-template <bool LAST, bool VS = false>
+// `CS` > 0: the pass size is a compile-time constant, and with it the tile shape (G = 1024 / 2^CS), the first stage (`CS0`), the carry
+// schedule (`CREN` = NttPass::ren_mask) and the Shoup table's resolution — the host launches such an instantiation for the sizes of
+// the prover's transforms (256- and 512-point passes) when the pass's parameters are exactly these, the generic one (CS = 0)
+// otherwise.  Every step then knows its stage: LDS offsets are immediates, the steps' variants that the schedule never takes are not
+// instantiated, the loops over a thread's elements have constant trip counts.
+template <uint32_t CS, uint32_t s, uint32_t step, class F>
+__device__ __forceinline__ void ntt_static_steps(F&& f) {
+  if constexpr (s < CS) {
+    f(std::integral_constant<uint32_t, s>{}, std::integral_constant<uint32_t, step>{});
+    ntt_static_steps<CS, (s + 1 < CS ? s + 2 : s + 1), step + 1>(f);
+  }
+}
+constexpr uint32_t ntt_spec_sh_res_log(uint32_t cs) { return cs == 8 ? 0u : 2u; }   // what ntt_dev's LDS budget gives 256- / 512-point passes
+template <bool LAST, bool VS = false, uint32_t CS = 0, uint32_t CS0 = 0, uint32_t CREN = 0>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict__ in, u256* __restrict__ out,
                                                          const u256* __restrict__ tw, const u256* __restrict__ tw_inter, NttPass p,
                                                          uint32_t tiles_per_col) {
   extern __shared__ uint4 smem[];
-  const uint32_t S = p.S, m = 1u << S, G = 1u << p.logG, T = m * G;
+  constexpr bool SPEC = CS > 0;
+  const uint32_t S = SPEC ? CS : p.S, P_logG = SPEC ? 10u - CS : p.logG, P_s0 = SPEC ? CS0 : p.s0, P_ren_mask = SPEC ? CREN : p.ren_mask;
+  const uint32_t P_sh_res_log = SPEC ? ntt_spec_sh_res_log(CS) : p.sh_res_log, P_sh_ns = SPEC ? ((1u << (CS ? CS - 1 : 0)) >> ntt_spec_sh_res_log(CS)) : p.sh_ns;
+  const int32_t P_sh_max_s = SPEC ? (int32_t)CS - 2 - (int32_t)ntt_spec_sh_res_log(CS) : p.sh_max_s;
+  const bool P_shoup = SPEC ? true : p.sh_tab != nullptr, P_blk0 = SPEC ? true : p.blk0 != 0;
+  const uint32_t m = 1u << S, G = 1u << P_logG, T = m * G;
   const uint32_t row = m + 1, NE = G * row, NW = m / 2 ? m / 2 : 1;
   L9Planes D, W;
   D.a = smem;
   D.b = D.a + NE;
   W.a = D.b + NE;
   W.b = W.a + NW;
-  const uint32_t NS = p.sh_tab ? p.sh_ns : 0;
+  const uint32_t NS = P_shoup ? P_sh_ns : 0;
   L9Planes WS, WQ;
   WS.a = W.b + NW;
   WS.b = WS.a + NS;
@@ -167,9 +185,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   uint64_t gstride;   // index step along g
   uint32_t i0 = 0, q0_base = 0, rdig = 0, rest = 1;
   if (!LAST) {
-    uint32_t tiles_inner = (1u << p.log_inner) >> p.logG;
+    uint32_t tiles_inner = (1u << p.log_inner) >> P_logG;
     uint32_t o = tile / tiles_inner;
-    i0 = (tile % tiles_inner) << p.logG;
+    i0 = (tile % tiles_inner) << P_logG;
     base = ((uint64_t)o << (S + p.log_inner)) + i0;
     jstride = 1ull << p.log_inner;
     gstride = 1;
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       gstride = 0;
     } else {
       rest = 1u << (p.log_n - S - p.prevS[0]);
-      q0_base = (tile / rest) << p.logG;
+      q0_base = (tile / rest) << P_logG;
       rdig = tile % rest;
       base = ((uint64_t)q0_base * rest + rdig) << S;
       jstride = 1;
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   }
   // load tile.  With s0 == 2 only the first quarter of every row is data; the two skipped stages would just copy
   // it into the other three quarters.
-  const uint32_t mload = m >> p.s0, Tload = mload * G;
+  const uint32_t mload = m >> P_s0, Tload = mload * G;
   L9 Z0, Z1, Z2;
   if (!VS && p.coset) {
     Z1 = l9_split(p.zeta1);
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
     uint32_t j, g;
     if (!LAST) {
       g = e & (G - 1);
-      j = e >> p.logG;
+      j = e >> P_logG;
     } else {
       j = e & (mload - 1);
       g = e / mload;
@@ -234,17 +252,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
 #pragma unroll
       for (int k = 0; k < 9; k++) v.l[k] = 0;
     }
-    for (uint32_t rep = 0; rep < (1u << p.s0); rep++) lds_put(D, g * row + j + rep * mload, v);
+    for (uint32_t rep = 0; rep < (1u << P_s0); rep++) lds_put(D, g * row + j + rep * mload, v);
   }
   __syncthreads();
   // butterfly steps: two stages at a time on four elements held in registers (one LDS round trip and one barrier
   // per two stages), a single radix-2 stage at the end when the number of stages is odd
-  uint32_t step = 0;
-  for (uint32_t s = p.s0; s < S; step++) {
+  auto do_step = [&](auto s_c, auto step_c) {
+    const uint32_t s = s_c, step = step_c;
     const uint32_t logh = S - 1 - s, h = 1u << logh;
-    const bool ren = (p.ren_mask >> step) & 1;
+    const bool ren = (P_ren_mask >> step) & 1;
     if (s + 1 < S) {
-      const uint32_t h2 = h >> 1;
+      const uint32_t h2 = h >> 1, lh1 = logh ? logh - 1 : 0;   // (logh >= 1 here; the guard keeps the dead instantiations of a compile-time schedule well formed)
       // (the body is instantiated per (first step, carry pass) combination: a run-time `if (ren)` inside one body makes the
       // compiler merge the two register sets with ~30 moves per step on the path that does not renormalise)
       // `s2_c`: the step that starts at stage 2.  Its block 0 — a quarter of its butterflies — has the twiddles of the very first step
@@ -255,16 +273,16 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         for (uint32_t t = tid; t < T / 4; t += NTT_THREADS) {
           uint32_t g, r, blk;
           if (S2) {
-            const uint32_t lb = p.logG + logh - 1;   // log2(threads per block) = log2(G h2)
+            const uint32_t lb = P_logG + lh1;   // log2(threads per block) = log2(G h2)
             // (rotated by the workgroup's number: a CU's resident workgroups then put their light wavefront on different SIMDs)
             blk = ((t >> lb) + blockIdx.x + (blockIdx.x >> 8)) & 3u;
-            g = (t >> (logh - 1)) & (G - 1);
+            g = (t >> lh1) & (G - 1);
             r = t & (h2 - 1);
           } else {
             const uint32_t gi = t & ((m >> 2) - 1);
             g = t >> (S - 2);
             r = gi & (h2 - 1);
-            blk = gi >> (logh - 1);
+            blk = gi >> lh1;
           }
           const uint32_t j0 = g * row + (blk << (logh + 1)) + r;
           L9 x0 = lds_get(D, j0), x1 = lds_get(D, j0 + h2), x2 = lds_get(D, j0 + h), x3 = lds_get(D, j0 + h + h2);
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
             l9_carry(a1);
             L9 t3;
             if (SHOUP) {
-              const uint32_t iq = (m >> 2) >> p.sh_res_log;
+              const uint32_t iq = (m >> 2) >> P_sh_res_log;
               t3 = l9_mul_shoup<Fr>(a3, lds_get(WS, iq), lds_get(WQ, iq));
             } else {
               t3 = l9_mul(a3, lds_get(W, m >> 2));
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
           } else if (SHOUP) {
             // both stages' twiddles lie in the quarter- (or full-) resolution table of plain residues and quotients: the products
             // come out below 3 r with normalised limbs, which is all the sums and differences below ask of them
-            const uint32_t e = bitrev_s(blk, s) << logh, rl = p.sh_res_log;
+            const uint32_t e = bitrev_s(blk, s) << logh, rl = P_sh_res_log;
             const uint32_t i0 = e >> rl, i1 = (e >> 1) >> rl, i2 = ((e >> 1) + (m >> 2)) >> rl;
             const L9 ws = lds_get(WS, i0), wq = lds_get(WQ, i0);
             const L9 t2 = l9_mul_shoup<Fr>(x2, ws, wq), t3 = l9_mul_shoup<Fr>(x3, ws, wq);
@@ -340,11 +358,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
       };
       using T_ = std::true_type;
       using F_ = std::false_type;
-      const bool s2 = s == 2 && !ren && p.blk0;   // (the schedule never carries at the start of this step; if it ever did: the general body)
+      const bool s2 = s == 2 && !ren && P_blk0;   // (the schedule never carries at the start of this step; if it ever did: the general body)
       if (s == 0) {
         if (ren) radix4(T_{}, T_{}, F_{}, F_{});
         else radix4(T_{}, F_{}, F_{}, F_{});
-      } else if (p.sh_tab && (int32_t)s <= p.sh_max_s) {
+      } else if (P_shoup && (int32_t)s <= P_sh_max_s) {
         if (ren) radix4(F_{}, T_{}, T_{}, F_{});
         else if (s2) radix4(F_{}, F_{}, T_{}, T_{});
         else radix4(F_{}, F_{}, T_{}, F_{});
@@ -353,7 +371,6 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         else if (s2) radix4(F_{}, F_{}, F_{}, T_{});
         else radix4(F_{}, F_{}, F_{}, F_{});
       }
-      s += 2;
     } else {
       for (uint32_t b = tid; b < T / 2; b += NTT_THREADS) {
         const uint32_t g = b >> (S - 1), pj = b & ((m >> 1) - 1);
@@ -368,9 +385,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
         lds_put(D, a0, l9_add(u, v));
         lds_put(D, a1, l9_sub(u, v, p.ckp));
       }
-      s += 1;
     }
     __syncthreads();
+  };
+  if constexpr (SPEC) {
+    ntt_static_steps<CS, CS0, 0>(do_step);
+  } else {
+    uint32_t step = 0;
+    for (uint32_t s = P_s0; s < S; step++) {
+      do_step(s, step);
+      s += (s + 1 < S) ? 2 : 1;
+    }
   }
   // write out: the inter-pass twiddle product (or the 1/n product of an inverse transform) brings the value below 2r
   // on its own; a forward transform's last pass reduces without a product (l9_canon_wide)
@@ -388,7 +413,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
 #pragma unroll
     for (uint32_t it = 0; it < EPT; it++) {
       const uint32_t e = tid + it * NTT_THREADS;
-      const uint32_t g = e & (G - 1), q = e >> p.logG;
+      const uint32_t g = e & (G - 1), q = e >> P_logG;
       const uint64_t ex = ((uint64_t)q * ((uint64_t)i0 + g)) << (p.log_n - S - p.log_inner);
       if (e < T) twv[it] = ld256(tw_inter + ex);
     }
@@ -397,7 +422,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const u256* __restrict
   for (uint32_t it = 0; it < EPT; it++) {
     const uint32_t e = tid + it * NTT_THREADS;
     if (e >= T) break;
-    uint32_t g = e & (G - 1), q = e >> p.logG;
+    uint32_t g = e & (G - 1), q = e >> P_logG;
     L9 v = lds_get(D, g * row + bitrev_s(q, S));
     if (p.ren_out) l9_renorm(v);
     if (!LAST) {
@@ -744,19 +769,34 @@ int ntt_dev(u256* data, u256* out_or_null, size_t n_cols, uint32_t log_n, const 
           raised = true;
         }
       }
-      if (last) {
-        {
-          VDB_PROF("k_ntt_pass");
-          if (l == 0 && vslots) hipLaunchKernelGGL((k_ntt_pass<true, true>), grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
-          else hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw, p, tiles);
-        }
-      } else {
-        {
-          VDB_PROF("k_ntt_pass");
-          if (l == 0 && vslots) hipLaunchKernelGGL((k_ntt_pass<false, true>), grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, tw_scaled, p, tiles);
-          else hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, l == 0 ? tw_scaled : tw, p, tiles);
+      // the instantiation with this pass's size, first stage, carry schedule and Shoup resolution as compile-time constants when there is
+      // one (the 256- and 512-point passes of the prover's transforms), the generic kernel otherwise (VDB_NTT_SPEC=0: always)
+      static const bool spec_on = !(getenv("VDB_NTT_SPEC") && getenv("VDB_NTT_SPEC")[0] == '0');
+      const u256* twi = last ? tw : (l == 0 ? tw_scaled : tw);
+      const bool vs = (l == 0 && vslots);
+      auto spec = [&](uint32_t cs, uint32_t cs0, uint32_t cren) {
+        const uint32_t rl = ntt_spec_sh_res_log(cs);
+        return spec_on && L > 1 && p.S == cs && p.s0 == cs0 && p.ren_mask == cren && p.logG == 10 - cs && p.sh_tab && p.blk0 && p.sh_res_log == rl &&
+               p.sh_ns == ((1u << (cs - 1)) >> rl) && p.sh_max_s == (int32_t)cs - 2 - (int32_t)rl;
+      };
+#define NTT_LAUNCH(...) hipLaunchKernelGGL((k_ntt_pass<__VA_ARGS__>), grid, dim3(NTT_THREADS), lds, c.stream, src, out, tw, twi, p, tiles)
+      {
+        VDB_PROF("k_ntt_pass");
+        if (last) {
+          if (vs) NTT_LAUNCH(true, true);
+          else if (spec(8, 0, 4)) NTT_LAUNCH(true, false, 8, 0, 4);
+          else if (spec(9, 0, 20)) NTT_LAUNCH(true, false, 9, 0, 20);
+          else NTT_LAUNCH(true, false);
+        } else {
+          if (vs && spec(8, 0, 4)) NTT_LAUNCH(false, true, 8, 0, 4);
+          else if (vs) NTT_LAUNCH(false, true);
+          else if (spec(8, 0, 4)) NTT_LAUNCH(false, false, 8, 0, 4);
+          else if (spec(9, 2, 4)) NTT_LAUNCH(false, false, 9, 2, 4);
+          else if (spec(9, 0, 20)) NTT_LAUNCH(false, false, 9, 0, 20);
+          else NTT_LAUNCH(false, false);
         }
       }
+#undef NTT_LAUNCH
       VDB_LAUNCH_CHECK();
       done_bits += S[l];
     }

@@ -52,7 +52,8 @@ with open(f"profiles/{tag}{suffix}_pmc_summary.csv", "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-proof (tools/profile_round.sh)\n")
     f.write("# Counter_Value is in KiB as reported; gfx950 correction (MI355X_MICROARCH.md §HBM): HBM read bytes = 2 * FETCH_SIZE * 1024\n")
     f.write("# for wide coalesced 16 B/lane streams, HBM write bytes = WRITE_SIZE * 1024.\n")
-    f.write("counter,kernel,launches,sum_counter_KiB,per_launch_KiB,sum_ms\n")
+    w = csv.writer(f)       # (kernel names of templates hold commas: quoted)
+    w.writerow(["counter", "kernel", "launches", "sum_counter_KiB", "per_launch_KiB", "sum_ms"])
     for kind, k, n, v, ms in sorted(rows, key=lambda r: (r[0], -r[3])):
-        f.write(f"{kind},{k},{n},{v:.1f},{v / n:.1f},{ms:.3f}\n")
+        w.writerow([kind, k, n, f"{v:.1f}", f"{v / n:.1f}", f"{ms:.3f}"])
 print("wrote", f"profiles/{tag}{suffix}_kernel_stats.csv", f"profiles/{tag}{suffix}_pmc_summary.csv")

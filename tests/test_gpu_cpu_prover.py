@@ -166,3 +166,31 @@ def test_baseline_c1_euclidean_distance_k13(api, O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_nearest_vector_circuit(api, O):
+    """nearest_vector over 6 x 4 vectors (examples/query.rs:32-58 without the Merkle half; tests/vectordb/mod.rs:220-247 assigns the
+    query, then the vectors), the result vector public: the same byte-for-byte comparison"""
+    from halo2_vectordb_amd import circuit_sym as CS
+    from halo2_vectordb_amd.pipeline import NearestHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import prover as PV
+    n, dim, k, P, L = 6, 4, 12, 48, 11
+    hp = NearestHotPath(n=n, dim=dim, k=k, P=P, L=L, tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.keygen_report.violations() == 0
+        rows = O.quantize(hp.vectors_f64, P)                    # row 0: the query, rows 1..n: the database
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        c.assign_witnesses(rows[0])
+        c.assign_witnesses(rows[1:])
+        ind, res = c.nearest_vector("euclidean", rows[0], rows[1:], P=P, L=L)
+        cm, (_ind, res_cells) = CS.build_nearest("euclidean", n, dim, P, L, builder=None)
+        cs = PV.Circuit(k, L, c.break_points(), c.selectors(), c.n_lookup, cm.copy_of, cm.const_idx, cm.consts, cm.lookup_src, [int(x) for x in res_cells])
+        _pk, outs = _compare(O, PV, hp, pr, cs, c.advice(), c.lookup(), seeds=(21,))
+        assert outs[0]["instances"] == [int(v) for v in O.fr_to_ints(res)]      # examples/query.rs:58 make_public.extend(result)
+        want = int(np.argmin(np.linalg.norm(hp.vectors_f64[1:] - hp.vectors_f64[0], axis=1)))
+        assert [int(v) for v in O.fr_to_ints(ind)].index(1) == want
+    finally:
+        pr.free()
+        hp.free()

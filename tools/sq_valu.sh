@@ -12,10 +12,11 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
-out = open("$R/gpurun_out/sq_valu_summary.csv", "w")
-out.write("kernel,launches,SQ_INSTS_VALU,SQ_ACTIVE_INST_VALU,GRBM_GUI_ACTIVE\n")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:14]:
-    out.write(f"{k},{n[k]},{v.get('SQ_INSTS_VALU',0):.0f},{v.get('SQ_ACTIVE_INST_VALU',0):.0f},{v.get('GRBM_GUI_ACTIVE',0):.0f}\n")
+out = open("$R/gpurun_out/sq_valu_summary.csv", "w", newline="")
+w = csv.writer(out)      # (template kernels' names hold commas: quoted)
+w.writerow(["kernel", "launches", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:16]:
+    w.writerow([k, n[k], f"{v.get('SQ_INSTS_VALU',0):.0f}", f"{v.get('SQ_ACTIVE_INST_VALU',0):.0f}", f"{v.get('GRBM_GUI_ACTIVE',0):.0f}"])
 out.close()
 print(open("$R/gpurun_out/sq_valu_summary.csv").read())
 PY

@@ -274,6 +274,7 @@ def whole_proof(api, rank=0, world=1, comm=None, small=False):
     same proof bytes; `proof_ms` is then the slowest rank's wall time (barrier before, max over ranks after)."""
     from halo2_vectordb_amd.pipeline import KmeansHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
+    api.alloc_stats(reset=True)
     t0 = time.perf_counter()
     if small:                        # functional check of this very code path (tests): a circuit of a few hundred columns
         hp = KmeansHotPath(n=16, dim=8, K=2, I=2, k=12, P=48, L=11, metric="cosine", col_shard=(rank, world))
@@ -281,8 +282,12 @@ def whole_proof(api, rank=0, world=1, comm=None, small=False):
         hp = KmeansHotPath(n=256, dim=128, K=4, I=8, k=16, P=48, L=15, metric="cosine", col_shard=(rank, world))
         hp.ext_block_cols = 256      # the rounds recompute the cosets block by block; HBM goes to the proving key
     hp.setup()
+    api.sync()
+    setup_s = time.perf_counter() - t0
     pr = ProverRounds(hp, comm=comm).keygen()
+    api.sync()
     keygen_s = time.perf_counter() - t0
+    alloc_s, alloc_bytes, _n = api.alloc_stats()
 
     def everyone(ms):
         """the slowest rank's figure"""
@@ -338,7 +343,11 @@ def whole_proof(api, rank=0, world=1, comm=None, small=False):
            "n_gpus": world, "proof_ms": wall, "hot_path_ms": min(hot), "hot_path_constraints_per_s": (hp.n_cells + hp.n_lookup) / (min(hot) * 1e-3),
            "host_transcript_ms": round(host_ms["transcript"], 1), "device_ms": sum(T.values()), "device_stage_ms": {k: round(v, 2) for k, v in T.items()},
            "constraints_per_s": (hp.n_cells + hp.n_lookup) / (wall * 1e-3), "proof_bytes": len(out["proof"]),
-           "keygen_and_setup_s": round(keygen_s, 1), "fixed_cosets_resident": bool(pr.fixed_cosets_resident),
+           "keygen_and_setup_s": round(keygen_s, 1), "setup_s": round(setup_s, 1),
+           # how much of it the driver spent inside device allocations: instant on a card whose HBM is clean, ~30 ms / GiB where HBM has
+           # to be mapped or cleared first (another process's or an earlier free's leftovers) — the part that varies from box to box
+           "keygen_and_setup_alloc_s": round(alloc_s, 1), "keygen_and_setup_alloc_gb": round(alloc_bytes / 2**30, 1),
+           "fixed_cosets_resident": bool(pr.fixed_cosets_resident),
            "amdahl": amdahl,
            "n_instances": len(out["instances"]),        # the public statement: the K x dim centroid words, tied to the instance column
            "mock_prover_violations": rep.violations(),

@@ -89,8 +89,9 @@ _SIGNATURES = {
     "vdb_transcript_write_points": [_P, _P, _SZ], "vdb_transcript_write_scalars": [_P, _P, _SZ], "vdb_transcript_common_points": [_P, _P, _SZ], "vdb_transcript_common_scalars": [_P, _P, _SZ],
     "vdb_transcript_write_scalar": [_P, _P], "vdb_transcript_write_point": [_P, _P], "vdb_transcript_squeeze": [_P, _P],
     "vdb_transcript_proof_len": [_P, _P], "vdb_transcript_proof_bytes": [_P, _P, _SZ],
-    "vdb_scratch_release": [], "vdb_mem_info": [_P, _P], "vdb_scratch_held": [_P], "vdb_msm_set_scratch_cap": [_SZ],
+    "vdb_scratch_release": [], "vdb_mem_info": [_P, _P], "vdb_scratch_held": [_P], "vdb_msm_set_scratch_cap": [_SZ], "vdb_alloc_stats": [_P, _P, _P, _I],
     "vdb_permutation_mapping_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P, _U64, _P],
+    "vdb_permutation_mapping_ws_dev": [_P, _U64, _U64, _P, _U64, _U32, _P, _U64, _U64, _U64, _P, _U64, _P, _P, _SZ],
     "vdb_gather_fr_dev": [_P, _P, _SZ, _P], "vdb_copymap_init_dev": [_U64, _U64, _P, _P, _P, _P],
     "vdb_copymap_place_dev": [_P, _P, _P, _U64, _P, _U64, _P, _P, _P, _U64, _U64, _U64, _U64, _P, _P, _P, _P],
     "vdb_copymap_finish_dev": [_P, _P, _U64, _P, _U64, _P, _P, _P], "vdb_mock_check_instances_dev": [_P, _U64, _P, _P, _U64, _P],

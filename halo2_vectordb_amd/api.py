@@ -749,6 +749,13 @@ def scratch_held():
     return b.value
 
 
+def alloc_stats(reset=False):
+    """(seconds, bytes, calls) of the device allocations made through the library since start / the last reset (vdb_alloc_stats)"""
+    sec, b, n = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.load().vdb_alloc_stats(ctypes.byref(sec), ctypes.byref(b), ctypes.byref(n), 1 if reset else 0)
+    return sec.value, b.value, n.value
+
+
 KEYGEN_SCRATCH_CAP = 16 << 30      # bound of the MSM's work space while setup / keygen allocate the proving key (vdb_msm_set_scratch_cap)
 
 

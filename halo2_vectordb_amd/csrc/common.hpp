@@ -68,6 +68,9 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // returns nullptr (and sets error) on failure
 void* scratch_get(int slot, size_t bytes);
+// hipMalloc with its wall time and size added to the process's allocation statistics (vdb_alloc_stats): on this driver an allocation
+// is instant or costs seconds — fresh HBM is mapped (and HBM another process or an earlier free left behind cleared) at ~30 ms / GiB
+hipError_t timed_malloc(void** p, size_t bytes);
 
 #define VDB_HIP(expr)                                                      \
   do {                                                                     \

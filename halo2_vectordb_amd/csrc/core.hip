@@ -1,5 +1,8 @@
 // libvdb_hip core: lifecycle (b0), device memory helpers, elementwise Fr kernels, batch inversion,
 // and the Montgomery-multiplication micro-benchmark used to calibrate the integer-ALU roofline.
+#include <atomic>
+#include <chrono>
+
 #include "common.hpp"
 
 namespace vdb {
@@ -38,6 +41,15 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
   return e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP;
 }
+static std::atomic<uint64_t> g_alloc_ns{0}, g_alloc_bytes{0}, g_alloc_calls{0};
+hipError_t timed_malloc(void** p, size_t bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMalloc(p, bytes);
+  g_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  g_alloc_bytes += bytes;
+  g_alloc_calls += 1;
+  return e;
+}
 void* scratch_get(int slot, size_t bytes) {
   Context& c = ctx();
   if (slot == 2 && c.msm_pending) {
@@ -50,7 +62,7 @@ void* scratch_get(int slot, size_t bytes) {
   c.scratch[slot] = nullptr;
   c.scratch_bytes[slot] = 0;
   size_t want = bytes + bytes / 8;
-  hipError_t e = hipMalloc(&c.scratch[slot], want);
+  hipError_t e = timed_malloc(&c.scratch[slot], want);
   if (e != hipSuccess) {
     hip_fail(e, "hipMalloc(scratch)", __FILE__, __LINE__);
     return nullptr;
@@ -304,7 +316,7 @@ void vdb_shutdown(void) {
 int vdb_malloc(void** dptr, size_t bytes) {
   VDB_REQUIRE_INIT();
   VDB_ARG(dptr, "null pointer");
-  VDB_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  VDB_HIP(timed_malloc(dptr, bytes ? bytes : 1));
   return VDB_OK;
 }
 int vdb_free(void* dptr) {
@@ -329,6 +341,17 @@ int vdb_mem_info(size_t* free_bytes, size_t* total_bytes) {
   VDB_REQUIRE_INIT();
   VDB_ARG(free_bytes && total_bytes, "null pointer");
   VDB_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return VDB_OK;
+}
+int vdb_alloc_stats(double* seconds, uint64_t* bytes, uint64_t* calls, int reset) {
+  if (seconds) *seconds = (double)g_alloc_ns.load() * 1e-9;
+  if (bytes) *bytes = g_alloc_bytes.load();
+  if (calls) *calls = g_alloc_calls.load();
+  if (reset) {
+    g_alloc_ns = 0;
+    g_alloc_bytes = 0;
+    g_alloc_calls = 0;
+  }
   return VDB_OK;
 }
 int vdb_msm_set_scratch_cap(size_t bytes) {

@@ -277,9 +277,23 @@ extern "C" int vdb_copymap_finish_dev(const int64_t* copy_of_dev, const int64_t*
   return VDB_OK;
 }
 
+extern "C" int vdb_permutation_mapping_ws_dev(int64_t* parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t* break_points, uint64_t n_bp, uint32_t k,
+                                              const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
+                                              const int64_t* instance_cells_dev, uint64_t n_instances, uint64_t* mapping_dev, void* work_dev,
+                                              size_t work_bytes);
 extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t* break_points, uint64_t n_bp, uint32_t k,
                                            const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
                                            const int64_t* instance_cells_dev, uint64_t n_instances, uint64_t* mapping_dev) {
+  return vdb_permutation_mapping_ws_dev(parent_dev, n_cells, n_consts, break_points, n_bp, k, lookup_src_dev, n_lookup, lookup_rows, n_cols, instance_cells_dev,
+                                        n_instances, mapping_dev, nullptr, 0);
+}
+// `work_dev` / `work_bytes`: device memory the caller lends for the sort records (4 x 8 B per grid position of a copy class + the sort's
+// histograms: 51 GiB for the k = 16 cosine k-means) — a keygen hands over the buffer its sigma columns and selectors will fill
+// afterwards, so that the records' memory is neither mapped nor handed back; too small or null: the call allocates its own
+extern "C" int vdb_permutation_mapping_ws_dev(int64_t* parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t* break_points, uint64_t n_bp, uint32_t k,
+                                              const int64_t* lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
+                                              const int64_t* instance_cells_dev, uint64_t n_instances, uint64_t* mapping_dev, void* work_dev,
+                                              size_t work_bytes) {
   VDB_REQUIRE_INIT();
   VDB_ARG(parent_dev && mapping_dev && (break_points || n_bp == 0) && k <= 28 && n_cells >= 1, "bad argument");
   const uint64_t rows = 1ull << k, n_adv = n_bp + 1;
@@ -335,10 +349,29 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   PmShape s{n_cells, n_bp, n_lookup, n_consts, n_instances, n_adv, lookup_rows ? lookup_rows : 1, n_cols};
   const uint64_t total = n_cells + n_bp + n_lookup + n_consts + n_instances;
   uint64_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
-  for (uint64_t** q : {&keys, &vals, &keys2, &vals2}) {
-    hipError_t e = hipMalloc(q, total * sizeof(uint64_t));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(permutation records: 4 x 8 B per grid position of a copy class)", __FILE__, __LINE__);
-    guard.p.push_back(*q);
+  // the sort's histograms are sized first, so that a lent workspace is known to hold everything
+  size_t tmp_bytes = 0;
+  {
+    rocprim::double_buffer<uint64_t> dk0(nullptr, nullptr), dv0(nullptr, nullptr);
+    VDB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk0, dv0, (size_t)total, 0u, 64u, cx.stream));
+  }
+  const size_t rec_bytes = (total * sizeof(uint64_t) + 255) / 256 * 256, tmp_room = (tmp_bytes + 255) / 256 * 256 + 256;
+  void* tmp = nullptr;
+  if (work_dev && work_bytes >= 4 * rec_bytes + tmp_room && ((uintptr_t)work_dev & 255) == 0) {
+    uint8_t* w = (uint8_t*)work_dev;
+    keys = (uint64_t*)w;
+    vals = (uint64_t*)(w + rec_bytes);
+    keys2 = (uint64_t*)(w + 2 * rec_bytes);
+    vals2 = (uint64_t*)(w + 3 * rec_bytes);
+    tmp = w + 4 * rec_bytes;
+  } else {
+    for (uint64_t** q : {&keys, &vals, &keys2, &vals2}) {
+      hipError_t e = timed_malloc((void**)q, total * sizeof(uint64_t));
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc(permutation records: 4 x 8 B per grid position of a copy class)", __FILE__, __LINE__);
+      guard.p.push_back(*q);
+    }
+    VDB_HIP(timed_malloc(&tmp, tmp_room));
+    guard.p.push_back(tmp);
   }
   {
     VDB_PROF("k_pm_records");
@@ -360,11 +393,15 @@ extern "C" int vdb_permutation_mapping_dev(int64_t* parent_dev, uint64_t n_cells
   while (end_bit < 64 && ((n_cells + n_consts) >> end_bit)) end_bit++;
   // double-buffered: the two copies of the records are the sort's own ping-pong storage, the temporary storage is histograms only
   rocprim::double_buffer<uint64_t> dk(keys, keys2), dv(vals, vals2);
-  size_t tmp_bytes = 0;
-  VDB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)total, 0u, end_bit, cx.stream));
-  void* tmp = nullptr;
-  VDB_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-  guard.p.push_back(tmp);
+  {
+    size_t need = 0;
+    VDB_HIP(rocprim::radix_sort_pairs(nullptr, need, dk, dv, (size_t)total, 0u, end_bit, cx.stream));
+    if (need > tmp_room) {
+      set_error("permutation mapping: the sort asks for more temporary storage than was sized");
+      return VDB_ERR_HIP;
+    }
+    tmp_bytes = need;
+  }
   {
     VDB_PROF("rocprim_radix_sort_pairs");
     VDB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, (size_t)total, 0u, end_bit, cx.stream));

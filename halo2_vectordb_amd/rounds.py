@@ -84,6 +84,12 @@ class _View:
     def at(self, offset):
         return ctypes.c_void_p(self.ptr.value + int(offset))
 
+    def download(self, shape, dtype=np.uint64, offset=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        check(api.init().vdb_memcpy_d2h(api._p(out), self.at(offset), _sz(out.nbytes)))
+        return out
+
     def free(self):
         pass
 
@@ -418,10 +424,17 @@ class ProverRounds:
         d_map = api.DeviceBuffer(self.n_perm * rows * 8)
         bp64 = np.ascontiguousarray(hp.bp, dtype=np.uint64)
         self._upload_instance_cells()
-        _chk(lib.vdb_permutation_mapping_dev(d_parent.ptr, ctypes.c_uint64(hp.n_cells), ctypes.c_uint64(len(self.consts)), api._p(bp64), ctypes.c_uint64(len(bp64)), k,
-                                             lsrc_ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
-                                             ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols),
-                                             self.d_inst_cells.ptr, ctypes.c_uint64(len(self.instance_cells)), d_map.ptr))
+        # The key's two big buffers — the sigma columns of my sets, the selectors of my advice columns — are ONE allocation, made
+        # before the permutation is built and lent to it for its sort records (51 GiB at C4'): HBM that is mapped once and never handed
+        # back (mapping or clearing HBM costs this driver ~30 ms / GiB, vdb_alloc_stats).
+        if getattr(self, "d_key", None) is not None:
+            self.d_key.free()
+        self.d_key = api.DeviceBuffer(max(self.my_sig + self.my_adv, 1) * rows * B)
+        _chk(lib.vdb_permutation_mapping_ws_dev(d_parent.ptr, ctypes.c_uint64(hp.n_cells), ctypes.c_uint64(len(self.consts)), api._p(bp64), ctypes.c_uint64(len(bp64)), k,
+                                                lsrc_ptr if tie_lookups else None, ctypes.c_uint64(hp.n_lookup if tie_lookups else 0),
+                                                ctypes.c_uint64(rows - MINIMUM_ROWS), ctypes.c_uint64(self.n_cols),
+                                                self.d_inst_cells.ptr, ctypes.c_uint64(len(self.instance_cells)), d_map.ptr,
+                                                self.d_key.ptr, _sz(self.d_key.nbytes)))
         d_parent.free()
         if d_lsrc is not None:
             d_lsrc.free()
@@ -439,7 +452,7 @@ class ProverRounds:
             raise ValueError("a sharded key keeps the packed mapping: column and row of a cell must fit 32 bits")
         # sigma columns: every rank builds the cycles of the whole circuit (the copy classes cross all columns) and keeps the
         # columns of its own sets
-        d_sigma = api.DeviceBuffer(max(self.my_sig, 1) * rows * B)
+        d_sigma = _View(self.d_key, 0, self.my_sig * rows * B)
         off = 0
         for lo, hi in self.sig_ranges:
             _chk(lib.vdb_permutation_sigma_dev(d_map.at(lo * rows * 8), _sz(hi - lo), k, api._p(self.delta), d_sigma.at(off * rows * B))
@@ -450,11 +463,15 @@ class ProverRounds:
             d_map.free()
         self._fixed_poly("sigma", d_sigma, self.my_sig, keep_lag=False, keep_ext=False, ranges=self.sig_ranges, n_total=self.n_perm)
         # gate selectors (after the permutation's work space is gone: both are tens of GB at BASELINE sizes), of my advice columns
-        d_q = api.DeviceBuffer(self.n_adv * rows * B)
-        _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
-        d_flags.free()
-        if self.my_adv != self.n_adv:
-            d_mine = api.DeviceBuffer(max(self.my_adv, 1) * rows * B)
+        d_mine = _View(self.d_key, self.my_sig * rows * B, self.my_adv * rows * B)
+        if self.my_adv == self.n_adv:
+            d_q = d_mine
+            _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+            d_flags.free()
+        else:       # a rank of a sharded run lays out every column's selectors and keeps its own
+            d_q = api.DeviceBuffer(self.n_adv * rows * B)
+            _chk(lib.vdb_layout_selectors_dev(d_flags.ptr, ctypes.c_uint64(hp.n_cells), api._p(hp.bp), ctypes.c_uint64(len(hp.bp)), k, d_q.ptr))
+            d_flags.free()
             _chk(lib.vdb_memcpy_d2d(d_mine.ptr, d_q.at(self.a_lo * rows * B), _sz(self.my_adv * rows * B)))
             api.sync()
             d_q.free()
@@ -1441,7 +1458,7 @@ class ProverRounds:
         self.fixed = {}
         self._vk_digest = None
         for name in ("pool_der", "d_lklag", "d_lag_a", "d_lag_s", "d_ea", "d_eb", "d_ez", "d_zf", "d_zlast", "d_h", "d_h2", "d_h3", "d_h4", "d_hg", "d_comb", "d_quot", "d_map32", "d_inst_lag", "d_inst_coeff", "d_inst_ext", "d_inst_cells",
-                     "d_foreign_lag", "d_foreign_coeff", "d_zhalo", "d_rand", "d_hf"):
+                     "d_foreign_lag", "d_foreign_coeff", "d_zhalo", "d_rand", "d_hf", "d_key"):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()

@@ -76,6 +76,9 @@ int vdb_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int vdb_scratch_release(void);
 /* Bytes the cached work buffers hold at the moment (what vdb_scratch_release would give back). */
 int vdb_scratch_held(size_t *bytes);
+/* Wall time, bytes and number of the device allocations this process made through the library (vdb_malloc, the work buffers, keygen's
+ * sort records) since start or the last reset: what a setup / keygen time consists of when HBM has to be mapped or cleared first. */
+int vdb_alloc_stats(double *seconds, uint64_t *bytes, uint64_t *calls, int reset);
 /* Upper bound for the MSM's work space from now on (0 = the default: half of the free HBM, between 8 and 96 GiB — one batch for
  * the whole k = 16 job).  A keygen that commits the fixed columns while the card is still empty sets a bound first: mapping 96 GiB
  * of fresh HBM for a two-second MSM and handing it back costs more than the MSM (keygen). */
@@ -483,6 +486,11 @@ int vdb_transcript_proof_bytes(const vdb_transcript *tr, uint8_t *out, size_t ca
 int vdb_permutation_mapping_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
                                 const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
                                 const int64_t *instance_cells_dev, uint64_t n_instances, uint64_t *mapping_dev);
+/* The same with device memory lent for the sort records (4 x 8 B per grid position of a copy class + the sort's histograms): a keygen
+ * passes the buffer its sigma columns and selectors fill afterwards; null or too small: the call allocates its own, as above. */
+int vdb_permutation_mapping_ws_dev(int64_t *parent_dev, uint64_t n_cells, uint64_t n_consts, const uint64_t *break_points, uint64_t n_bp, uint32_t k,
+                                   const int64_t *lookup_src_dev, uint64_t n_lookup, uint64_t lookup_rows, uint64_t n_cols,
+                                   const int64_t *instance_cells_dev, uint64_t n_instances, uint64_t *mapping_dev, void *work_dev, size_t work_bytes);
 /* The constraint map itself built on the device.  halo2-base records one equality per `Existing` / `Constant` cell while the closure
  * runs (reached from src/scaffold/mod.rs:378-400); the gadgets' structure is data independent and repeats, so a caller that knows a
  * block's template (one distance, one assignment, one filter, one division: halo2_vectordb_amd/circuit_sym.py) places it at all its

@@ -42,8 +42,10 @@ t0 = time.time()
 hp = KmeansHotPath(n=256, dim=128, K=4, I=I, k=16, P=48, L=15, metric="cosine")
 hp.ext_block_cols = 256
 hp.setup()
+api.sync()
 t1 = time.time()
 pr = ProverRounds(hp).keygen()
+api.sync()
 t2 = time.time()
 prof.disable()
 print("setup_s", round(t1 - t0, 1), "keygen_s", round(t2 - t1, 1))

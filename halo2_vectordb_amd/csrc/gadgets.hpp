@@ -386,33 +386,61 @@ struct Gadgets {
     r_check_big_less_than_safe(div, bound, a_bits - shift + 1);
     r_check_big_less_than_safe(rem, T.pow2[shift], shift + 1);
   }
-  // 256-bit schoolbook shift-subtract division of canonical integers (BigUint div_mod_floor)
+  // 256-bit division of canonical integers (BigUint div_mod_floor), b != 0: long division in base 2^32 (Knuth's algorithm D) in a
+  // shape that indexes no register array at run time.  The divisor is shifted left until its top bit is bit 255 (bn), the dividend by
+  // the same amount (a 512-bit value hi : lo); hi < bn is the first partial remainder, and each of lo's eight words, from the top,
+  // yields one 32-bit quotient digit: the estimate floor(top two words of the remainder / top word of bn) is at most 2 too large for a
+  // normalised divisor, which at most two add-backs correct.  Words that cannot produce a digit (remainder below the divisor's top
+  // word) cost a shift.  The bit-serial loop this replaces took ~60 instructions for every BIT of the dividend — half of the
+  // sequential chain of a distance's tail (qsqrt divides twice).
   HD static void divmod_u256(const u256& a, const u256& b, u256& q, u256& r) {
     q = u256_zero();
-    r = u256_zero();
-    int nb = (int)u256_bits(a);
-    if (nb == 0) return;
-    u256 cur = u256_shl(a, 256u - (unsigned)nb);  // dividend bits leave through bit 255 (static indexing only)
-    for (int i = 0; i < nb; i++) {
-      u256 t;
-#pragma unroll
-      for (int k = 7; k >= 1; k--) t.w[k] = (r.w[k] << 1) | (r.w[k - 1] >> 31);
-      t.w[0] = (r.w[0] << 1) | (cur.w[7] >> 31);
-      r = t;
-#pragma unroll
-      for (int k = 7; k >= 1; k--) t.w[k] = (cur.w[k] << 1) | (cur.w[k - 1] >> 31);
-      t.w[0] = cur.w[0] << 1;
-      cur = t;
-#pragma unroll
-      for (int k = 7; k >= 1; k--) t.w[k] = (q.w[k] << 1) | (q.w[k - 1] >> 31);
-      t.w[0] = q.w[0] << 1;
-      q = t;
-      u256 d;
-      if (!u256_sub(d, r, b)) {  // r >= b
-        r = d;
-        q.w[0] |= 1u;
-      }
+    const unsigned na = u256_bits(a), nb = u256_bits(b);
+    if (nb == 0 || na < nb) {
+      r = nb ? a : u256_zero();
+      return;
     }
+    const unsigned s = 256u - nb;
+    const u256 bn = u256_shl(b, s);
+    u256 lo = u256_shl(a, s);
+    u256 R = s ? u256_shr(a, nb) : u256_zero();   // hi = a >> (256 - s)
+    const uint32_t bt = bn.w[7];
+    for (int i = 0; i < 8; i++) {
+      const uint32_t R8 = R.w[7];
+#pragma unroll
+      for (int k = 7; k >= 1; k--) R.w[k] = R.w[k - 1];
+      R.w[0] = lo.w[7];
+#pragma unroll
+      for (int k = 7; k >= 1; k--) lo.w[k] = lo.w[k - 1];
+      lo.w[0] = 0;
+      uint32_t qh = 0;
+      const uint64_t top = ((uint64_t)R8 << 32) | R.w[7];
+      if (top >= bt) {
+        const uint64_t e = top / bt;
+        qh = e > 0xffffffffull ? 0xffffffffu : (uint32_t)e;
+        uint64_t carry = 0, borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint64_t p = (uint64_t)qh * bn.w[k] + carry;
+          carry = p >> 32;
+          const uint64_t d = (uint64_t)R.w[k] - (uint32_t)p - borrow;
+          R.w[k] = (uint32_t)d;
+          borrow = (d >> 32) & 1;
+        }
+        int64_t t8 = (int64_t)(uint64_t)R8 - (int64_t)carry - (int64_t)borrow;
+#pragma unroll
+        for (int fix = 0; fix < 2; fix++) {
+          if (t8 < 0) {
+            t8 += (int64_t)u256_add(R, R, bn);
+            qh--;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 7; k >= 1; k--) q.w[k] = q.w[k - 1];
+      q.w[0] = qh;
+    }
+    r = u256_shr(R, s);
   }
   static HDN EmitOut2 r_div_mod_var__ool(WCtx cv, u256 a, u256 b, uint32_t a_bits, uint32_t b_bits) {
     Gadgets g(cv);

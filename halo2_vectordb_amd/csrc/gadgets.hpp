@@ -46,17 +46,19 @@ struct FpTables {
   Sizes sz;
 };
 
-struct WCtx {
+// What does not change over the kernels of one call: where the streams lie, the rank's window, the chip's tables, the deferred-
+// inversion list.  It lives in CONSTANT memory on the device (g_winv, written by the host entry before the call's kernels:
+// witness.hip set_winv) and in a thread-local on the host (counting runs), NOT in the context: the out-of-line generators take the
+// context by value, and a 132-byte struct travels through scratch memory — stores before every call, loads after, and on gfx9 a
+// load's wait is a wait for every cell store queued before it (one in-order vmcnt).  With these fields read through scalar loads the
+// context is ten dwords and travels in registers.
+struct WInv {
   u256* adv;          // advice stream base (absolute indexing)
   uint8_t* sel;       // optional gate-start bits (keygen run), may be null
   u256* lk;           // lookup stream base
-  uint64_t pos, lpos; // absolute positions of the next advice / lookup cell
-  uint64_t lo, hi;    // emit window over advice positions (the slice of a sequential gadget this wavefront owns)
   // rank window (multi-GPU): only cells of the columns this rank commits are stored; everything else runs
   // through the value-only paths.  Advice positions [rlo, rhi), lookup positions [rllo, rlhi).
   uint64_t rlo, rhi, rllo, rlhi;
-  bool count_only;    // host sizing run: count cells, store nothing, never skip
-  int err;
   const FpTables* T;
   // deferred inversions (halo2's Assigned::Rational + batch_invert): instead of a 380-product Fermat chain on
   // the critical path, (cell position, denominator) is appended here and k_inv_fixup patches the cell later
@@ -64,33 +66,49 @@ struct WCtx {
   u256* inv_val;
   uint32_t* inv_cnt;
   uint32_t inv_cap;
+};
+static __constant__ WInv g_winv;
+inline thread_local WInv h_winv{};
+HD const WInv& winv() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return g_winv;
+#else
+  return h_winv;
+#endif
+}
+
+struct WCtx {
+  uint64_t pos, lpos; // absolute positions of the next advice / lookup cell
+  uint64_t lo, hi;    // emit window over advice positions (the slice of a sequential gadget this wavefront owns)
+  bool count_only;    // host sizing run: count cells, store nothing, never skip
+  int err;
 
   HD bool in_window(uint64_t p) const { return p >= lo && p < hi; }
-  HD bool in_rank(uint64_t p) const { return p >= rlo && p < rhi; }
+  HD bool in_rank(uint64_t p) const { return p >= winv().rlo && p < winv().rhi; }
   // `cst`: the cell holds a data-independent constant of the gate template (QuantumCell::Constant); recorded in
   // bit 1 of the keygen-side flag byte so the prover's MSM can take those cells from a precomputed point
   HD void push(const u256& v, bool gate, bool cst = false) {
     if (!count_only && in_window(pos) && in_rank(pos)) {
-      adv[pos] = v;
-      if (sel) sel[pos] = (uint8_t)((gate ? 1 : 0) | (cst ? 2 : 0));
+      winv().adv[pos] = v;
+      if (winv().sel) winv().sel[pos] = (uint8_t)((gate ? 1 : 0) | (cst ? 2 : 0));
     }
     pos++;
   }
   // a lookup cell belongs to the window that owns the advice cell pushed just before it
   HD void lookup(const u256& v) {
-    if (!count_only && pos > 0 && in_window(pos - 1) && lpos >= rllo && lpos < rlhi) lk[lpos] = v;
+    if (!count_only && pos > 0 && in_window(pos - 1) && lpos >= winv().rllo && lpos < winv().rlhi) winv().lk[lpos] = v;
     lpos++;
   }
   // keygen-style runs only (sel != null): bit 2 of the flag byte marks the advice cell at `p` as the cell a lookup cell copies
   // (cells_to_lookup holds copies of advice cells; the j-th marked cell in stream order is the source of lookup cell j)
   HD void mark_lookup_source(uint64_t p) {
-    if (sel && !count_only && in_window(p) && in_rank(p)) sel[p] |= 4;
+    if (winv().sel && !count_only && in_window(p) && in_rank(p)) winv().sel[p] |= 4;
   }
   // true when a sub-gadget of `cells` advice cells (and `lks` lookup cells) starting here cannot touch the windows
   HD bool skip(uint32_t cells, uint32_t lks = 0) const {
     if (count_only) return false;
     const bool seg_out = pos + cells <= lo || pos > hi;
-    const bool rank_out = (pos + cells <= rlo || pos >= rhi) && (lks == 0 || lpos + lks <= rllo || lpos >= rlhi);
+    const bool rank_out = (pos + cells <= winv().rlo || pos >= winv().rhi) && (lks == 0 || lpos + lks <= winv().rllo || lpos >= winv().rlhi);
     return seg_out || rank_out;
   }
   HD bool skip2(const uint32_t sz[2]) const { return skip(sz[0], sz[1]); }
@@ -137,7 +155,7 @@ struct EmitOut2 {
 struct Gadgets {
   WCtx& c;
   const FpTables& T;
-  HD Gadgets(WCtx& ctx) : c(ctx), T(*ctx.T) {}
+  HD Gadgets(WCtx& ctx) : c(ctx), T(*winv().T) {}
 
   HD u256 zero() const { return u256_zero(); }
   // Montgomery form v * 2^256 mod r of a small integer (v < 2^24) WITHOUT a table: v c - q r with c = 2^256 mod r and
@@ -170,12 +188,12 @@ struct Gadgets {
   // value of the inverse cell of an is_zero block that starts at the current position (the cell is pos + 2)
   HD u256 inv_cell(const u256& x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (c.inv_cnt) {
+    if (winv().inv_cnt) {
       if (!c.in_window(c.pos + 2) || !c.in_rank(c.pos + 2)) return mont_one<Fr>();  // this window does not store the cell at all
-      uint32_t i = atomicAdd(c.inv_cnt, 1u);
-      if (i < c.inv_cap) {
-        c.inv_pos[i] = c.pos + 2;
-        c.inv_val[i] = x;
+      uint32_t i = atomicAdd(winv().inv_cnt, 1u);
+      if (i < winv().inv_cap) {
+        winv().inv_pos[i] = c.pos + 2;
+        winv().inv_val[i] = x;
         return mont_one<Fr>();  // placeholder, overwritten by k_inv_fixup
       }
     }
@@ -960,9 +978,10 @@ inline void compute_sizes(FpTables& T) {
     WCtx c{};
     c.count_only = true;
     c.hi = ~0ull;
-    c.rhi = ~0ull;
-    c.rlhi = ~0ull;
-    c.T = &T;
+    h_winv = WInv{};
+    h_winv.rhi = ~0ull;
+    h_winv.rlhi = ~0ull;
+    h_winv.T = &T;
     Gadgets g(c);
     fn(g);
     out[0] = (uint32_t)c.pos;

@@ -218,27 +218,35 @@ struct Streams {
   }
 };
 
-__device__ __forceinline__ WCtx make_ctx(const Streams& s, const FpTables* T, uint64_t pos, uint64_t lpos) {
+// (the streams, the rank window, the tables and the inversion list are not part of the context: they are the call's g_winv, set_winv)
+__device__ __forceinline__ WCtx make_ctx(const Streams&, const FpTables*, uint64_t pos, uint64_t lpos) {
   WCtx c;
-  c.adv = s.adv;
-  c.sel = s.sel;
-  c.lk = s.lk;
   c.pos = pos;
   c.lpos = lpos;
   c.lo = 0;
   c.hi = ~0ull;
   c.count_only = false;
   c.err = 0;
-  c.T = T;
-  c.inv_pos = s.inv_pos;
-  c.inv_val = s.inv_val;
-  c.inv_cnt = s.inv_cnt;
-  c.inv_cap = s.inv_cap;
-  c.rlo = s.rlo;
-  c.rhi = s.rhi;
-  c.rllo = s.rllo;
-  c.rlhi = s.rlhi;
   return c;
+}
+// every host entry publishes its call's invariant context before it launches a kernel (stream ordered: kernels of an earlier call
+// still read the earlier one)
+static int set_winv(const Streams& st, const FpTables* T) {
+  WInv h{};
+  h.adv = st.adv;
+  h.sel = st.sel;
+  h.lk = st.lk;
+  h.rlo = st.rlo;
+  h.rhi = st.rhi;
+  h.rllo = st.rllo;
+  h.rlhi = st.rlhi;
+  h.T = T;
+  h.inv_pos = st.inv_pos;
+  h.inv_val = st.inv_val;
+  h.inv_cnt = st.inv_cnt;
+  h.inv_cap = st.inv_cap;
+  VDB_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_winv), &h, sizeof(WInv), 0, hipMemcpyHostToDevice, ctx().stream));
+  return VDB_OK;
 }
 
 #define HEAD_TB 128
@@ -414,7 +422,6 @@ __global__ __launch_bounds__(64) void k_dist_values(const FpTables* __restrict__
   const u256* a = A + (size_t)(t % im.a_mod) * D;
   const u256* b = Bv + (size_t)(t / im.b_div) * D;
   WCtx c{};
-  c.T = T;
   Gadgets g(c);
   u256 s0 = u256_zero(), s1 = u256_zero(), s2 = u256_zero();
   for (uint32_t i = lane; i < D; i += 64) {
@@ -575,7 +582,6 @@ static int run_distances(const Streams& st, FpEntry* fp, const DistLayout& dl, c
 __global__ void k_nv_prefix_min(const FpTables* __restrict__ T, const u256* __restrict__ d, uint32_t n, u256* __restrict__ pm) {
   if (blockIdx.x || threadIdx.x) return;
   WCtx c{};
-  c.T = T;
   Gadgets g(c);
   u256 m = d[0];
   pm[0] = m;
@@ -692,7 +698,7 @@ __device__ __forceinline__ u256 chain_fold_wave(WCtx& c, uint64_t base, uint64_t
   const uint32_t first = lo ? lo : 1;
   if (first >= hi) return total;
   const uint64_t c_lo = base + (uint64_t)(first - 1) * stride, c_hi = base + (uint64_t)(hi - 2) * stride + 4;
-  if (!c.count_only && (c_hi <= c.rlo || c_lo >= c.rhi)) return total;
+  if (!c.count_only && (c_hi <= winv().rlo || c_lo >= winv().rhi)) return total;
   for (uint32_t v0 = lo; v0 < hi; v0 += KM_PF) {
     u256 xv[KM_PF];
 #pragma unroll
@@ -835,7 +841,9 @@ __device__ void trace_dense(WCtx& c, const FpTables* T, u256 st[PSD_T], const u2
   for (int i = 0; i < PSD_T; i++) r[i] = trace_ip_const(c, T, st, m[i], PSD_T);
   for (int i = 0; i < PSD_T; i++) st[i] = r[i];
 }
-__device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
+// (the context by value and back: ten dwords in registers — by reference it lived in the caller's scratch and was re-read around
+//  every cell store, which on gfx9 waits for the stores before it)
+__device__ __noinline__ WCtx trace_permutation(WCtx c, const FpTables* T, const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
   Gadgets g(c);
   {
     u256 v[2] = {st[0], sp->start[0][0]};
@@ -874,6 +882,7 @@ __device__ __noinline__ void trace_permutation(WCtx& c, const FpTables* T, const
   u256 z = u256_zero();
   for (int i = 0; i < PSD_T; i++) trace_sbox(g, st[i], z);
   trace_dense(c, T, st, sp->mds);
+  return c;
 }
 HD uint32_t perm_cells(int n_in) { return (n_in == 2 ? 18u : (n_in == 1 ? 15u : 12u)) + 2238u; }
 
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(64) void k_mk_leaf_trace(Streams stq, const FpTable
   for (int i = 0; i < PSD_T; i++) st[i] = states[((size_t)v * nperm + p) * PSD_T + i];
   const u256* msg = vectors + (size_t)v * D;
   u256 in[PSD_RATE] = {cnt > 0 ? msg[off] : u256_zero(), cnt > 1 ? msg[off + 1] : u256_zero()};
-  trace_permutation(c, T, sp, st, in, cnt);
+  c = trace_permutation(c, T, sp, st, in, cnt);
 }
 // one thread per tree node: two permutations (absorb [l, r], then padding only)
 __global__ __launch_bounds__(64) void k_mk_node(Streams stq, const FpTables* __restrict__ T, const PoseidonSpec* __restrict__ sp, const u256* __restrict__ in_lv,
@@ -934,8 +943,8 @@ __global__ __launch_bounds__(64) void k_mk_node(Streams stq, const FpTables* __r
     return;
   }
   WCtx c = make_ctx(stq, T, p0, 0);
-  trace_permutation(c, T, sp, st, in, 2);
-  trace_permutation(c, T, sp, st, in, 0);
+  c = trace_permutation(c, T, sp, st, in, 2);
+  c = trace_permutation(c, T, sp, st, in, 0);
   out_lv[t] = st[1];
 }
 
@@ -1059,6 +1068,7 @@ int wit_distance_dev(FpEntry* fp, int metric, const u256* a, const u256* b, size
   DistLayout dl;
   TRY(dist_layout(fp->host, metric, dim, &dl));
   TRY(inv_list_attach(st, n_pairs * dl.total_cells));
+  TRY(set_winv(st, fp->dev));
   InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 1};
   u256* mid = (u256*)scratch_get(0, n_pairs * 3 * sizeof(u256) + 64);
   if (!mid) return VDB_ERR_OOM;
@@ -1087,6 +1097,7 @@ int wit_nearest_dev(FpEntry* fp, int metric, const u256* query, const u256* vect
   NvLayout nl;
   TRY(nv_layout(fp, metric, n, dim, &dl, &nl));
   TRY(inv_list_attach(st, nl.total));
+  TRY(set_winv(st, fp->dev));
   InstMap im{adv_off, lk_off, 1, dl.total_cells, dl.total_lk, 0xffffffffu, 0xffffffffu};  // (vector_i, query)
   u256* mid = (u256*)scratch_get(0, (n * 5 + 8) * sizeof(u256));
   if (!mid) return VDB_ERR_OOM;
@@ -1145,6 +1156,7 @@ int wit_kmeans_dev(FpEntry* fp, int metric, const u256* vectors, size_t n, size_
   KmLayout kl;
   TRY(km_layout(fp, metric, n, dim, K, &dl, &kl));
   TRY(inv_list_attach(st, I * kl.iter));
+  TRY(set_winv(st, fp->dev));
   hipStream_t s = ctx().stream;
   size_t need = (n * K * 4 + K * dim * 2 + K + K * n * dim + 16) * sizeof(u256);
   u256* buf = (u256*)scratch_get(0, need);
@@ -1222,6 +1234,7 @@ static void mk_layout(size_t n, size_t dim, int zero_cached, MkLayout* o) {
 int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, Streams st, uint64_t adv_off, u256* root_out) {
   FpEntry* fp;
   TRY(get_fp(48, 13, &fp));  // only GateChip primitives are used: P and L are irrelevant
+  TRY(set_winv(st, fp->dev));
   const PoseidonSpec* sp;
   TRY(poseidon_spec_dev(&sp, nullptr));
   MkLayout ml;

@@ -948,6 +948,46 @@ __global__ __launch_bounds__(64) void k_mk_node(Streams stq, const FpTables* __r
   out_lv[t] = st[1];
 }
 
+// The tree without a launch per level's TRACE: the digests of every level first (value only: two permutations of latency per level,
+// k_mk_level_values), then every node's two permutations traced in ONE launch — a thread per (node, permutation), the padding-only
+// permutation starting from the state its thread recomputes.  (One thread per node tracing 4.5 k cells level after level cost ten
+// launches of 2.1 ms each whatever the level's size: 21 of C3's 49 ms of witness.)
+__global__ __launch_bounds__(64) void k_mk_level_values(const PoseidonSpec* __restrict__ sp, const u256* __restrict__ in_lv, uint32_t n_out,
+                                                        u256* __restrict__ out_lv) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_out) return;
+  u256 st[PSD_T] = {sp->cap, u256_zero(), u256_zero()};
+  u256 in[PSD_RATE] = {in_lv[2 * t], in_lv[2 * t + 1]};
+  psd_permute_absorb(sp, st, in, 2);
+  psd_permute_absorb(sp, st, in, 0);
+  out_lv[t] = st[1];
+}
+// levels: level 0 = the lp (padded) leaf digests, level l at offset lp (2 - 2^(1-l)) ... i.e. one after the other; node g of the
+// tree (level-major numbering, g < lp - 1) has its cells at base + g * (perm_cells(2) + perm_cells(0))
+__global__ __launch_bounds__(64) void k_mk_tree_trace(Streams stq, const FpTables* __restrict__ T, const PoseidonSpec* __restrict__ sp,
+                                                      const u256* __restrict__ levels, uint32_t lp, uint64_t base) {
+  const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t g = id >> 1, j = id & 1u;
+  if (g + 1 >= lp) return;
+  // level of node g: level sizes lp/2, lp/4, ...; in_off = offset of the level it reads in `levels`
+  uint32_t sz = lp >> 1, first = 0, in_off = 0, in_sz = lp;
+  while (g >= first + sz) {
+    first += sz;
+    in_off += in_sz;
+    in_sz = sz;
+    sz >>= 1;
+  }
+  const uint32_t t = g - first;
+  const uint64_t p0 = base + (uint64_t)g * (perm_cells(2) + perm_cells(0)) + (j ? perm_cells(2) : 0);
+  const uint32_t cells = j ? perm_cells(0) : perm_cells(2);
+  if (!stq.touches(p0, p0 + cells, 0, 0)) return;
+  u256 st[PSD_T] = {sp->cap, u256_zero(), u256_zero()};
+  u256 in[PSD_RATE] = {levels[in_off + 2 * t], levels[in_off + 2 * t + 1]};
+  if (j) psd_permute_absorb(sp, st, in, 2);   // the padding-only permutation starts where the absorbing one ended
+  WCtx c = make_ctx(stq, T, p0, 0);
+  c = trace_permutation(c, T, sp, st, in, j ? 0 : 2);
+}
+
 // ------------------------------------------------------------------ layout (halo2-base assign_threads_in)
 // break points from the gate-start bits: the row walk of GateThreadBuilder::assign_all.  A column that
 // starts at stream cell S breaks at the first row r in {M-3, M-2 (if that cell starts a gate), M-1}.
@@ -1266,6 +1306,30 @@ int wit_merkle_dev(const u256* vectors, size_t n, size_t dim, int zero_cached, S
     }
     VDB_LAUNCH_CHECK();
     pos += 1;
+  }
+  // the tree: every level's digests (lva holds the levels one after the other: lp + lp / 2 + ... + 1 < 2 lp entries = lva | lvb), then one
+  // launch that traces all lp - 1 nodes (VDB_MK_TREE=0: a launch per level, each thread tracing its node's two permutations)
+  static const bool tree_on = !(getenv("VDB_MK_TREE") && getenv("VDB_MK_TREE")[0] == '0');
+  const uint64_t lp = ml.n_leaves_pow2;
+  if (tree_on && lp > 1 && lp <= (1u << 30)) {
+    uint64_t lv = lp, off = 0;
+    while (lv > 1) {
+      const uint64_t no = lv / 2;
+      {
+        VDB_PROF("k_mk_level_values");
+        hipLaunchKernelGGL(k_mk_level_values, dim3((unsigned)((no + 63) / 64)), dim3(64), 0, s, sp, lva + off, (uint32_t)no, lva + off + lv);
+      }
+      VDB_LAUNCH_CHECK();
+      off += lv;
+      lv = no;
+    }
+    {
+      VDB_PROF("k_mk_tree_trace");
+      hipLaunchKernelGGL(k_mk_tree_trace, dim3((unsigned)((2 * (lp - 1) + 63) / 64)), dim3(64), 0, s, st, fp->dev, sp, lva, (uint32_t)lp, pos);
+    }
+    VDB_LAUNCH_CHECK();
+    VDB_HIP(hipMemcpyAsync(root_out, lva + off, sizeof(u256), hipMemcpyDeviceToDevice, s));
+    return VDB_OK;
   }
   uint64_t lv = ml.n_leaves_pow2;
   while (lv > 1) {

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "field.hpp"
+#include "limb9.hpp"
 
 namespace vdb {
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ void psd_dense(u256 st[PSD_T], const u256 m[PSD_T][PS
 }
 // PoseidonChip::permutation value semantics: absorb n_in (<= RATE) inputs with the pre-constants and
 // the +1 padding marker, then the optimized rounds
-__device__ __forceinline__ void psd_permute_absorb(const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
+__device__ __forceinline__ void psd_permute_absorb_words(const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
   st[0] = fr_add(st[0], sp->start[0][0]);
 #pragma unroll
   for (int i = 0; i < PSD_RATE; i++) {
@@ -98,6 +99,84 @@ __device__ __forceinline__ void psd_permute_absorb(const PoseidonSpec* __restric
 #pragma unroll
   for (int i = 0; i < PSD_T; i++) st[i] = psd_pow5(st[i]);
   psd_dense(st, sp->mds);
+}
+// ---- the same permutation for the VALUE chains (leaf sponges, tree levels: one lane walks 600 dependent products per permutation and
+// nothing hides them) in nine-limb form.  A word x is held as x 2^261 mod p (Montgomery R' = 2^261, what a nine-limb product divides
+// by), lazily: sums just add limbs, a product's first operand may carry limbs up to 6 x 2^29, its second is normalised.  The spec's
+// constants (R = 2^256 form) enter as 32 c = l9_split32(c); squarings use the squaring core, a dense row is two products under one
+// reduction plus one.  ~113 k vector instructions per permutation against ~186 k for the eight-word Montgomery products.
+struct PsdL9 {
+  L9 s[PSD_T];
+};
+__device__ __forceinline__ L9 psd9_in(const u256& x) { return l9_split32(x); }
+__device__ __forceinline__ u256 psd9_out(const L9& x) {  // limbs below 6 x 2^29, any value below 2^261 -> canonical R = 2^256 form
+  return l9_canon<Fr>(l9_mul<Fr>(x, l9_split(mont_one<Fr>())));
+}
+__device__ __forceinline__ L9 psd9_pow5(L9 x) {
+  l9_renorm(x);
+  const L9 x2 = l9_sqr<Fr>(x), x4 = l9_sqr<Fr>(x2);
+  return l9_mul<Fr>(x4, x);
+}
+__device__ __forceinline__ void psd9_dense(PsdL9& st, const u256 m[PSD_T][PSD_T]) {   // st: limbs below 2 x 2^29 each
+  L9 r[PSD_T];
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++)
+    r[i] = l9_add(l9_mul2<Fr>(st.s[0], psd9_in(m[i][0]), st.s[1], psd9_in(m[i][1])), l9_mul<Fr>(st.s[2], psd9_in(m[i][2])));
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st.s[i] = r[i];
+}
+__device__ __forceinline__ void psd9_permute_absorb(const PoseidonSpec* __restrict__ sp, PsdL9& st, const u256* in, int n_in) {
+  // on entry the words are sums of at most two normalised values (a dense layer's output) or fresh
+  st.s[0] = l9_add(st.s[0], psd9_in(sp->start[0][0]));
+#pragma unroll
+  for (int i = 0; i < PSD_RATE; i++) {
+    if (i < n_in) st.s[1 + i] = l9_add(l9_add(st.s[1 + i], psd9_in(in[i])), psd9_in(sp->start[0][1 + i]));
+    else if (i == n_in) st.s[1 + i] = l9_add(st.s[1 + i], psd9_in(fr_add(sp->start[0][1 + i], sp->one)));
+    else st.s[1 + i] = l9_add(st.s[1 + i], psd9_in(sp->start[0][1 + i]));
+  }
+  for (int r = 1; r < PSD_HALF; r++) {
+#pragma unroll
+    for (int i = 0; i < PSD_T; i++) st.s[i] = l9_add(psd9_pow5(st.s[i]), psd9_in(sp->start[r][i]));
+    psd9_dense(st, sp->mds);
+  }
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st.s[i] = l9_add(psd9_pow5(st.s[i]), psd9_in(sp->start[PSD_HALF][i]));
+  psd9_dense(st, sp->pre_sparse);
+  for (int p = 0; p < PSD_RP; p++) {
+    // words 1, 2 take one product more every round: a carry pass every second round keeps their limbs below 4 x 2^29 (their
+    // values grow to at most ~70 p < 2^261 over the 57 rounds, which a product's first operand may be)
+    if (p & 1) {
+      l9_renorm(st.s[1]);
+      l9_renorm(st.s[2]);
+    }
+    st.s[0] = l9_add(psd9_pow5(st.s[0]), psd9_in(sp->partial[p]));
+    const L9 n0 = l9_add(l9_mul2<Fr>(st.s[0], psd9_in(sp->sparse_row[p][0]), st.s[1], psd9_in(sp->sparse_row[p][1])),
+                         l9_mul<Fr>(st.s[2], psd9_in(sp->sparse_row[p][2])));
+#pragma unroll
+    for (int i = 1; i < PSD_T; i++) st.s[i] = l9_add(l9_mul<Fr>(st.s[0], psd9_in(sp->sparse_col[p][i - 1])), st.s[i]);
+    st.s[0] = n0;
+  }
+  l9_renorm(st.s[1]);
+  l9_renorm(st.s[2]);
+  for (int r = 0; r < PSD_HALF - 1; r++) {
+#pragma unroll
+    for (int i = 0; i < PSD_T; i++) st.s[i] = l9_add(psd9_pow5(st.s[i]), psd9_in(sp->end[r][i]));
+    psd9_dense(st, sp->mds);
+  }
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st.s[i] = psd9_pow5(st.s[i]);
+  psd9_dense(st, sp->mds);
+}
+
+// what the hash-only kernels and the value chains call: canonical words in and out, the nine-limb permutation in between
+// (psd_permute_absorb_words is the same permutation on eight-word Montgomery products: kept as the readable form)
+__device__ __forceinline__ void psd_permute_absorb(const PoseidonSpec* __restrict__ sp, u256 st[PSD_T], const u256* in, int n_in) {
+  PsdL9 t;
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) t.s[i] = psd9_in(st[i]);
+  psd9_permute_absorb(sp, t, in, n_in);
+#pragma unroll
+  for (int i = 0; i < PSD_T; i++) st[i] = psd9_out(t.s[i]);
 }
 // sponge: clear(); update(msg[0..len)); squeeze()  (elements `stride` apart)
 __device__ __forceinline__ u256 psd_hash(const PoseidonSpec* __restrict__ sp, const u256* msg, size_t len, size_t stride) {

@@ -232,7 +232,12 @@ __device__ __forceinline__ WCtx make_ctx(const Streams&, const FpTables*, uint64
 // every host entry publishes its call's invariant context before it launches a kernel (stream ordered: kernels of an earlier call
 // still read the earlier one)
 static int set_winv(const Streams& st, const FpTables* T) {
-  WInv h{};
+  // (the source outlives the call: a pageable source is staged before hipMemcpyToSymbolAsync returns on this runtime, as the other
+  //  small uploads of this file rely on too; the ring only makes that assumption harmless should a runtime ever defer the read)
+  static thread_local WInv ring[8];
+  static thread_local unsigned slot = 0;
+  WInv& h = ring[slot++ & 7u];
+  h = WInv{};
   h.adv = st.adv;
   h.sel = st.sel;
   h.lk = st.lk;

@@ -524,45 +524,44 @@ def main():
         from halo2_vectordb_amd._lib import check as _check
         hp.free()
         _check(api.init().vdb_scratch_release())
-        if True:
-            # The sharded proof must never cost the run its bench line: a rank that fails inside it leaves the others waiting in
-            # a collective.  It runs in a worker thread that the main thread gives a bounded time; if a rank fails or the time runs
-            # out, rank 0 still prints the line (proof = the error) and every rank leaves without another collective.
-            import threading
-            box = {}
+        # The sharded proof must never cost the run its bench line: a rank that fails inside it leaves the others waiting in
+        # a collective.  It runs in a worker thread that the main thread gives a bounded time; if a rank fails or the time runs
+        # out, rank 0 still prints the line (proof = the error) and every rank leaves without another collective.
+        import threading
+        box = {}
 
-            def work():
-                from halo2_vectordb_amd.dist import Comm
-                ok = True
-                try:
-                    if dist.get_backend() == "nccl":
-                        import torch
-                        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # the current device is per thread
-                    if os.environ.get("VDB_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: this rank drops out of the proof
-                        raise RuntimeError("rank failure injected by the test")
-                    box["proof"] = whole_proof(api, rank, world, Comm(dist), small=args.small)
-                except BaseException as e:
-                    box["proof"] = {"error": repr(e)[:300]}
-                    ok = False
-                # Every rank that gets here tells the others how its proof went — still inside the bounded worker: a peer that is stuck
-                # in a collective of a proof this rank dropped out of never answers (or answers a different collective), and the join
-                # below runs into its limit.  Only when EVERY rank reports success do the ranks meet again in the closing barrier.
-                try:
-                    flags = Comm(dist).gather_rows(np.array([1 if ok else 0], dtype=np.uint64))
-                    box["all_ok"] = bool(flags.shape[0] == world and flags.all())
-                except BaseException:
-                    box["all_ok"] = False
-            th = threading.Thread(target=work, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("VDB_BENCH_PROOF_TIMEOUT", "420")))
-            if th.is_alive():
-                proof = {"error": "the sharded proof did not finish in time on this rank (a rank failed, or a collective hangs)"}
-                abandoned = True
-            else:
-                proof = box["proof"]
-                abandoned = not box.get("all_ok", False)
-                if abandoned and "error" not in proof:
-                    proof = dict(proof, error="another rank failed inside the sharded proof")
+        def work():
+            from halo2_vectordb_amd.dist import Comm
+            ok = True
+            try:
+                if dist.get_backend() == "nccl":
+                    import torch
+                    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # the current device is per thread
+                if os.environ.get("VDB_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: this rank drops out of the proof
+                    raise RuntimeError("rank failure injected by the test")
+                box["proof"] = whole_proof(api, rank, world, Comm(dist), small=args.small)
+            except BaseException as e:
+                box["proof"] = {"error": repr(e)[:300]}
+                ok = False
+            # Every rank that gets here tells the others how its proof went — still inside the bounded worker: a peer that is stuck
+            # in a collective of a proof this rank dropped out of never answers (or answers a different collective), and the join
+            # below runs into its limit.  Only when EVERY rank reports success do the ranks meet again in the closing barrier.
+            try:
+                flags = Comm(dist).gather_rows(np.array([1 if ok else 0], dtype=np.uint64))
+                box["all_ok"] = bool(flags.shape[0] == world and flags.all())
+            except BaseException:
+                box["all_ok"] = False
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VDB_BENCH_PROOF_TIMEOUT", "420")))
+        if th.is_alive():
+            proof = {"error": "the sharded proof did not finish in time on this rank (a rank failed, or a collective hangs)"}
+            abandoned = True
+        else:
+            proof = box["proof"]
+            abandoned = not box.get("all_ok", False)
+            if abandoned and "error" not in proof:
+                proof = dict(proof, error="another rank failed inside the sharded proof")
 
     if rank == 0 and cpu is not None and proof is not None and "shape" in proof:
         est, parts = cpu_proof_estimate(cpu["proof_unit_costs"], cpu["cores"], proof["shape"])

@@ -680,41 +680,146 @@ class ProverRounds:
         flag-recording witness pass, no permutation construction).  The Lagrange forms the rounds read (sigma, table) are
         recovered with a forward transform; raises ValueError when the file describes another circuit, another rank or another
         partition of the columns."""
-        hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
         with np.load(path, allow_pickle=False) as doc:
             meta, shards = self._key_header()
             if not np.array_equal(doc["meta"], meta) or not np.array_equal(doc["shards"], shards) \
-                    or not np.array_equal(doc["break_points"], np.asarray(hp.bp, dtype=np.uint64)):
+                    or not np.array_equal(doc["break_points"], np.asarray(self.hp.bp, dtype=np.uint64)):
                 raise ValueError("proving key does not describe this circuit (shape, break points, rank or column blocks differ)")
-            self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
-            self.srs_few = api.Srs(k, hp.g_monomial, None)
-            omega = api.root_of_unity(k)
-            # (name, polynomials held here, their place in the whole set, size of the whole set, Lagrange form kept, cosets kept)
-            plan = (("sel", self.my_adv, [(self.a_lo, self.a_hi)], self.n_adv, False, False), ("sigma", self.my_sig, self.sig_ranges, self.n_perm, False, False),
-                    ("cst", 1, None, 1, True, True), ("table", 1, None, 1, True, True), ("lag", 3, None, 3, False, True))
-            for name, n_cols, ranges, n_total, need_lag, keep_ext in plan:
-                coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
-                commits = np.ascontiguousarray(doc[name + "_commits"])
-                if coeff_h.shape != (n_cols, rows, 4) or commits.shape != (n_total, 8):
-                    raise ValueError("proving key: wrong shape for " + name)
-                coeff = api.DeviceBuffer(max(coeff_h.nbytes, 32))
-                if coeff_h.nbytes:
-                    coeff.upload(coeff_h)
-                lag = None
-                if need_lag:
-                    lag = api.DeviceBuffer(coeff_h.nbytes)
-                    check(lib.vdb_memcpy_d2d(lag.ptr, coeff.ptr, _sz(coeff_h.nbytes)))
-                    check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
-                self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=commits,
-                                         ranges=ranges, n_total=n_total, replicated=ranges is None)
-            self.instance_cells = [int(c) for c in doc["instance_cells"]]      # the public cells come with the key
-            if int(doc["instance_cells_are_the_default"][0]):
-                self.public_cells = list(self.instance_cells)
+            return self._install_key(doc)
+
+    def _install_key(self, doc):
+        """doc[name + "_coeff"], doc[name + "_commits"] for every fixed polynomial, doc["instance_cells"]: the key's polynomials go
+        to the device in the forms the rounds read"""
+        hp, lib, rows, k = self.hp, self.lib, self.rows, self.k
+        self.srs_m = api.Srs(k, hp.g_monomial, hp.g_lagrange, window_bits=14)
+        self.srs_few = api.Srs(k, hp.g_monomial, None)
+        omega = api.root_of_unity(k)
+        # (name, polynomials held here, their place in the whole set, size of the whole set, Lagrange form kept, cosets kept)
+        plan = (("sel", self.my_adv, [(self.a_lo, self.a_hi)], self.n_adv, False, False), ("sigma", self.my_sig, self.sig_ranges, self.n_perm, False, False),
+                ("cst", 1, None, 1, True, True), ("table", 1, None, 1, True, True), ("lag", 3, None, 3, False, True))
+        for name, n_cols, ranges, n_total, need_lag, keep_ext in plan:
+            coeff_h = np.ascontiguousarray(doc[name + "_coeff"])
+            commits = np.ascontiguousarray(doc[name + "_commits"])
+            if coeff_h.shape != (n_cols, rows, 4) or commits.shape != (n_total, 8):
+                raise ValueError("proving key: wrong shape for " + name)
+            coeff = api.DeviceBuffer(max(coeff_h.nbytes, 32))
+            if coeff_h.nbytes:
+                coeff.upload(coeff_h)
+            lag = None
+            if need_lag:
+                lag = api.DeviceBuffer(coeff_h.nbytes)
+                check(lib.vdb_memcpy_d2d(lag.ptr, coeff.ptr, _sz(coeff_h.nbytes)))
+                check(lib.vdb_ntt_batch_dev(lag.ptr, _sz(n_cols), k, api._p(omega), 0))
+            self.fixed[name] = _Poly(name, n_cols, lag=lag, coeff=coeff, ext=self._to_ext(coeff, n_cols) if keep_ext else None, commits=commits,
+                                     ranges=ranges, n_total=n_total, replicated=ranges is None)
+        self.instance_cells = [int(c) for c in doc["instance_cells"]]      # the public cells come with the key
+        if int(doc["instance_cells_are_the_default"][0]):
+            self.public_cells = list(self.instance_cells)
         self._upload_instance_cells()
         if hp.ext_cols >= self.my_adv + self.my_lk + 2:
             check(lib.vdb_memcpy_d2d(hp.d_ext.at((self.my_adv + self.my_lk) * self.ne * B), self.fixed["cst"].ext.ptr, _sz(self.ne * B)))
         api.sync()
         return self._alloc_working_set()
+
+    # upstream's own key files ------------------------------------------------------------------------------------------------
+    RAW_FIXED = ("table", "cst", "sel")     # halo2-base creates the fixed columns in this order (io.py, [UPSTREAM-RECALL])
+    RAW_BLOCK = 64                          # polynomials converted and written at a time
+
+    @property
+    def raw_ext_k(self):
+        """halo2's extended domain has 2^(k + ceil(log2(degree - 1))) points: 4n for the circuits with lookups (degree 4), 2n without
+        (the rounds here evaluate on degree - 1 cosets of size n instead, self.ne points per column)"""
+        return int(self.chunk_len).bit_length()
+
+    def _raw_blocks(self, names, form):
+        """The polynomials of `names`, in order, as host blocks of at most RAW_BLOCK: form "coeff", "lagrange" (values over the
+        2^k domain) or "extended" (values over the 4n coset, halo2's ExtendedLagrangeCoeff)"""
+        omega = api.root_of_unity(self.k)
+        for name in names:
+            q = self.fixed[name]
+            for lo in range(0, q.n_cols, self.RAW_BLOCK):
+                m = min(self.RAW_BLOCK, q.n_cols - lo)
+                coeff = q.coeff.download((m, self.rows, 4), offset=lo * self.rows * B)
+                yield coeff if form == "coeff" else api.ntt_batch(coeff, omega) if form == "lagrange" else api.coeff_to_extended(coeff, self.raw_ext_k)
+
+    def _write_vk_raw(self, f):
+        from .io import write_vk_raw
+        if self.world != 1:
+            raise ValueError("upstream's key files describe the whole circuit: write them from a one-rank keygen (save_proving_key writes a rank's share)")
+        api.sync()
+        fixed = np.concatenate([self.fixed[name].commits for name in self.RAW_FIXED])
+        write_vk_raw(f, self.k, fixed, self.fixed["sigma"].commits, (np.any(v != 0, axis=2) for v in self._raw_blocks(("sel",), "lagrange")))
+
+    def save_verifying_key_raw(self, path):
+        """data/{name}.vk as the reference's Keygen arm writes it (src/scaffold/mod.rs:276-281): halo2's
+        `VerifyingKey::write(.., SerdeFormat::RawBytes)` layout (io.py restates it; [UPSTREAM-RECALL], parity unpinned) — k, the fixed
+        columns' commitments (table, constants, one per gate selector), the sigma commitments, the selectors' bits.
+        io.read_verifying_key_raw reads it back; tests/verify_file.py verifies a proof against it."""
+        with open(path, "wb") as f:
+            self._write_vk_raw(f)
+
+    def save_proving_key_raw(self, path):
+        """data/{name}.pk as snark-verifier-sdk's gen_pk leaves it for read_pk (src/scaffold/mod.rs:273, :325-331): halo2's
+        `ProvingKey::write` layout — the verifying key; l_0, l_last, l_active_row over the extended domain; every fixed column as
+        values, coefficients and extended coset; the sigma columns likewise.  Written a block of polynomials at a time (the cosets are
+        made for the file only: 6 x 2^k x 32 bytes per column, which is why upstream's later versions dropped them from the key).
+        The break points and the public cells are not part of it — they travel in the pinning file (io.write_pinning) and with the
+        circuit, as upstream."""
+        from .io import write_poly_raw, write_polys_raw
+        with open(path, "wb") as f:
+            self._write_vk_raw(f)
+            for poly in next(self._raw_blocks(("lag",), "extended")):
+                write_poly_raw(f, poly)
+            n_fixed = sum(self.fixed[name].n_cols for name in self.RAW_FIXED)
+            for form in ("lagrange", "coeff", "extended"):
+                write_polys_raw(f, self._raw_blocks(self.RAW_FIXED, form), n_fixed)
+            for form in ("lagrange", "coeff", "extended"):
+                write_polys_raw(f, self._raw_blocks(("sigma",), form), self.n_perm)
+
+    def load_proving_key_raw(self, path, instance_cells=None):
+        """The Prove arm reading upstream's pk layout (custom_read_pk, src/scaffold/mod.rs:325-331): commitments and coefficient
+        forms come from the file, the extended cosets are skipped over and re-derived on the device, l_0 / l_last / l_active are
+        checked against this circuit's.  `instance_cells`: as in keygen (None = the gadget's own public cells, which a circuit map
+        the circuit's constraint map names).  Raises ValueError when the file is not a key of this circuit."""
+        from .io import read_vk_raw, read_poly_raw, read_polys_raw
+        if self.world != 1:
+            raise ValueError("upstream's key files describe the whole circuit: load them on one rank")
+        rows, ne = self.rows, self.rows << self.raw_ext_k
+        with open(path, "rb") as f:
+            vk = read_vk_raw(f, self.n_perm, self.n_adv)
+            if vk["k"] != self.k or len(vk["fixed_commitments"]) != self.n_adv + 2:
+                raise ValueError("proving key does not describe this circuit (k or the number of fixed columns differ)")
+            lag_ext = np.stack([read_poly_raw(f, ne) for _ in range(3)])
+            read_polys_raw(f, self.n_adv + 2, rows, keep=False)
+            fixed = read_polys_raw(f, self.n_adv + 2, rows)
+            read_polys_raw(f, self.n_adv + 2, ne, keep=False)
+            read_polys_raw(f, self.n_perm, rows, keep=False)
+            sigma = read_polys_raw(f, self.n_perm, rows)
+            read_polys_raw(f, self.n_perm, ne, keep=False)
+            if f.read(1):
+                raise ValueError("proving key: bytes after the permutation's cosets")
+        lag = np.zeros((3, rows, 4), dtype=np.uint64)
+        one = _fr_from_int(1)
+        lag[0, 0], lag[1, self.usable], lag[2, : self.usable] = one, one, one
+        lag_coeff = api.lagrange_to_coeff(lag)
+        if not np.array_equal(api.coeff_to_extended(lag_coeff, self.raw_ext_k), lag_ext):
+            raise ValueError("proving key: l_0, l_last, l_active_row are not this circuit's (another number of blinding rows?)")
+        sel_bits = np.any(api.ntt_batch(fixed[2:], api.root_of_unity(self.k)) != 0, axis=2) if self.n_adv else np.zeros((0, rows), dtype=bool)
+        if not np.array_equal(sel_bits, vk["selectors"]):
+            raise ValueError("proving key: the selectors' bits are not where the selector columns are non-zero")
+        if instance_cells is None:
+            if not self.public_cells:
+                d_flags = self.hp.keygen_flags()       # the circuit's own public cells: from its constraint map, as keygen takes them
+                self.circuit_map(d_flags)
+                d_flags.free()
+            instance_cells = self.public_cells
+        fc = vk["fixed_commitments"]
+        doc = {"table_coeff": fixed[0:1], "cst_coeff": fixed[1:2], "sel_coeff": fixed[2:], "sigma_coeff": sigma, "lag_coeff": lag_coeff,
+               "table_commits": fc[0:1], "cst_commits": fc[1:2], "sel_commits": fc[2:], "sigma_commits": vk["permutation_commitments"],
+               "lag_commits": np.zeros((3, 8), dtype=np.uint64),
+               "instance_cells": np.asarray(instance_cells, dtype=np.int64),
+               "instance_cells_are_the_default": np.array([int(list(instance_cells) == list(self.public_cells))])}
+        return self._install_key(doc)
 
     # ------------------------------------------------------------------ the rounds
     def prove(self, challenges=None, seed=None, timings=None, multiopen="shplonk", instances=None):

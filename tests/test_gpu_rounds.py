@@ -4,6 +4,8 @@ evaluations, and every opening against its commitments in the exponent (the test
 handed in, once from nothing but the proof bytes and the fixed commitments, replaying the Fiat–Shamir transcript.
 Parity unpinned: the reference holds no vectors for the prover rounds; these are the PLONK / KZG
 identities themselves."""
+import os
+
 import numpy as np
 import pytest
 
@@ -340,6 +342,24 @@ def test_rounds_on_a_merkle_circuit_without_lookups(O):
                   tau_h=PR.pt_mul(PR.G2, TAU), instances=out2["instances"])
         assert _verify(O, api, out2["proof"], vk)
         assert not _verify(O, api, out2["proof"], {**vk, "instances": [(out2["instances"][0] + 1) % O.R_MOD]})    # another root: rejected
+        # the key files in upstream's layout at degree 3 (an extended domain of 2n points): the key read back proves the same bytes,
+        # the .vk file alone tells the verifier the circuit has no lookup columns
+        import tempfile
+        import verify_file
+        from halo2_vectordb_amd.io import write_snark
+        with tempfile.TemporaryDirectory() as d:
+            pr.save_proving_key_raw(os.path.join(d, "merkle.pk"))
+            pr.save_verifying_key_raw(os.path.join(d, "merkle.vk"))
+            assert os.path.getsize(os.path.join(d, "merkle.pk")) == os.path.getsize(os.path.join(d, "merkle.vk")) + 3 * (4 + 64 * pr.rows) \
+                + (pr.n_adv + 2 + pr.n_perm) * (2 * (4 + 32 * pr.rows) + 4 + 64 * pr.rows) + 24
+            pr2 = ProverRounds(hp).load_proving_key_raw(os.path.join(d, "merkle.pk"))
+            try:
+                assert pr2.prove(None, seed=4)["proof"] == out2["proof"]
+            finally:
+                pr2.free()
+            write_snark(os.path.join(d, "merkle.snark"), out2["proof"], out2["instances"])
+            rep = verify_file.main(os.path.join(d, "merkle.snark"), os.path.join(d, "merkle.vk"), TAU)
+            assert rep["accepted"] and not rep["tampered_byte_accepted"]
     finally:
         pr.free()
         hp.free()
@@ -441,6 +461,78 @@ def test_proving_key_round_trip_gives_the_same_proof(circuit, tmp_path):
             ProverRounds(other).load_proving_key(path)
     finally:
         other.free()
+
+
+def test_key_files_in_upstreams_layout(circuit, O, tmp_path):
+    """Keygen arm -> data/{name}.vk + data/{name}.pk in halo2's SerdeFormat::RawBytes layout (src/scaffold/mod.rs:273-281; io.py restates
+    the layout, [UPSTREAM-RECALL]) -> Prove arm (custom_read_pk, :325-331) -> Verify arm (custom_read_vk, :334-343): the layout field by
+    field, the same proof bytes from the loaded key, the proof accepted against the .vk file, another circuit's key refused."""
+    from halo2_vectordb_amd import api
+    from halo2_vectordb_amd.io import read_verifying_key_raw, write_snark
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    import verify_file
+    hp, pr = circuit
+    vk_path, pk_path = str(tmp_path / "kmeans.vk"), str(tmp_path / "kmeans.pk")
+    pr.save_verifying_key_raw(vk_path)
+    pr.save_proving_key_raw(pk_path)
+    raw = open(vk_path, "rb").read()
+    n, ne, n_fixed = pr.rows, pr.rows * 4, pr.n_adv + 2        # halo2's extended domain: 4n points at degree 4
+    pts = lambda a: np.ascontiguousarray(a, dtype="<u8").tobytes()
+    assert raw[:4] == pr.k.to_bytes(4, "big") and raw[4:8] == n_fixed.to_bytes(4, "big")
+    body = pts(pr.fixed["table"].commits) + pts(pr.fixed["cst"].commits) + pts(pr.fixed["sel"].commits) + pts(pr.fixed["sigma"].commits)
+    assert raw[8: 8 + len(body)] == body and len(raw) == 8 + len(body) + pr.n_adv * n // 8
+    meta, fixed, selectors = read_verifying_key_raw(vk_path, n_instances=len(pr.instance_cells))
+    assert {key: meta[key] for key in _meta(pr)} == _meta(pr)
+    assert all(np.array_equal(fixed[name], pr.fixed[name].commits) for name in FIXED)
+    # the selectors' bits: one per gate of the keygen witness, where the selector columns of the proving key are one
+    flags = hp.keygen_flags()
+    assert selectors.shape == (pr.n_adv, n) and int(selectors.sum()) == int((flags.download((hp.n_cells,), dtype=np.uint8) & 1).sum())
+    flags.free()
+    with open(pk_path, "rb") as f:
+        assert f.read(len(raw)) == raw                                     # the proving key starts with the verifying key
+        poly = lambda m: (int.from_bytes(f.read(4), "big"), np.frombuffer(f.read(32 * m), dtype="<u8").reshape(m, 4))
+        lag = [poly(ne) for _ in range(3)]
+        assert all(m == ne for m, _ in lag)
+        assert int.from_bytes(f.read(4), "big") == n_fixed
+        values = [poly(n) for _ in range(n_fixed)]
+        one = O.fr_from_ints([1])[0]
+        table = O.fr_to_ints(values[0][1])
+        assert [int(v) for v in table[: 1 << hp.L]] == list(range(1 << hp.L)) and not any(table[1 << hp.L:])      # the lookup table first
+        for bits, (_, v) in zip(selectors, values[2:]):
+            assert np.array_equal(v[bits], np.broadcast_to(one, v[bits].shape)) and not v[~bits].any()
+        assert int.from_bytes(f.read(4), "big") == n_fixed
+        coeffs = [poly(n) for _ in range(n_fixed)]
+        assert np.array_equal(O.ntt(coeffs[1][1].astype(np.uint64), O.root_of_unity(pr.k)), values[1][1])                # constants: coefficients <-> values
+        assert int.from_bytes(f.read(4), "big") == n_fixed
+        cosets = [poly(ne) for _ in range(n_fixed)]
+        assert np.array_equal(O.coeff_to_extended(coeffs[1][1].astype(np.uint64), 2), cosets[1][1])
+    size = len(raw) + 3 * (4 + 32 * ne) + (n_fixed + pr.n_perm) * ((4 + 32 * n) * 2 + 4 + 32 * ne) + 6 * 4
+    assert os.path.getsize(pk_path) == size
+    want = pr.prove(None, seed=77)
+    pr2 = ProverRounds(hp).load_proving_key_raw(pk_path)
+    try:
+        assert all(np.array_equal(pr2.fixed[name].commits, pr.fixed[name].commits) for name in FIXED)
+        assert pr2.instance_cells == pr.instance_cells
+        got = pr2.prove(None, seed=77)["proof"]
+        assert got == want["proof"] and len(got) > 0
+    finally:
+        pr2.free()
+    write_snark(str(tmp_path / "kmeans.snark"), want["proof"], want["instances"])
+    rep = verify_file.main(str(tmp_path / "kmeans.snark"), vk_path, TAU)
+    assert rep["accepted"] and not rep["tampered_byte_accepted"]
+    assert not verify_file.main(str(tmp_path / "kmeans.snark"), vk_path)["accepted"]             # the reference's SRS is not this fixture's
+    other = KmeansHotPath(n=8, dim=4, K=2, I=1, k=12, L=10, metric="cosine", tau=TAU).setup()
+    try:
+        with pytest.raises(ValueError):
+            ProverRounds(other).load_proving_key_raw(pk_path)
+    finally:
+        other.free()
+    with open(pk_path, "r+b") as f:                                         # a damaged file: l_active_row is not this circuit's
+        f.seek(len(raw) + 2 * (4 + 32 * ne) + 4 + 5)
+        f.write(b"\x01")
+    with pytest.raises(ValueError):
+        ProverRounds(hp).load_proving_key_raw(pk_path)
 
 
 def _verify(O, api, proof, vk):

@@ -125,3 +125,47 @@ def test_verifying_key_file_round_trip(tmp_path):
         read_verifying_key(path)
     with pytest.raises(ValueError):
         read_verifying_key(str(tmp_path / "absent.npz"))
+
+
+def test_halo2_rawbytes_key_layout_round_trips():
+    """io.write_vk_raw / read_vk_raw / write_polys_raw / read_polys_raw: halo2's SerdeFormat::RawBytes key layout as restated in io.py
+    ([UPSTREAM-RECALL], parity unpinned: the reference ships no key file) — big-endian u32 counts, Montgomery limbs little-endian,
+    selector bits packed least significant first"""
+    import io as _io
+    from halo2_vectordb_amd import io as vio
+    rng = np.random.default_rng(5)
+    k = 4
+    fixed = rng.integers(0, 1 << 63, (3, 8), dtype=np.uint64)
+    perm = rng.integers(0, 1 << 63, (5, 8), dtype=np.uint64)
+    sel = np.zeros((2, 16), dtype=bool)
+    sel[0, [0, 3, 9]] = True
+    sel[1, 15] = True
+    f = _io.BytesIO()
+    vio.write_vk_raw(f, k, fixed, perm, sel)
+    raw = f.getvalue()
+    assert raw[:8] == bytes([0, 0, 0, 4, 0, 0, 0, 3]) and len(raw) == 8 + 64 * 8 + 2 * 2
+    assert raw[8:16] == int(fixed[0, 0]).to_bytes(8, "little")
+    assert raw[-4:] == bytes([0b00001001, 0b00000010, 0, 0b10000000])
+    f.seek(0)
+    doc = vio.read_vk_raw(f, 5, 2)
+    assert doc["k"] == k and np.array_equal(doc["fixed_commitments"], fixed) and np.array_equal(doc["permutation_commitments"], perm)
+    assert np.array_equal(doc["selectors"], sel)
+    # the selectors in blocks give the same bytes
+    g = _io.BytesIO()
+    vio.write_vk_raw(g, k, fixed, perm, iter([sel[:1], sel[1:]]))
+    assert g.getvalue() == raw
+    with pytest.raises(ValueError):
+        vio.read_vk_raw(_io.BytesIO(raw[:-1]), 5, 2)
+    polys = rng.integers(0, 1 << 63, (3, 16, 4), dtype=np.uint64)
+    f = _io.BytesIO()
+    vio.write_polys_raw(f, iter([polys[:2], polys[2:]]), 3)
+    raw = f.getvalue()
+    assert raw[:8] == bytes([0, 0, 0, 3, 0, 0, 0, 16]) and len(raw) == 4 + 3 * (4 + 16 * 32)
+    f.seek(0)
+    assert np.array_equal(vio.read_polys_raw(f, 3, 16), polys)
+    f.seek(0)
+    assert vio.read_polys_raw(f, 3, 16, keep=False) == 3 and not f.read(1)
+    with pytest.raises(ValueError):
+        vio.read_polys_raw(_io.BytesIO(raw), 4, 16)
+    with pytest.raises(ValueError):
+        vio.write_polys_raw(_io.BytesIO(), iter([polys[:2]]), 3)

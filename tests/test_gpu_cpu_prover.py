@@ -194,3 +194,36 @@ def test_nearest_vector_circuit(api, O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_query_circuit_nearest_and_merkle_in_one(api, O):
+    """examples/query.rs:32-73 (tests/vectordb/mod.rs:220-247 chip_nearest_vector): nearest_vector(query, database) and
+    merkle_commitment(database) over the same assigned vectors in ONE circuit, the result vector and then the root public.  The map of
+    this circuit is placed block by block on the device (circuit_dev.py; tests/test_gpu_copymap.py holds that placement against the
+    host's construction); the CPU prover is handed its arrays as downloaded and the oracle's own witness, break points and gate starts."""
+    from halo2_vectordb_amd.pipeline import QueryHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import prover as PV
+    n, dim, k, P, L = 5, 4, 12, 48, 11
+    hp = QueryHotPath(n=n, dim=dim, k=k, P=P, L=L, tau=TAU).setup()
+    pr = ProverRounds(hp).keygen()
+    try:
+        assert pr.keygen_report.violations() == 0
+        rows = O.quantize(hp.vectors_f64, P)                    # row 0: the query, rows 1..n: the database
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        c.assign_witnesses(rows[0])
+        c.assign_witnesses(rows[1:])
+        ind, res = c.nearest_vector("euclidean", rows[0], rows[1:], P=P, L=L)
+        root = c.merkle_commitment(rows[1:])
+        stream = c.advice()
+        assert stream.shape[0] == hp.n_cells and c.n_lookup == hp.n_lookup
+        cm = pr.circuit
+        cs = PV.Circuit(k, L, c.break_points(), c.selectors(), c.n_lookup, cm.copy_of, cm.const_idx, cm.consts, cm.lookup_src, list(pr.instance_cells))
+        assert len(pr.instance_cells) == dim + 1 and np.array_equal(stream[pr.instance_cells[-1]], root)
+        _pk, outs = _compare(O, PV, hp, pr, cs, stream, c.lookup(), seeds=(34,))
+        assert outs[0]["instances"] == [int(v) for v in O.fr_to_ints(res)] + [_int(O, root)]     # examples/query.rs:58, :69
+        want = int(np.argmin(np.linalg.norm(hp.vectors_f64[1:] - hp.vectors_f64[0], axis=1)))
+        assert [int(v) for v in O.fr_to_ints(ind)].index(1) == want
+    finally:
+        pr.free()
+        hp.free()

@@ -258,7 +258,7 @@ def msm_batch_dev(srs, dev_ptr, n_cols, n, basis=1):
 
 
 # ---------------------------------------------------------------- fixed point + witness streams
-METRICS = dict(euclidean=0, cosine=1, manhattan=2)
+METRICS = dict(euclidean=0, cosine=1, manhattan=2, hamming=3)
 
 
 def quantize(x, P=48):

@@ -387,6 +387,11 @@ class Sym:
         if metric == "manhattan":                            # :177-195
             d = [self.g_sub(x, y) for x, y in zip(a, b)]
             return self.g_sum([self.qabs(x) for x in d])
+        if metric == "hamming":                              # :146-175; `len` and `ab_sum_q` are load_witness cells nothing ties
+            s = self.g_sum([self.g_is_equal(x, y) for x, y in zip(a, b)])
+            len_q, sum_q = self.push(None), self.push(None)
+            sim = self.qdiv(sum_q, len_q)
+            return self.g_sub(self.load_constant(quantize(1.0, self.P)), sim)
         raise ValueError(metric)
 
     # ------------------------------------------------------------------ VectorDBChip (vectordb.rs)

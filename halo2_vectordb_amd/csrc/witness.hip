@@ -153,7 +153,7 @@ static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
 }
 
 // ------------------------------------------------------------------ distance layout
-enum { M_EUCLID = 0, M_COSINE = 1, M_MANHATTAN = 2 };
+enum { M_EUCLID = 0, M_COSINE = 1, M_MANHATTAN = 2, M_HAMMING = 3 };
 struct DistLayout {
   uint32_t metric, D;
   uint64_t head_cells, head_lk, tail_cells, tail_lk, total_cells, total_lk;
@@ -182,8 +182,14 @@ static int dist_layout(const FpTables& T, int metric, size_t D, DistLayout* o) {
       o->tail_cells = 0;
       o->tail_lk = 0;
       break;
+    case M_HAMMING:  // distance.rs:146-175: is_equal per element (sub + is_zero), gate().sum, two load_witness, qdiv, load_constant, qsub
+      o->head_cells = 12 * D + (D == 0 ? 0 : (D == 1 ? 1 : 1 + 3 * (D - 1)));
+      o->head_lk = 0;
+      o->tail_cells = 2ull + z.qdiv[0] + 1 + 4;
+      o->tail_lk = z.qdiv[1];
+      break;
     default:
-      set_error("unsupported metric %d (0 euclidean, 1 cosine, 2 manhattan; hamming stays on the CPU)", metric);
+      set_error("unsupported metric %d (0 euclidean, 1 cosine, 2 manhattan, 3 hamming)", metric);
       return VDB_ERR_ARG;
   }
   o->total_cells = o->head_cells + o->tail_cells;
@@ -327,21 +333,28 @@ __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTable
     block_inner_product(st, T, a, b, 0, D, base, lbase, sh, &mid[3 * (size_t)t]);
     block_inner_product(st, T, a, a, 0, D, base + ipc, lbase + ipl, sh, &mid[3 * (size_t)t + 1]);
     block_inner_product(st, T, b, b, 0, D, base + 2 * ipc, lbase + 2 * ipl, sh, &mid[3 * (size_t)t + 2]);
-  } else {  // manhattan, distance.rs:177-195
+  } else {  // manhattan, distance.rs:177-195; hamming, distance.rs:146-175: one value per element, then gate().sum over them
+    const bool ham = dl.metric == M_HAMMING;
     const uint32_t qa = T->sz.qabs[0], qal = T->sz.qabs[1];
-    const uint64_t sumbase = base + 4ull * D + (uint64_t)D * qa;
+    const uint64_t sumbase = ham ? base + 12ull * D : base + 4ull * D + (uint64_t)D * qa;
     if (tid == 0) sh[HEAD_TB] = u256_zero();
     __syncthreads();
     for (uint32_t c0 = 0; c0 < D; c0 += HEAD_TB) {
       uint32_t i = c0 + tid;
       u256 v = u256_zero();
       if (i < D) {
-        WCtx c = make_ctx(st, T, base + 4ull * i, lbase);
-        Gadgets g(c);
-        u256 d = g.g_sub(a[i], b[i]);
-        c.pos = base + 4ull * D + (uint64_t)i * qa;
-        c.lpos = lbase + (uint64_t)i * qal;
-        v = g.fp_qabs(d);
+        if (ham) {  // gate().is_equal(a_i, b_i): [a - b, b, 1, a] then is_zero's eight cells
+          WCtx c = make_ctx(st, T, base + 12ull * i, lbase);
+          Gadgets g(c);
+          v = g.g_is_equal(a[i], b[i]);
+        } else {
+          WCtx c = make_ctx(st, T, base + 4ull * i, lbase);
+          Gadgets g(c);
+          u256 d = g.g_sub(a[i], b[i]);
+          c.pos = base + 4ull * D + (uint64_t)i * qa;
+          c.lpos = lbase + (uint64_t)i * qal;
+          v = g.fp_qabs(d);
+        }
       }
       sh[tid] = v;
       __syncthreads();
@@ -368,7 +381,12 @@ __global__ __launch_bounds__(HEAD_TB) void k_dist_head(Streams st, const FpTable
       }
       __syncthreads();
     }
-    if (tid == 0) result[t] = sh[HEAD_TB];
+    if (tid == 0) {
+      if (ham)
+        mid[3 * (size_t)t] = sh[HEAD_TB];   // the number of equal elements: the tail quantizes it
+      else
+        result[t] = sh[HEAD_TB];
+    }
   }
 }
 
@@ -392,6 +410,16 @@ __global__ __launch_bounds__(64) void k_dist_tail(Streams st, const FpTables* __
   u256 r;
   if (dl.metric == M_EUCLID) {
     r = g.fp_qsqrt(mid[3 * (size_t)t]);
+  } else if (dl.metric == M_HAMMING) {
+    // len = load_witness(quantization(D)), ab_sum_q = load_witness(quantization(the count as f64)): both exact (an integer times 2^P),
+    // neither constrained by the reference (distance.rs:165-169); 1 - ab_sum_q / len
+    const u256 len = fr_mul(to_mont<Fr>(u256_from_u64(dl.D)), T->scale);
+    const u256 sq = fr_mul(mid[3 * (size_t)t], T->scale);
+    c.push(len, false);
+    c.push(sq, false);
+    u256 sim = g.fp_qdiv(sq, len);
+    u256 one = g.load_constant(T->c_one_q);
+    r = g.g_sub(one, sim);
   } else {
     u256 ab = mid[3 * (size_t)t], aa = mid[3 * (size_t)t + 1], bb = mid[3 * (size_t)t + 2];
     u256 as = g.fp_qsqrt(aa);
@@ -438,6 +466,8 @@ __global__ __launch_bounds__(64) void k_dist_values(const FpTables* __restrict__
       s0 = fr_add(s0, g.v_qmul(x, y));
       s1 = fr_add(s1, g.v_qmul(x, x));
       s2 = fr_add(s2, g.v_qmul(y, y));
+    } else if (dl.metric == M_HAMMING) {
+      if (u256_eq(x, y)) s0 = fr_add(s0, mont_one<Fr>());
     } else {
       s0 = fr_add(s0, g.v_qabs(fr_sub(x, y)));
     }
@@ -472,6 +502,16 @@ __global__ __launch_bounds__(64) void k_dist_tail_values(Streams st, const FpTab
   u256 r;
   if (dl.metric == M_EUCLID) {
     r = g.fp_qsqrt(mid[3 * (size_t)t]);
+  } else if (dl.metric == M_HAMMING) {
+    // len = load_witness(quantization(D)), ab_sum_q = load_witness(quantization(the count as f64)): both exact (an integer times 2^P),
+    // neither constrained by the reference (distance.rs:165-169); 1 - ab_sum_q / len
+    const u256 len = fr_mul(to_mont<Fr>(u256_from_u64(dl.D)), T->scale);
+    const u256 sq = fr_mul(mid[3 * (size_t)t], T->scale);
+    c.push(len, false);
+    c.push(sq, false);
+    u256 sim = g.fp_qdiv(sq, len);
+    u256 one = g.load_constant(T->c_one_q);
+    r = g.g_sub(one, sim);
   } else {
     u256 ab = mid[3 * (size_t)t], aa = mid[3 * (size_t)t + 1], bb = mid[3 * (size_t)t + 2];
     u256 as = g.fp_qsqrt(aa);

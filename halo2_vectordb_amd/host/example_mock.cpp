@@ -5,7 +5,7 @@
 // a + b c = d, every lookup cell against the range table 0 .. 2^LOOKUP_BITS - 1, every lookup cell against the advice cell it
 // copies, every constant cell against the keygen-time stream — through the C ABI alone (vdb_mock_check_dev).
 // The GPUs are bound through the multi-device lifecycle (vdb_init_devices), the thread works on device 0.
-// Usage: example_mock <metric: 0 euclidean | 1 cosine | 2 manhattan> <lookup_bits> [tamper_cell]  < "dim a_0 .. a_{dim-1} b_0 .. b_{dim-1}"
+// Usage: example_mock <metric: 0 euclidean | 1 cosine | 2 manhattan | 3 hamming> <lookup_bits> [tamper_cell]  < "dim a_0 .. a_{dim-1} b_0 .. b_{dim-1}"
 // Prints the cell counts and the report; exit code 0 when the circuit is satisfied, 4 when it is not.
 #include <cstdio>
 #include <iostream>

@@ -31,7 +31,7 @@ inline void check(int rc) {
 }
 
 using F = vdb_fr;
-enum class Metric : int { Euclidean = 0, Cosine = 1, Manhattan = 2 };
+enum class Metric : int { Euclidean = 0, Cosine = 1, Manhattan = 2, Hamming = 3 };
 
 // halo2-base AssignedValue in witness_gen_only mode: the value; `cell` is the stream index when known
 struct AssignedValue {
@@ -142,6 +142,10 @@ class DistanceChip {
   }
   AssignedValue manhattan_distance(Context& ctx, const std::vector<AssignedValue>& a, const std::vector<AssignedValue>& b) const {
     return distance(ctx, Metric::Manhattan, a, b);
+  }
+  // one minus the share of equal elements (distance.rs:146-175)
+  AssignedValue hamming_distance(Context& ctx, const std::vector<AssignedValue>& a, const std::vector<AssignedValue>& b) const {
+    return distance(ctx, Metric::Hamming, a, b);
   }
 };
 

@@ -734,13 +734,12 @@ class QueryHotPath(NearestHotPath):
 
 class DistancesHotPath(KmeansHotPath):
     """The reference's two-vector circuits through the same hot path: examples/distances.rs:29-59 (assign a, assign b, then
-    euclidean, manhattan and cosine distance of the same two vectors, each made public; the Hamming distance of that example is
-    outside the GPU path) and examples/euclid.rs:26-46 (ten Euclidean distances of one pair, nothing public:
+    euclidean, manhattan, cosine and hamming distance of the same two vectors, each made public) and examples/euclid.rs:26-46 (ten Euclidean distances of one pair, nothing public:
     `metrics=("euclidean",) * 10, public=False`).  BASELINE configs[0] is this circuit with one Euclidean distance of two 4-dim
     vectors at k = 13, LOOKUP_BITS = 12.  Stream: [a | b | the cells of each distance in turn]; every rank emits every cell (a few
     columns: nothing to shard the witness by)."""
 
-    def __init__(self, dim=4, metrics=("euclidean", "manhattan", "cosine"), k=13, P=48, L=12, seed=20260001, tau=None, col_shard=(0, 1), vectors=None,
+    def __init__(self, dim=4, metrics=("euclidean", "manhattan", "cosine", "hamming"), k=13, P=48, L=12, seed=20260001, tau=None, col_shard=(0, 1), vectors=None,
                  blind_seed=None, public=True):
         """`vectors`: (2, dim) f64 rows, a then b"""
         super().__init__(n=2, dim=dim, K=1, I=1, k=k, P=P, L=L, metric=metrics[0], seed=seed, tau=tau, col_shard=col_shard, vectors=vectors,

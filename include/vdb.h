@@ -127,7 +127,8 @@ int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr *x, double *out, siz
 /* ---- b5 witness streams.  Each call emits exactly the cells the Rust gadget pushes into
  *      halo2-base `Context.advice` (stream_out) and `cells_to_lookup` (lookup_out), in order, for
  *      already-assigned quantized inputs; sizes come from the matching *_size call.
- *      metric: 0 euclidean, 1 cosine, 2 manhattan (DistanceChip, src/gadget/distance.rs:97-195).
+ *      metric: 0 euclidean, 1 cosine, 2 manhattan, 3 hamming (DistanceChip, src/gadget/distance.rs:97-195; hamming = one minus the
+ *      share of equal elements, its two load_witness cells unconstrained as in the reference, :165-169).
  *      selector_out (optional, 1 flag byte per advice cell): bit 0 marks gate starts — the keygen-side information
  *      from which vdb_layout_plan derives the break points that the reference pins in configs/<name>.json
  *      (src/scaffold/mod.rs:272, 285-287); bit 1 marks cells that hold a data-independent QuantumCell::Constant

@@ -19,13 +19,15 @@ def clean(rep, allow_asserts=False):
     return not bad, bad
 
 
-@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan"])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan", "hamming"])
 @pytest.mark.parametrize("dim,P,L", [(3, 48, 12), (5, 32, 10), (1, 48, 13)])
 def test_distance_map_on_oracle_witnesses(O, metric, dim, P, L):
     cm, outs = CS.trace_distance(metric, dim, P, L)
     rng = np.random.default_rng(dim * 7 + L)
     for trial in range(2):
         a, b = rng.uniform(-3, 3, dim), rng.uniform(-3, 3, dim)
+        if trial and metric == "hamming":
+            b[0] = a[0]                                       # one equal pair: what the Hamming distance counts
         qa, qb = O.quantize(a, P), O.quantize(b, P)
         c = O.Ctx(store=True, keygen=True)
         c.assign_witnesses(qa)
@@ -38,13 +40,13 @@ def test_distance_map_on_oracle_witnesses(O, metric, dim, P, L):
         assert vals[outs[0]] == to_ints(O, res)[0]
     # most cells are tied to something: copies, constants, asserted constants
     tied = (cm.copy_of != np.arange(cm.n_cells)) | (cm.const_idx >= 0)
-    assert tied.mean() > 0.4 and cm.asserted.sum() == (0 if metric == "manhattan" else (8 if metric == "euclidean" else 16))   # per qlog2: is_invalid, 3 x 2 in check_power_of_two, the bracket
+    assert tied.mean() > 0.4 and cm.asserted.sum() == (0 if metric in ("manhattan", "hamming") else (8 if metric == "euclidean" else 16))   # per qlog2: is_invalid, 3 x 2 in check_power_of_two, the bracket
 
 
 def test_distances_example_map_on_the_oracles_witness(O):
-    """examples/distances.rs:40-59: three distances of the same two assigned vectors in one context; the map's outputs are the cells
+    """examples/distances.rs:40-59: the four distances of the same two assigned vectors in one context; the map's outputs are the cells
     the example makes public"""
-    metrics = ("euclidean", "manhattan", "cosine")
+    metrics = ("euclidean", "manhattan", "cosine", "hamming")
     cm, outs = CS.trace_distances(metrics, 3, 48, 12)
     qa, qb = O.quantize(np.array([0.123, 0.456, 1.789])), O.quantize(np.array([1.123, 0.456, 0.789]))
     c = O.Ctx(store=True, keygen=True)
@@ -56,8 +58,8 @@ def test_distances_example_map_on_the_oracles_witness(O):
     ok, bad = clean(cm.check_witness(vals, to_ints(O, c.lookup()), flags=c.selectors()))
     assert ok, bad
     assert [vals[o] for o in outs] == [to_ints(O, r)[0] for r in res]
-    # every distance reads the assigned vectors themselves: each of the six input cells is copied by all three
-    assert all(int((cm.copy_of == cell).sum()) >= 4 for cell in range(6))
+    # every distance reads the assigned vectors themselves: each of the six input cells is copied by all four
+    assert all(int((cm.copy_of == cell).sum()) >= 5 for cell in range(6))
 
 
 def test_sqrt_of_zero_violates_its_asserted_constant(O):

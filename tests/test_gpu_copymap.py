@@ -25,7 +25,7 @@ def table(O, consts):
     return O.fr_from_ints(consts) if len(consts) else np.zeros((1, 4), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan"])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan", "hamming"])
 def test_distance_witness_against_the_symbolic_map(api, O, metric):
     """examples/distances.rs shape (two assigned vectors, one distance), P = 48, LOOKUP_BITS = 12: the GPU's cells under the
     whole map, on the device checker"""

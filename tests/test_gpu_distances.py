@@ -27,9 +27,9 @@ def _same_stream(hp, c, O):
     assert np.array_equal(flags & 1, c.selectors().astype(np.uint8)[: hp.n_cells] & 1)
 
 
-def test_distances_example_proves_with_its_three_public_distances(api, O):
+def test_distances_example_proves_with_its_four_public_distances(api, O):
     """examples/distances.rs on data/distances.in (k and LOOKUP_BITS of the README's command line): [a | b | euclidean | manhattan |
-    cosine] is the oracle's context up to where its Hamming distance starts; the three distances are the proof's instances"""
+    cosine | hamming] is the oracle's whole context; the four distances are the proof's instances"""
     from halo2_vectordb_amd.pipeline import DistancesHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     from oracle import pairing as PR
@@ -38,28 +38,29 @@ def test_distances_example_proves_with_its_three_public_distances(api, O):
     hp = DistancesHotPath(dim=len(d["a"]), k=cfg["k"], L=cfg["L"], tau=TAU, vectors=np.array([d["a"], d["b"]], dtype=np.float64)).setup()
     pr = None
     try:
-        assert hp.n_cells == r["offsets"][("hamming", 3)][0] and hp.n_lookup == r["offsets"][("hamming", 3)][1]
+        assert hp.n_cells == len(r["ctx"]) and hp.n_lookup == r["ctx"].n_lookup and hp.n_cells > r["offsets"][("hamming", 3)][0]
         _same_stream(hp, r["ctx"], O)
-        want = [r["results"][(m, i)] for i, m in enumerate(("euclidean", "manhattan", "cosine"))]
+        want = [r["results"][(m, i)] for i, m in enumerate(("euclidean", "manhattan", "cosine", "hamming"))]
         assert np.array_equal(hp.results(), np.stack(want))
         for m, got in zip(hp.metrics, api.dequantize(hp.results())):
             f = E.F64[m](d["a"], d["b"])
             assert abs(float(got) - f) <= 1e-6 * max(abs(f), 1.0)              # assert_float_relative_eq! of tests/distances_test.rs
         pr = ProverRounds(hp).keygen()
         assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
-        assert len(pr.instance_cells) == 3
+        assert len(pr.instance_cells) == 4
         out = pr.prove(None, seed=3)
         assert out["instances"] == O.fr_to_ints(np.stack(want))
         assert quotient_identity_holds(pr, out["challenges"], out["evals"], out["instances"])
         vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
         assert _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
-        for i in range(3):                                                    # another distance than the circuit computed
+        for i in range(4):                                                    # another distance than the circuit computed
             other = list(out["instances"])
             other[i] = (other[i] + 1) % O.R_MOD
             assert not _verify(O, api, out["proof"], {**vk, "instances": other})
         # other vectors under the same key
         rng = np.random.default_rng(9)
         v = rng.random((2, hp.dim))
+        v[1, 1] = v[0, 1]
         hp.set_vectors(v)
         out2 = pr.prove(None)
         assert _verify(O, api, out2["proof"], {**vk, "instances": out2["instances"]}) and out2["instances"] != out["instances"]

@@ -33,14 +33,12 @@ def same_cells(got, c, off, n_adv=None, n_lk=None):
 
 
 def test_distances_in(api, O):
-    """examples/distances.rs on data/distances.in: euclidean, manhattan, cosine (Hamming is CPU-only: SURVEY 2 #3)"""
+    """examples/distances.rs on data/distances.in: euclidean, manhattan, cosine, hamming"""
     r = E.oracle_distances(O)
     d, L = E.load("distances"), E.README["distances"]["L"]
     qa, qb = api.quantize([d["a"]]), api.quantize([d["b"]])
     assert np.array_equal(qa[0], r["qa"]) and np.array_equal(qb[0], r["qb"])
     for (m, i), want in r["results"].items():
-        if m == "hamming":
-            continue
         got = api.wit_distance(m, qa, qb, L=L, selectors=True)
         assert np.array_equal(got["result"][0], want)
         same_cells(got, r["ctx"], r["offsets"][(m, i)])

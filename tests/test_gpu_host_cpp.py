@@ -79,7 +79,7 @@ def test_example_mock_is_the_mock_arm_in_compiled_code(O):
     a, b = [0.123, 0.456, 1.789, 1.123], [1.123, 0.456, 0.789, 0.123]
     txt = "4 " + " ".join(repr(x) for x in a + b) + "\n"
     qa, qb = O.quantize(np.array(a)), O.quantize(np.array(b))
-    for metric, name in ((0, "euclidean"), (1, "cosine"), (2, "manhattan")):
+    for metric, name in ((0, "euclidean"), (1, "cosine"), (2, "manhattan"), (3, "hamming")):
         out = subprocess.run([exe, str(metric), "12"], input=txt, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, (out.stdout, out.stderr)
         c = O.Ctx(store=True, keygen=True)

@@ -47,7 +47,7 @@ def test_quantize_dequantize_host(api, O):
         assert np.array_equal(api.dequantize(q, P), O.dequantize(q, P), equal_nan=True)
 
 
-@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan"])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan", "hamming"])
 @pytest.mark.parametrize("L,dim", [(12, 4), (13, 10), (15, 128), (13, 1), (13, 130)])
 def test_distance_streams(api, O, metric, L, dim):
     rng = np.random.default_rng(600 + L + dim)
@@ -57,6 +57,7 @@ def test_distance_streams(api, O, metric, L, dim):
     if dim == 128:
         a, b = sift_like(rng, n, dim), sift_like(rng, n, dim)
     a[0] = b[0]  # distance 0: qsqrt(0) quirk path
+    a[1, ::3] = b[1, ::3]  # some equal elements (what the Hamming distance counts)
     qa, qb = O.quantize(a), O.quantize(b)
     got = api.wit_distance(metric, qa, qb, L=L, selectors=True)
     c, res = oracle_distance(O, metric, qa, qb, L)
@@ -72,6 +73,8 @@ def test_distance_reference_data(api, O):
     assert abs(float(api.dequantize(got["result"])[0]) - 2 ** 0.5) < 1e-6 * 2 ** 0.5
     man = api.wit_distance("manhattan", qa, qb, L=12)
     assert O.fr_to_ints(man["result"])[0] == 2 << 48
+    ham = api.wit_distance("hamming", qa, qb, L=12)                       # one of three elements equal: 1 - 1/3
+    assert abs(float(api.dequantize(ham["result"])[0]) - 2 / 3) < 1e-6
 
 
 def test_distance_other_precision(api, O):
@@ -85,7 +88,7 @@ def test_distance_other_precision(api, O):
     assert_streams(got, c)
 
 
-@pytest.mark.parametrize("metric,n,dim", [("euclidean", 4, 4), ("euclidean", 9, 16), ("cosine", 5, 8), ("manhattan", 70, 3)])
+@pytest.mark.parametrize("metric,n,dim", [("euclidean", 4, 4), ("euclidean", 9, 16), ("cosine", 5, 8), ("manhattan", 70, 3), ("hamming", 6, 5)])
 def test_nearest_vector(api, O, metric, n, dim):
     rng = np.random.default_rng(700 + n)
     db = rng.random((n, dim))

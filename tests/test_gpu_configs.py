@@ -164,6 +164,45 @@ def test_sharded_ranks_reproduce_the_unsharded_job(api, O, world, metric):
     assert np.array_equal(np.concatenate(adv + lk), want_commit)
 
 
+def test_sharded_kmeans_with_the_hamming_distance(api, O):
+    """the same for the distance that counts equal elements (distance.rs:146-175; its value-only form serves the ranks that store
+    other columns): two groups of vectors that agree on most coordinates, so that equal elements exist at all — against the oracle's
+    cells on one rank, and two ranks against one"""
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    rng = np.random.default_rng(8)
+    vec = np.repeat(np.array([[0.25] * 6, [1.5] * 6]), 6, axis=0)[[0, 6, 1, 7, 2, 8, 3, 9, 4, 10, 5, 11]]      # A, B, A, B, ...
+    for i in range(2, 12):
+        vec[i, rng.integers(0, 6)] += 0.125 * (1 + i)                      # one coordinate of its own each
+    cfg = dict(n=12, dim=6, K=2, I=2, k=10, P=48, L=9, metric="hamming", blind_seed=4, vectors=vec)
+    full = KmeansHotPath(**cfg).setup()
+    want_commit = full.step().copy()
+    want_cent, want_ind = full.results()
+    c = O.Ctx(store=True)
+    q = O.quantize(vec, 48)
+    c.assign_witnesses(q)
+    cent, ind = c.kmeans("hamming", q, 2, 2, P=48, L=9)
+    assert np.array_equal(want_cent, cent) and np.array_equal(want_ind, ind)
+    assert np.array_equal(full.d_stream.download((full.n_cells, 4)), c.advice()) and np.array_equal(full.d_lookup.download((full.n_lookup, 4)), c.lookup())
+    assert sorted(np.array(O.fr_to_ints(ind.reshape(-1, 4)), dtype=object).reshape(12, 2).sum(axis=0).tolist()) == [6 << 48, 6 << 48]   # both clusters keep their six
+    full.relayout()
+    want_cols = full.download_columns(list(range(full.n_cols)))
+    full.free()
+    got = []
+    for r in range(2):
+        hp = KmeansHotPath(col_shard=(r, 2), **cfg).setup()
+        assert hp.lib.vdb_memset_dev(hp.d_stream.ptr, 0xA5, hp.n_cells * 32) == 0
+        assert hp.lib.vdb_memset_dev(hp.d_lookup.ptr, 0xA5, max(hp.n_lookup, 1) * 32) == 0
+        com = hp.step().copy()
+        got.append((com[: hp.my_adv], com[hp.my_adv:]))
+        hp.relayout()
+        mine = hp.global_columns()
+        assert np.array_equal(hp.download_columns(mine), want_cols[mine]), f"rank {r} columns"
+        cent_r, ind_r = hp.results()
+        assert np.array_equal(cent_r, want_cent) and np.array_equal(ind_r, want_ind)
+        hp.free()
+    assert np.array_equal(np.concatenate([g[0] for g in got] + [g[1] for g in got]), want_commit)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_nearest_vector_ranks_reproduce_the_unsharded_job(api, O, world):
     """SURVEY §8(e) for nearest_vector: "gather N distances then the short min chain" — here every rank computes the N distance

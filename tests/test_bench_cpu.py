@@ -51,8 +51,12 @@ def test_traffic_is_withheld_when_the_kernel_source_changed(tmp_path, monkeypatc
     # another kernel's file changes: this kernel's counters still stand
     (csrc / "msm.hip").write_text('__global__ void k_msm_accum(int* a) { a[0] = 3; }\n')
     assert bench.pmc_traffic_per_launch("k_ntt_pass")[2] is False
+    # a header the kernel includes changes in its comments and its spacing only: the same code, the same counters
+    (csrc / "field.hpp").write_text("// field, its documentation edited\n\n/* more\n   words */\n")
+    (csrc / "ntt.hip").write_text('#include "field.hpp"  // the field\nnamespace vdb {\n__global__ __launch_bounds__(256)\n    void k_ntt_pass(int* a) { a[0] = 1; }\n}\n')
+    assert bench.pmc_traffic_per_launch("k_ntt_pass")[2] is False
     # a header the kernel includes changes: the counters no longer describe what runs
-    (csrc / "field.hpp").write_text("// field, edited\n")
+    (csrc / "field.hpp").write_text("// field\nstruct Edited {};\n")
     assert bench.pmc_traffic_per_launch("k_ntt_pass") == (None, "r02_pmc_summary.csv", True)
 
 

@@ -829,9 +829,12 @@ __global__ __launch_bounds__(64) void k_km_div(Streams st, const FpTables* __res
 }
 __global__ void k_push_cells(Streams st, uint64_t pos, u256 a, u256 b, uint32_t n) {
   if (blockIdx.x || threadIdx.x) return;
-  st.adv[pos] = a;  // load_constant / load_zero cells: data-independent
-  if (st.sel) st.sel[pos] = 2;
-  if (n > 1) {
+  // load_constant / load_zero cells: data-independent; stored by the rank whose window holds them, like every other cell
+  if (pos >= st.rlo && pos < st.rhi) {
+    st.adv[pos] = a;
+    if (st.sel) st.sel[pos] = 2;
+  }
+  if (n > 1 && pos + 1 >= st.rlo && pos + 1 < st.rhi) {
     st.adv[pos + 1] = b;
     if (st.sel) st.sel[pos + 1] = 2;
   }

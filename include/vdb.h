@@ -134,7 +134,7 @@ int vdb_fp_dequantize(uint32_t precision_bits, const vdb_fr *x, double *out, siz
  *      (src/scaffold/mod.rs:272, 285-287); bit 1 marks cells that hold a data-independent QuantumCell::Constant
  *      of the gate templates (used by vdb_msm_batch_masked_dev).  VDB_ERR_DOMAIN replaces the reference's panics. ---------- */
 int vdb_wit_distance_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n_pairs, size_t dim, uint64_t *cells, uint64_t *lookups);
-/* DistanceChip::{euclidean,cosine,manhattan}_distance for n_pairs independent (a_i, b_i) */
+/* DistanceChip::{euclidean,cosine,manhattan,hamming}_distance for n_pairs independent (a_i, b_i) */
 int vdb_wit_distance(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a, const vdb_fr *b, size_t n_pairs, size_t dim,
                      vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *result_out);
 /* the same with inputs and outputs resident in HBM (the distances circuit of examples/distances.rs / examples/euclid.rs inside the hot
@@ -145,12 +145,12 @@ int vdb_wit_distance_dev(int metric, uint32_t precision_bits, uint32_t lookup_bi
 int vdb_wit_nearest_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, uint64_t *cells, uint64_t *lookups);
 int vdb_wit_nearest(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *query, const vdb_fr *vectors, size_t n, size_t dim,
                     vdb_fr *stream_out, vdb_fr *lookup_out, uint8_t *selector_out, vdb_fr *indicator_out, vdb_fr *result_out);
-/* VectorDBChip::kmeans::<K, I> (src/gadget/vectordb.rs:225-362): centroids K x dim, indicators n x K
- * (quantized 1.0 / 0).  zero_cached: Context::load_zero already called earlier in this context. */
-/* the same on device-resident buffers (query_dev: dim, vectors_dev: n x dim; outputs stay in HBM); always emits the whole
- * stream (the rank window of vdb_wit_set_window is not applied: the running minimum is one sequential chain) */
+/* the same on device-resident buffers (query_dev: dim, vectors_dev: n x dim; outputs stay in HBM); honours vdb_wit_set_window:
+ * a rank stores the cells of its own columns, every rank computes every value (the n distances, the short minimum chain) */
 int vdb_wit_nearest_dev(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *query_dev, const vdb_fr *vectors_dev, size_t n, size_t dim,
                         vdb_fr *stream_dev, vdb_fr *lookup_dev, uint8_t *selector_dev, vdb_fr *indicator_dev, vdb_fr *result_dev);
+/* VectorDBChip::kmeans::<K, I> (src/gadget/vectordb.rs:225-362): centroids K x dim, indicators n x K
+ * (quantized 1.0 / 0).  zero_cached: Context::load_zero already called earlier in this context. */
 int vdb_wit_kmeans_size(int metric, uint32_t precision_bits, uint32_t lookup_bits, size_t n, size_t dim, size_t K, size_t I, int zero_cached,
                         uint64_t *cells, uint64_t *lookups);
 int vdb_wit_kmeans(int metric, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *vectors, size_t n, size_t dim, size_t K, size_t I,

@@ -1,0 +1,216 @@
+"""A seeded sweep over shapes the fixed cases of tests/test_gpu_witness.py do not name: every gadget entry point at random sizes, all
+four distances, both precisions the reference's examples use, lookup widths 8 .. 15 — advice cells, lookup cells, gate flags and
+results against the oracle, bit for bit; then the same traces stored through random rank windows (vdb_wit_set_window): every cell
+inside the window equal, every cell outside it untouched.  Where the oracle reports a domain error (the reference would panic: an
+empty cluster's division) the library must refuse with VDB_ERR_DOMAIN instead of returning cells."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from test_gpu_witness import assert_streams
+
+pytestmark = pytest.mark.gpu
+
+METRICS = ("euclidean", "cosine", "manhattan", "hamming")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from halo2_vectordb_amd import api as a
+    a.init()
+    return a
+
+
+def _vectors(rng, n, dim, metric):
+    v = rng.uniform(-2.5, 2.5, size=(n, dim))
+    if metric == "hamming":                       # equal elements have to exist for the count to mean anything
+        v = rng.integers(0, 3, size=(n, dim)).astype(np.float64) * 0.5
+    if metric == "cosine":                        # no zero vector: the cosine of one is a division by zero
+        v[np.abs(v).sum(axis=1) == 0, 0] = 1.0
+    return v
+
+
+def test_random_shapes_of_every_gadget_against_the_oracle(api, O):
+    rng = np.random.default_rng(20261005)
+    refused = 0
+    for case in range(36):
+        metric = METRICS[case % 4]
+        P = 48 if case % 5 else 32
+        L = int(rng.integers(8, 16))
+        kind = ("distance", "nearest", "kmeans")[case % 3]
+        dim = int(rng.choice([1, 2, 3, 5, 8, 17, 64, 65, 129]))
+        c = O.Ctx(store=True, keygen=True)
+        tag = f"case {case}: {kind} {metric} P={P} L={L} dim={dim}"
+        if kind == "distance":
+            n = int(rng.integers(1, 70))
+            a, b = _vectors(rng, n, dim, metric), _vectors(rng, n, dim, metric)
+            qa, qb = O.quantize(a, P), O.quantize(b, P)
+            want = np.stack([c.distance(metric, x, y, P=P, L=L) for x, y in zip(qa, qb)])
+            call = lambda: api.wit_distance(metric, qa, qb, P=P, L=L, selectors=True)
+            results = lambda got: np.array_equal(got["result"], want)
+        elif kind == "nearest":
+            n = int(rng.integers(1, 40))
+            db, q = _vectors(rng, n, dim, metric), _vectors(rng, 1, dim, metric)[0]
+            qq, qdb = O.quantize(q, P), O.quantize(db, P)
+            ind, res = c.nearest_vector(metric, qq, qdb, P=P, L=L)
+            call = lambda: api.wit_nearest(metric, qq, qdb, P=P, L=L, selectors=True)
+            results = lambda got: np.array_equal(got["indicator"], ind) and np.array_equal(got["result"], res)
+        else:
+            n = int(rng.integers(3, 40))
+            K, I = int(rng.integers(1, min(n, 5))), int(rng.integers(1, 4))
+            tag += f" n={n} K={K} I={I}"
+            qv = O.quantize(_vectors(rng, n, dim, metric) + (0.0 if metric == "hamming" else 3.0), P)
+            cent, ind = c.kmeans(metric, qv, K, I, P=P, L=L)
+            call = lambda: api.wit_kmeans(metric, qv, K, I, P=P, L=L, selectors=True)
+            results = lambda got: np.array_equal(got["centroids"], cent) and np.array_equal(got["indicators"], ind)
+        if c.err:
+            with pytest.raises(api.VdbError) as e:
+                call()
+            assert e.value.code == -5, tag
+            refused += 1
+            continue
+        got = call()
+        assert results(got), tag
+        try:
+            assert_streams(got, c)
+        except AssertionError as e:
+            raise AssertionError(tag + ": " + str(e)) from e
+    assert refused <= 12          # the sweep is not allowed to degenerate into error cases
+
+
+def test_random_rank_windows_store_their_cells_and_nothing_else(api, O):
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    rng = np.random.default_rng(777)
+    POISON = np.uint64(0xA5A5A5A5A5A5A5A5)
+    done = 0
+    for case in range(14):
+        metric = METRICS[case % 4]
+        P, L = 48, int(rng.integers(9, 14))
+        n, dim = int(rng.integers(6, 30)), int(rng.choice([3, 8, 33, 70]))
+        K, I = int(rng.integers(2, 4)), int(rng.integers(1, 3))
+        qv = O.quantize(_vectors(rng, n, dim, metric) + (0.0 if metric == "hamming" else 3.0), P)
+        c = O.Ctx(store=True)
+        cent, ind = c.kmeans(metric, qv, K, I, P=P, L=L)
+        if c.err:
+            continue
+        adv, lk = c.advice(), c.lookup()
+        lo, hi = sorted(int(x) for x in rng.integers(0, len(adv) + 1, 2))
+        llo, lhi = sorted(int(x) for x in rng.integers(0, len(lk) + 1, 2))
+        bufs = [api.DeviceBuffer(max(x, 32)) for x in (qv.nbytes, adv.nbytes, lk.nbytes, cent.nbytes, ind.nbytes)]
+        d_vec, d_adv, d_lk, d_cent, d_ind = bufs
+        try:
+            d_vec.upload(qv)
+            check(lib.vdb_memset_dev(d_adv.ptr, 0xA5, ctypes.c_size_t(adv.nbytes)))
+            check(lib.vdb_memset_dev(d_lk.ptr, 0xA5, ctypes.c_size_t(max(lk.nbytes, 32))))
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(llo), ctypes.c_uint64(lhi)))
+            try:
+                check(lib.vdb_wit_kmeans_dev(api.METRICS[metric], P, L, d_vec.ptr, n, dim, K, I, 0, d_adv.ptr, d_lk.ptr, None, d_cent.ptr, d_ind.ptr))
+            finally:
+                check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2 ** 64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2 ** 64 - 1)))
+            g_adv, g_lk = d_adv.download(adv.shape), d_lk.download(lk.shape) if len(lk) else lk
+            tag = f"case {case}: {metric} n={n} dim={dim} K={K} I={I} L={L} window [{lo}, {hi}) / [{llo}, {lhi})"
+            assert np.array_equal(g_adv[lo:hi], adv[lo:hi]), tag
+            assert (g_adv[:lo] == POISON).all() and (g_adv[hi:] == POISON).all(), tag
+            if len(lk):
+                # a lookup cell is stored by the rank that stores the advice cell it copies: inside both windows it must be there,
+                # outside the lookup window it must not
+                inside = g_lk[llo:lhi]
+                stored = ~(inside == POISON).all(axis=1)
+                assert np.array_equal(inside[stored], lk[llo:lhi][stored]), tag
+                assert (g_lk[:llo] == POISON).all() and (g_lk[lhi:] == POISON).all(), tag
+                if lo == 0 and hi == len(adv):
+                    assert stored.all(), tag
+            # every rank computes every value
+            assert np.array_equal(d_cent.download(cent.shape), cent) and np.array_equal(d_ind.download(ind.shape), ind), tag
+            done += 1
+        finally:
+            for b in bufs:
+                b.free()
+    assert done >= 8
+
+
+def _windowed(api, lib, check, adv, lk, window, run):
+    """runs `run(d_adv, d_lk)` on poisoned device streams under the rank window; -> the streams as left behind"""
+    POISON = 0xA5
+    lo, hi, llo, lhi = window
+    d_adv, d_lk = api.DeviceBuffer(max(adv.nbytes, 32)), api.DeviceBuffer(max(lk.nbytes, 32))
+    try:
+        check(lib.vdb_memset_dev(d_adv.ptr, POISON, ctypes.c_size_t(max(adv.nbytes, 32))))
+        check(lib.vdb_memset_dev(d_lk.ptr, POISON, ctypes.c_size_t(max(lk.nbytes, 32))))
+        check(lib.vdb_wit_set_window(ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_uint64(llo), ctypes.c_uint64(lhi)))
+        try:
+            run(d_adv, d_lk)
+        finally:
+            check(lib.vdb_wit_set_window(ctypes.c_uint64(0), ctypes.c_uint64(2 ** 64 - 1), ctypes.c_uint64(0), ctypes.c_uint64(2 ** 64 - 1)))
+        return d_adv.download(adv.shape), (d_lk.download(lk.shape) if len(lk) else lk)
+    finally:
+        d_adv.free()
+        d_lk.free()
+
+
+def _check_window(adv, lk, g_adv, g_lk, window, tag):
+    POISON = np.uint64(0xA5A5A5A5A5A5A5A5)
+    lo, hi, llo, lhi = window
+    assert np.array_equal(g_adv[lo:hi], adv[lo:hi]), tag
+    assert (g_adv[:lo] == POISON).all() and (g_adv[hi:] == POISON).all(), tag
+    if len(lk):
+        inside = g_lk[llo:lhi]
+        stored = ~(inside == POISON).all(axis=1)
+        assert np.array_equal(inside[stored], lk[llo:lhi][stored]), tag
+        assert (g_lk[:llo] == POISON).all() and (g_lk[lhi:] == POISON).all(), tag
+        if lo == 0 and hi == len(adv):
+            assert stored.all(), tag
+
+
+def test_rank_windows_of_the_other_device_entry_points(api, O):
+    """vdb_wit_distance_dev, vdb_wit_nearest_dev and vdb_wit_merkle_dev under random rank windows (the k-means entry point: above)"""
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    rng = np.random.default_rng(4711)
+    P = 48
+    for case in range(12):
+        metric = METRICS[case % 4]
+        L = int(rng.integers(9, 14))
+        n, dim = int(rng.integers(2, 24)), int(rng.choice([2, 5, 16, 67]))
+        c = O.Ctx(store=True)
+        up = []
+
+        def dev(a):
+            b = api.DeviceBuffer(max(a.nbytes, 32))
+            b.upload(np.ascontiguousarray(a))
+            up.append(b)
+            return b
+        try:
+            kind = case % 3
+            if kind == 0:
+                qa, qb = O.quantize(_vectors(rng, n, dim, metric), P), O.quantize(_vectors(rng, n, dim, metric), P)
+                want = np.stack([c.distance(metric, x, y, P=P, L=L) for x, y in zip(qa, qb)])
+                d_a, d_b, d_res = dev(qa), dev(qb), dev(np.zeros_like(want))
+                run = lambda d_adv, d_lk: check(lib.vdb_wit_distance_dev(api.METRICS[metric], P, L, d_a.ptr, d_b.ptr, n, dim, d_adv.ptr, d_lk.ptr, None, d_res.ptr))
+                values = lambda: np.array_equal(d_res.download(want.shape), want)
+            elif kind == 1:
+                q, db = O.quantize(_vectors(rng, 1, dim, metric)[0], P), O.quantize(_vectors(rng, n, dim, metric), P)
+                ind, res = c.nearest_vector(metric, q, db, P=P, L=L)
+                d_q, d_db, d_ind, d_res = dev(q), dev(db), dev(np.zeros_like(ind)), dev(np.zeros_like(res))
+                run = lambda d_adv, d_lk: check(lib.vdb_wit_nearest_dev(api.METRICS[metric], P, L, d_q.ptr, d_db.ptr, n, dim, d_adv.ptr, d_lk.ptr, None, d_ind.ptr, d_res.ptr))
+                values = lambda: np.array_equal(d_ind.download(ind.shape), ind) and np.array_equal(d_res.download(res.shape), res)
+            else:
+                v = O.quantize(rng.random((n, dim)), P)
+                root = c.merkle_commitment(v)
+                d_v, d_root = dev(v), dev(np.zeros_like(root))
+                run = lambda d_adv, d_lk: check(lib.vdb_wit_merkle_dev(d_v.ptr, n, dim, 0, d_adv.ptr, None, d_root.ptr))
+                values = lambda: np.array_equal(d_root.download(root.shape), root)
+            assert c.err == 0
+            adv, lk = c.advice(), c.lookup()
+            lo, hi = sorted(int(x) for x in rng.integers(0, len(adv) + 1, 2))
+            llo, lhi = sorted(int(x) for x in rng.integers(0, len(lk) + 1, 2)) if len(lk) else (0, 0)
+            for window in ((lo, hi, llo, lhi), (0, len(adv), 0, len(lk))):
+                tag = f"case {case}: kind {kind} {metric} n={n} dim={dim} L={L} window {window}"
+                g_adv, g_lk = _windowed(api, lib, check, adv, lk, window, run)
+                _check_window(adv, lk, g_adv, g_lk, window, tag)
+                assert values(), tag
+        finally:
+            for b in up:
+                b.free()

@@ -358,3 +358,37 @@ def test_msm_wide_windows(api, O, window_bits):
     short = cols[:, : n - 37]
     assert np.array_equal(api.msm_batch(srs, short, basis=0), O.msm_batch(short, g[: n - 37], threads=4))
     srs.free()
+
+
+def test_msm_sweep_of_window_sizes_and_digit_boundaries(api, O):
+    """every window size the table builder accepts (2 .. 14 bits) at random SRS sizes, batch widths and ragged lengths; the scalars
+    include what sits on the edges of the signed-digit recoding: 2^(c j) - 1 and 2^(c j - 1) (a digit that carries / the largest digit
+    that does not), their negatives, the fold point (r - 1) / 2, and the short / long classification's limit 2^32"""
+    rng = np.random.default_rng(20261005)
+    for case in range(26):
+        c = 2 + case % 13
+        k = int(rng.integers(3, 12))
+        n_full = 1 << k
+        n = n_full if case % 3 else int(rng.integers(1, n_full + 1))
+        n_cols = int(rng.integers(1, 9))
+        g, gl = O.srs_from_tau(k, 0xF00D + case)
+        srs = api.Srs(k, g, gl, window_bits=c)
+        assert srs.info()[1] == c
+        edges = [0, 1, R - 1, (R - 1) // 2, (R + 1) // 2, (1 << 32) - 1, 1 << 32, R - (1 << 32), (1 << 253)]
+        for j in range(1, 254 // c + 1):
+            edges += [(1 << (c * j)) - 1, 1 << (c * j - 1), (1 << (c * j - 1)) + 1, R - (1 << (c * j - 1)), R - (1 << (c * j)) + 1]
+        edges = [int(e) % R for e in edges]
+        cols = []
+        for col in range(n_cols):
+            kind = (case + col) % 3
+            v = O.random_fr(rng, n) if kind == 0 else witness_like(O, rng, n)
+            if kind == 2:
+                pick = [edges[int(i)] for i in rng.integers(0, len(edges), size=n)]
+                v = O.fr_from_ints(pick)
+            cols.append(v)
+        cols = np.stack(cols)
+        basis = case % 2
+        bases = (g, gl)[basis][:n]
+        got = api.msm_batch(srs, cols, basis=basis)
+        assert np.array_equal(got, O.msm_batch(cols, bases, threads=4)), (case, c, k, n, n_cols, basis)
+        srs.free()

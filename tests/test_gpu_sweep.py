@@ -214,3 +214,39 @@ def test_rank_windows_of_the_other_device_entry_points(api, O):
         finally:
             for b in up:
                 b.free()
+
+
+def test_break_points_and_columns_of_random_gadget_sequences(api, O):
+    """halo2-base's column layout (GateThreadBuilder::assign_all: a column ends where the next gate would not fit, the cell two gates
+    share is assigned again at the top of the next) on streams no fixed gadget produces: random sequences of FixedPointChip operations
+    and bare witness cells at small column heights, so that breaks fall after every kind of cell — break points, advice columns and
+    lookup columns against the oracle's Context"""
+    rng = np.random.default_rng(60606)
+    ops1 = ("neg", "qabs", "is_neg", "signed_div_scale")
+    ops2 = ("qadd", "qsub", "qmul", "qmin", "qmax", "qdiv")
+    for case in range(14):
+        k = int(rng.integers(6, 11))
+        L = int(rng.integers(4, k))                       # the lookup table must fit the column
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        vals = [O.quantize(np.array([x]))[0] for x in rng.uniform(-4, 4, 6)]
+        for _ in range(int(rng.integers(3, 40))):
+            r = rng.random()
+            if r < 0.2:
+                c.assign_witnesses(np.stack([vals[int(i)] for i in rng.integers(0, len(vals), int(rng.integers(1, 9)))]))
+            elif r < 0.5:
+                vals.append(c.op(ops1[int(rng.integers(0, len(ops1)))], vals[int(rng.integers(0, len(vals)))], L=L))
+            else:
+                a, b = vals[int(rng.integers(0, len(vals)))], vals[int(rng.integers(0, len(vals)))]
+                name = ops2[int(rng.integers(0, len(ops2)))]
+                if name == "qdiv" and not O.fr_to_ints(b.reshape(1, 4))[0]:
+                    name = "qmul"
+                vals.append(c.op(name, a, b, L=L))
+            vals = vals[-8:]
+        assert c.err == 0
+        adv, lk, flags = c.advice(), c.lookup(), c.selectors().astype(np.uint8)
+        bp = api.layout_plan(flags, k)
+        assert np.array_equal(bp, c.break_points()), (case, k, len(adv))
+        cols, lcols = api.layout_columns(adv, bp, k, lookup=lk if len(lk) else None)
+        assert np.array_equal(cols, O.layout_columns(adv, c.break_points(), k, len(bp) + 1)), (case, k)
+        if len(lk):
+            assert np.array_equal(lcols, O.layout_lookup(lk, k, lcols.shape[0])), (case, k)

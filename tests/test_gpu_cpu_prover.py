@@ -227,3 +227,50 @@ def test_query_circuit_nearest_and_merkle_in_one(api, O):
     finally:
         pr.free()
         hp.free()
+
+
+def test_random_kmeans_circuits_prove_the_same_bytes_on_both_provers(api, O):
+    """The comparison above at shapes nobody picked: seeded random k-means circuits (vectors, clusters, iterations, distance, lookup
+    width, column height, block size of the streamed rounds) — the numbers of advice and lookup columns, whether the last set of the
+    permutation argument is full, where the set that spans the advice / lookup junction falls all vary.  Satisfiable distances only
+    (cosine, manhattan, hamming: the Euclidean k-means violates qlog2's asserted constants at iteration 0, tests/test_gpu_copymap.py)."""
+    from halo2_vectordb_amd import circuit_sym as CS
+    from halo2_vectordb_amd.pipeline import KmeansHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import prover as PV
+    rng = np.random.default_rng(31337)
+    shapes = set()
+    for case in range(4):
+        metric = ("cosine", "manhattan", "hamming", "cosine")[case]
+        n, dim = int(rng.integers(4, 9)), int(rng.integers(2, 6))
+        K, I = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        k, L = (11, int(rng.integers(8, 11))) if case % 2 else (12, int(rng.integers(9, 12)))
+        P = 48
+        if metric == "hamming":
+            vec = np.repeat(np.array([[0.5] * dim, [1.25] * dim]), (n + 1) // 2, axis=0)[:n]
+            vec = vec[[i // 2 + (i % 2) * ((n + 1) // 2) for i in range(n)]]          # two groups, alternating: equal elements exist
+            for i in range(2, n):
+                vec[i, int(rng.integers(0, dim))] += 0.125 * i
+        else:
+            vec = rng.uniform(0.5, 3.0, size=(n, dim))
+        cfg = dict(n=n, dim=dim, K=K, I=I, k=k, P=P, L=L, metric=metric, tau=TAU, vectors=vec)
+        qv = O.quantize(vec, P)
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        c.assign_witnesses(qv)
+        c.kmeans(metric, qv, K, I, P=P, L=L)
+        assert c.err == 0, (case, metric)
+        cm, (cent, _ind) = CS.build_kmeans(metric, n, dim, K, I, P, L, builder=None)
+        cs = PV.Circuit(k, L, c.break_points(), c.selectors(), c.n_lookup, cm.copy_of, cm.const_idx, cm.consts, cm.lookup_src, [int(x) for x in np.asarray(cent).reshape(-1)])
+        hp = KmeansHotPath(**cfg)
+        if case % 2:
+            hp.ext_block_cols = int(rng.integers(3, 9))          # the streamed rounds, with a block size of its own
+        hp.setup()
+        pr = ProverRounds(hp, block_cols=int(rng.integers(4, 20)) * 2 if case % 2 else 510).keygen()
+        try:
+            assert pr.keygen_report.violations() == 0, (case, metric, pr.keygen_report.as_dict())
+            _compare(O, PV, hp, pr, cs, c.advice(), c.lookup(), seeds=(100 + case,), threads=8)
+            shapes.add((pr.n_adv, pr.n_lk, pr.n_sets))
+        finally:
+            pr.free()
+            hp.free()
+    assert len(shapes) >= 3

@@ -165,3 +165,29 @@ def test_lde_k18_maximum_config_size(api, O):
     got_c = api.lagrange_to_coeff(cols)
     assert np.array_equal(got_c, want_c)
     assert np.array_equal(api.coeff_to_extended(got_c, 2), want_e)
+
+
+def test_transform_sweep_every_size_and_odd_batches(api, O):
+    """every transform size 2^0 .. 2^17 with batch widths that are not a multiple of anything (1 .. 37 columns: the kernels group
+    columns per launch and per tile), forward, lagrange_to_coeff and the extension to 2, 4 and 8 times the rows, on random columns
+    and on columns with structure (constant, a single one, alternating signs) — against the oracle"""
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    rng = np.random.default_rng(171717)
+    for k in range(0, 18):
+        n = 1 << k
+        n_cols = int(rng.integers(1, 38)) if k <= 12 else int(rng.integers(1, 6))
+        cols = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+        cols[0] = O.fr_from_ints([7] * n)                                  # a constant: one non-zero coefficient
+        if n_cols > 1:
+            cols[1] = 0
+            cols[1, n // 3] = O.fr_from_ints([1])[0]                       # a Lagrange basis polynomial
+        if n_cols > 2:
+            cols[2] = O.fr_from_ints([1, R - 1] * (n // 2) if n > 1 else [1])
+        w = O.root_of_unity(k)
+        assert np.array_equal(api.ntt_batch(cols, w), O.ntt_batch(cols, w, threads=4)), k
+        ext = 1 + k % 3
+        want_c, want_e = O.lde_batch(cols, ext=ext, threads=4)
+        got_c = api.lagrange_to_coeff(cols)
+        assert np.array_equal(got_c, want_c), k
+        if k + ext <= 19:
+            assert np.array_equal(api.coeff_to_extended(got_c, ext), want_e), (k, ext)

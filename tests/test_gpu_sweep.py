@@ -250,3 +250,54 @@ def test_break_points_and_columns_of_random_gadget_sequences(api, O):
         assert np.array_equal(cols, O.layout_columns(adv, c.break_points(), k, len(bp) + 1)), (case, k)
         if len(lk):
             assert np.array_equal(lcols, O.layout_lookup(lk, k, lcols.shape[0])), (case, k)
+
+
+def test_permutation_of_random_copy_forests(api, O):
+    """keygen's cycle construction on the device (vdb_permutation_mapping_dev: pointer jumping over the copy forest, one sort) on copy
+    structures no gadget produces: random forests of any depth over the cells of a small circuit, roots tied to random constants, lookup
+    cells copying random cells, public rows naming random cells (some twice) — the sigma commitments against the CPU prover's
+    construction (oracle/prover.py permutation_mapping: an explicit root search and a stable sort)"""
+    from halo2_vectordb_amd import circuit_sym as CS
+    from halo2_vectordb_amd.pipeline import DistancesHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import prover as PV
+    TAU = 0x1234567890ABCDEF1234567
+    rng = np.random.default_rng(90210)
+    k, L = 9, 8
+    hp = DistancesHotPath(dim=3, metrics=("manhattan", "hamming"), k=k, L=L, tau=TAU).setup()
+    g, gl = O.srs_from_tau(k, TAU)
+    d_flags = hp.keygen_flags()
+    flags = d_flags.download((hp.n_cells,), dtype=np.uint8)
+    d_flags.free()
+    try:
+        nc, nl = hp.n_cells, hp.n_lookup
+        assert hp.n_adv_cols >= 3 and nl > 0
+        for case in range(6):
+            p_copy = (0.0, 0.3, 0.6, 0.9, 0.98, 0.5)[case]
+            idx = np.arange(nc, dtype=np.int64)
+            parent = np.where(rng.random(nc) < p_copy, (rng.random(nc) * (idx + 1)).astype(np.int64), idx)     # an earlier cell, or itself
+            parent[0] = 0
+            if case == 4:
+                parent = np.maximum(idx - 1, 0)                               # one chain through every cell: the deepest forest there is
+            consts = [int(x) for x in rng.integers(0, 1 << 40, int(rng.integers(1, 9)))]
+            consts = list(dict.fromkeys(consts))
+            const_idx = np.full(nc, -1, dtype=np.int64)
+            roots = np.flatnonzero(parent == idx)
+            tied = roots[rng.random(roots.size) < 0.2]
+            const_idx[tied] = rng.integers(0, len(consts), tied.size)
+            lookup_src = rng.integers(0, nc, nl).astype(np.int64)
+            inst = [int(x) for x in rng.integers(0, nc, int(rng.integers(0, 7)))]
+            if len(inst) > 2:
+                inst[-1] = inst[0]                                            # two public rows naming one cell
+            cm = CS.CopyMap(parent, const_idx, consts, np.zeros(nc, dtype=bool), (flags & 1).astype(bool), lookup_src)
+            pr = ProverRounds(hp).keygen(circuit=cm, instance_cells=inst, check=False)
+            try:
+                cs = PV.Circuit(k, L, np.asarray(hp.bp), (flags & 1), nl, parent, const_idx, consts, lookup_src, inst)
+                assert (cs.n_adv, cs.n_lk, cs.n_sets) == (pr.n_adv, pr.n_lk, pr.n_sets)
+                pk = PV.keygen(cs, g, gl, threads=4)
+                for name in ("sigma", "cst", "sel", "table"):
+                    assert np.array_equal(pk.commits[name], pr.fixed[name].commits), (case, name)
+            finally:
+                pr.free()
+    finally:
+        hp.free()

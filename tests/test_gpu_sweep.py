@@ -301,3 +301,76 @@ def test_permutation_of_random_copy_forests(api, O):
                 pr.free()
     finally:
         hp.free()
+
+
+def test_device_mock_prover_counts_what_a_host_recount_counts(api, O):
+    """vdb_mock_check_dev on corrupted witnesses: a nearest_vector witness with one random cell (or lookup cell) replaced, again and
+    again — the violation counts per kind (gate rows, copies, constants, lookup copies, cells outside the table) and the first offenders
+    must be those of a recount in Python integers over the same arrays"""
+    from halo2_vectordb_amd import circuit_sym as CS
+    R = O.R_MOD
+    rng = np.random.default_rng(1234321)
+    n, dim, P, L = 5, 4, 48, 10
+    cm, _ = CS.build_nearest("euclidean", n, dim, P, L, builder=None)
+    v = rng.uniform(0.1, 2.0, size=(n + 1, dim))
+    q, db = api.quantize([v[0]])[0], api.quantize(v[1:])
+    got = api.wit_nearest("euclidean", q, db, P=P, L=L, selectors=True)
+    stream = np.concatenate([q, db.reshape(-1, 4), got["stream"]])
+    flags = np.concatenate([np.zeros((n + 1) * dim, dtype=np.uint8), got["flags"]])
+    lookup = got["lookup"]
+    nc, nl = stream.shape[0], lookup.shape[0]
+    assert nc == cm.n_cells and nl == len(cm.lookup_src)
+    table = O.fr_from_ints(cm.consts)
+    consts = np.array(cm.consts, dtype=object)
+    gates = np.flatnonzero(flags & 1)
+    copies = np.flatnonzero(cm.copy_of != np.arange(nc))
+    tied = np.flatnonzero(cm.const_idx >= 0)
+
+    def recount(vals, lks):
+        a, b, c, d = (vals[gates + i] for i in range(4))
+        bad_g = gates[np.array([(int(w) + int(x) * int(y) - int(z)) % R != 0 for w, x, y, z in zip(a, b, c, d)], dtype=bool)]
+        bad_c = copies[vals[copies] != vals[cm.copy_of[copies]]]
+        bad_k = tied[vals[tied] != consts[cm.const_idx[tied]]]
+        bad_l = np.flatnonzero(lks != vals[cm.lookup_src])
+        out_t = np.flatnonzero(np.array([int(x) >= (1 << L) for x in lks], dtype=bool))
+        return bad_g, bad_c, bad_k, bad_l, out_t
+
+    bufs = {}
+
+    def dev(name, a):
+        a = np.ascontiguousarray(a)
+        if name not in bufs:
+            bufs[name] = api.DeviceBuffer(max(a.nbytes, 32))
+        bufs[name].upload(a)
+        return bufs[name].ptr
+    try:
+        p_flags, p_copy, p_src = dev("flags", flags), dev("copy", cm.copy_of), dev("src", cm.lookup_src)
+        p_cidx, p_table = dev("cidx", cm.const_idx), dev("table", table)
+        seen = set()
+        for trial in range(40):
+            s2, l2 = stream.copy(), lookup.copy()
+            if trial == 0:
+                pass                                                         # the honest witness
+            elif trial % 5 == 4:
+                j = int(rng.integers(0, nl))
+                l2[j] = O.fr_from_ints([int(rng.integers(0, 1 << (L + 2)))])[0]
+            else:
+                i = int(rng.integers(0, nc))
+                s2[i] = O.random_fr(rng, 1)[0] if trial % 2 else O.fr_add(s2[i].reshape(1, 4), O.fr_from_ints([1]))[0]
+            vals, lks = np.array(O.fr_to_ints(s2), dtype=object), np.array(O.fr_to_ints(l2), dtype=object)
+            bad_g, bad_c, bad_k, bad_l, out_t = recount(vals, lks)
+            rep = api.mock_check_dev(dev("stream", s2), nc, p_flags, dev("lookup", l2), nl, L, p_copy, p_src, None, p_cidx, p_table, len(cm.consts))
+            want = (len(bad_g), len(bad_c), len(bad_k), len(bad_l), len(out_t))
+            assert (rep.gate_rows_violated, rep.copies_unequal, rep.constants_changed, rep.lookup_copies_unequal, rep.lookup_cells_out_of_table) == want, (trial, rep.as_dict(), want)
+            for cnt, first, bad in ((rep.gate_rows_violated, rep.first_gate_row, bad_g), (rep.copies_unequal, rep.first_copy, bad_c),
+                                    (rep.constants_changed, rep.first_constant, bad_k), (rep.lookup_copies_unequal, rep.first_lookup_copy, bad_l),
+                                    (rep.lookup_cells_out_of_table, rep.first_lookup_cell, out_t)):
+                if cnt:
+                    assert first == int(bad[0]), (trial, rep.as_dict())
+            seen.add(tuple(x > 0 for x in want))
+            if trial == 0:
+                assert want == (0, 0, 0, 0, 0)
+        assert len(seen) >= 4            # the corruptions hit several kinds of constraint
+    finally:
+        for b in bufs.values():
+            b.free()

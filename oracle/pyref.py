@@ -141,6 +141,10 @@ class FixedPoint:
     def manhattan(self, a, b):  # :177-195
         return sum(self.qabs((x - y) % R) for x, y in zip(a, b)) % R
 
+    def hamming(self, a, b):  # :146-175: one minus the share of equal elements; both counts quantized as f64 values
+        same = sum(1 for x, y in zip(a, b) if x == y)
+        return (self.quantize(1.0) - self.qdiv(self.quantize(float(same)), self.quantize(float(len(a))))) % R
+
     # vectordb.rs:122-163
     def nearest_vector(self, query, vectors, dist):
         d = [dist(v, query) for v in vectors]

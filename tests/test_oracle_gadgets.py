@@ -77,6 +77,13 @@ def test_random_distances_like_reference_tests(O, PY, L):
         m = c.distance("manhattan", qa, qb, L=L)
         assert rel_eq(float(O.dequantize(m)), float(np.abs(a - b).sum()))
         assert O.fr_to_ints(m)[0] == fp.manhattan(O.fr_to_ints(qa), O.fr_to_ints(qb))
+        b2 = b.copy()
+        b2[::3] = a[::3]                                      # four of ten elements equal (random_vector never produces one)
+        qb2 = O.quantize(b2)
+        h = c.distance("hamming", qa, qb2, L=L)
+        assert rel_eq(float(O.dequantize(h)), 0.6)
+        assert O.fr_to_ints(h)[0] == fp.hamming(O.fr_to_ints(qa), O.fr_to_ints(qb2))
+        assert O.fr_to_ints(c.distance("hamming", qa, qb, L=L))[0] == fp.hamming(O.fr_to_ints(qa), O.fr_to_ints(qb)) == fp.quantize(1.0)
         assert c.err == 0 and c.check_gates(L) == 0
 
 

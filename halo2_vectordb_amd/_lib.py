@@ -61,6 +61,8 @@ _SIGNATURES = {
     "vdb_wit_kmeans_size": [_I, _U32, _U32, _SZ, _SZ, _SZ, _SZ, _I, _P, _P],
     "vdb_wit_kmeans": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
     "vdb_wit_kmeans_dev": [_I, _U32, _U32, _P, _SZ, _SZ, _SZ, _SZ, _I, _P, _P, _P, _P, _P],
+    "vdb_wit_fp_op_size": [_I, _U32, _U32, _SZ, _P, _P], "vdb_wit_fp_op": [_I, _U32, _U32, _P, _P, _SZ, _P, _P, _P, _P],
+    "vdb_wit_fp_op_dev": [_I, _U32, _U32, _P, _P, _SZ, _P, _P, _P, _P],
     "vdb_wit_merkle_size": [_SZ, _SZ, _I, _P], "vdb_wit_merkle": [_P, _SZ, _SZ, _I, _P, _P, _P],
     "vdb_wit_distance_dev": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P],
     "vdb_wit_nearest_dev": [_I, _U32, _U32, _P, _P, _SZ, _SZ, _P, _P, _P, _P, _P],

@@ -302,6 +302,29 @@ def wit_distance(metric, a, b, P=48, L=13, selectors=False):
     return dict(stream=stream, lookup=lookup, **_split_flags(sel), result=res)
 
 
+FP_OPS = dict(qadd=0, qsub=1, qmul=2, qdiv=3, neg=4, qabs=5, is_neg=6, qmin=7, qsqrt=8, qlog2=9, qexp2=10, qlog=11, qexp=12, qpow=13, bit_xor=14,
+              cond_neg=15, signed_div_scale=16, qmax=17)
+
+
+def wit_fp_op(op, a, b=None, P=48, L=13, selectors=False):
+    """n independent FixedPointChip calls op(a_i [, b_i]) (vdb_wit_fp_op): a, b (n, 4) quantized values; instance i's cells are
+    stream[i * cells_per_call : (i + 1) * cells_per_call]"""
+    lib = _lib.init()
+    a = _fr(a).reshape(-1, 4)
+    n = a.shape[0]
+    b = None if b is None else _fr(b).reshape(-1, 4)
+    assert b is None or b.shape == a.shape
+    cells, lk = _u64(), _u64()
+    check(lib.vdb_wit_fp_op_size(FP_OPS[op], ctypes.c_uint32(P), ctypes.c_uint32(L), _sz(n), ctypes.byref(cells), ctypes.byref(lk)))
+    stream = np.zeros((cells.value, 4), dtype=np.uint64)
+    lookup = np.zeros((lk.value, 4), dtype=np.uint64)
+    sel = np.zeros(cells.value, dtype=np.uint8) if selectors else None
+    res = np.zeros((n, 4), dtype=np.uint64)
+    check(lib.vdb_wit_fp_op(FP_OPS[op], ctypes.c_uint32(P), ctypes.c_uint32(L), _p(a), _p(b) if b is not None else None, _sz(n), _p(stream), _p(lookup),
+                            _p(sel) if selectors else None, _p(res)))
+    return dict(stream=stream, lookup=lookup, **_split_flags(sel), result=res)
+
+
 def wit_nearest(metric, query, vectors, P=48, L=13, selectors=False):
     lib = _lib.init()
     query, vectors = _fr(query), _fr(vectors)

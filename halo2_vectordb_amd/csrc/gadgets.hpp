@@ -656,7 +656,10 @@ struct Gadgets {
     u256 one = g_add(mont_one<Fr>(), zero());
     u256 d = g_sub(ab, one);
     // d in {-1, 0, 1}
-    u256 inv = u256_is_zero(d) ? mont_one<Fr>() : (u256_eq(d, mont_one<Fr>()) ? mont_one<Fr>() : fr_neg(mont_one<Fr>()));
+    // d in {-1, 0, 1} for the bits the gadget asserts; anything else (a caller handing in non-bits: the assertions then fail) takes the
+    // general inverse
+    const u256 m1 = fr_neg(mont_one<Fr>());
+    u256 inv = u256_is_zero(d) ? mont_one<Fr>() : (u256_eq(d, mont_one<Fr>()) ? mont_one<Fr>() : (u256_eq(d, m1) ? m1 : inv_or_one(d)));
     return g_is_zero_inv(d, inv);
   }
   HD u256 fp_qdiv(const u256& a, const u256& b) {  // :631-656
@@ -698,6 +701,11 @@ struct Gadgets {
     u256 amb = g_sub(a, b);
     u256 s = fp_is_neg(amb);
     return g_select(a, b, s);
+  }
+  HD u256 fp_qmax(const u256& a, const u256& b) {  // :918-934
+    u256 amb = g_sub(a, b);
+    u256 s = fp_is_neg(amb);
+    return g_select(b, a, s);
   }
   template <int M>
   HD u256 fp_polynomial(const u256& x, const u256 (&coef)[M], const uint32_t (&sz)[2]) {  // :658-686
@@ -1002,6 +1010,50 @@ inline void compute_sizes(FpTables& T) {
   measure([&](Gadgets& g) { g.fp_qlog(x); }, T.sz.qlog);
   measure([&](Gadgets& g) { g.fp_qexp(x); }, T.sz.qexp);
   measure([&](Gadgets& g) { g.fp_qsqrt(x); }, T.sz.qsqrt);
+}
+
+// One FixedPointInstructions call by number (vdb_wit_fp_op*; the numbering is the oracle's OPS): what the reference's circuits reach
+// through the trait, one operation at a time.  b is ignored by the unary ones.
+enum FpOp {
+  FP_QADD = 0, FP_QSUB, FP_QMUL, FP_QDIV, FP_NEG, FP_QABS, FP_IS_NEG, FP_QMIN, FP_QSQRT, FP_QLOG2, FP_QEXP2, FP_QLOG, FP_QEXP, FP_QPOW, FP_BIT_XOR,
+  FP_COND_NEG, FP_SIGNED_DIV_SCALE, FP_QMAX, FP_OP_COUNT
+};
+HD inline u256 fp_op_apply(Gadgets& g, int op, const u256& a, const u256& b) {
+  switch (op) {
+    case FP_QADD: return g.g_add(a, b);                    // qadd / qsub are the gate's add / sub (fixed_point.rs:475-509)
+    case FP_QSUB: return g.g_sub(a, b);
+    case FP_QMUL: return g.fp_qmul(a, b);
+    case FP_QDIV: return g.fp_qdiv(a, b);
+    case FP_NEG: return g.g_neg(a);
+    case FP_QABS: return g.fp_qabs(a);
+    case FP_IS_NEG: return g.fp_is_neg(a);
+    case FP_QMIN: return g.fp_qmin(a, b);
+    case FP_QSQRT: return g.fp_qsqrt(a);
+    case FP_QLOG2: return g.fp_qlog2(a);
+    case FP_QEXP2: return g.fp_qexp2(a);
+    case FP_QLOG: return g.fp_qlog(a);
+    case FP_QEXP: return g.fp_qexp(a);
+    case FP_QPOW: return g.fp_qpow(a, b);
+    case FP_BIT_XOR: return g.fp_bit_xor(a, b);
+    case FP_COND_NEG: return g.fp_cond_neg(a, b);
+    case FP_SIGNED_DIV_SCALE: return g.fp_signed_div_scale(a);
+    case FP_QMAX: return g.fp_qmax(a, b);
+  }
+  return u256_zero();
+}
+// cells / lookup cells of one call (data independent: a counting run on the host)
+inline void fp_op_size(FpTables& T, int op, uint32_t out[2]) {
+  WCtx c{};
+  c.count_only = true;
+  c.hi = ~0ull;
+  h_winv = WInv{};
+  h_winv.rhi = ~0ull;
+  h_winv.rlhi = ~0ull;
+  h_winv.T = &T;
+  Gadgets g(c);
+  fp_op_apply(g, op, T.c_one_q, op == FP_BIT_XOR || op == FP_COND_NEG ? T.one : T.c_half);
+  out[0] = (uint32_t)c.pos;
+  out[1] = (uint32_t)c.lpos;
 }
 
 }  // namespace vdb

@@ -1164,6 +1164,31 @@ int wit_distance_dev(FpEntry* fp, int metric, const u256* a, const u256* b, size
   return inv_list_fixup(st);
 }
 
+// ------------------------------------------------------------------ one FixedPointInstructions call per lane (vdb_wit_fp_op*)
+__global__ __launch_bounds__(64) void k_fp_op(Streams st, const FpTables* __restrict__ T, int op, const u256* __restrict__ a, const u256* __restrict__ b,
+                                              uint32_t n, uint32_t cells, uint32_t lks, uint64_t adv_off, uint64_t lk_off, u256* __restrict__ result) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  WCtx c = make_ctx(st, T, adv_off + (uint64_t)i * cells, lk_off + (uint64_t)i * lks);
+  Gadgets g(c);
+  const u256 r = fp_op_apply(g, op, a[i], b ? b[i] : u256_zero());
+  result[i] = r;
+  if (c.err) atomicOr(st.err, c.err);
+}
+int wit_fp_op_dev(FpEntry* fp, int op, const u256* a, const u256* b, size_t n, Streams st, uint64_t adv_off, uint64_t lk_off, u256* result) {
+  uint32_t sz[2];
+  fp_op_size(fp->host, op, sz);
+  TRY(inv_list_attach(st, n * (uint64_t)sz[0]));
+  TRY(set_winv(st, fp->dev));
+  {
+    VDB_PROF("k_fp_op");
+    hipLaunchKernelGGL(k_fp_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx().stream, st, fp->dev, op, a, b, (uint32_t)n, sz[0], sz[1], adv_off, lk_off,
+                       result);
+  }
+  VDB_LAUNCH_CHECK();
+  return inv_list_fixup(st);
+}
+
 struct NvLayout {
   uint64_t dist, dist_l, qmin, qmin_l, iseq, sel, total, total_l;
 };
@@ -1523,6 +1548,52 @@ int vdb_wit_distance_dev(int metric, uint32_t P, uint32_t L, const vdb_fr* a_dev
   VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
   Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], g_win[2], g_win[3]};
   TRY(wit_distance_dev(fp, metric, as_u256(a_dev), as_u256(b_dev), n_pairs, dim, st, 0, 0, as_u256(result_dev)));
+  return check_err_flag(derr);
+}
+
+int vdb_wit_fp_op_size(int op, uint32_t P, uint32_t L, size_t n, uint64_t* cells, uint64_t* lookups) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(op >= 0 && op < FP_OP_COUNT, "unknown fixed-point operation");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  uint32_t sz[2];
+  fp_op_size(fp->host, op, sz);
+  if (cells) *cells = n * (uint64_t)sz[0];
+  if (lookups) *lookups = n * (uint64_t)sz[1];
+  return VDB_OK;
+}
+int vdb_wit_fp_op(int op, uint32_t P, uint32_t L, const vdb_fr* a, const vdb_fr* b, size_t n, vdb_fr* stream_out, vdb_fr* lookup_out,
+                  uint8_t* selector_out, vdb_fr* result_out) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(a && result_out, "null pointer");
+  uint64_t cells, lookups;
+  TRY(vdb_wit_fp_op_size(op, P, L, n, &cells, &lookups));
+  if (n == 0) return VDB_OK;
+  VDB_ARG(n <= 0xffffffffull, "too many instances for one call");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  DevBuf da, db, dres;
+  HostStreams hs;
+  TRY(upload(da, a, n * sizeof(u256)));
+  if (b) TRY(upload(db, b, n * sizeof(u256)));
+  TRY(dres.alloc(n * sizeof(u256)));
+  TRY(hs.init(cells, lookups, selector_out != nullptr));
+  TRY(wit_fp_op_dev(fp, op, da.as<u256>(), b ? db.as<u256>() : nullptr, n, hs.st, 0, 0, dres.as<u256>()));
+  TRY(download(result_out, dres.p, n * sizeof(u256)));
+  return hs.finish(stream_out, lookup_out, selector_out, cells, lookups);
+}
+int vdb_wit_fp_op_dev(int op, uint32_t P, uint32_t L, const vdb_fr* a_dev, const vdb_fr* b_dev, size_t n, vdb_fr* stream_dev, vdb_fr* lookup_dev,
+                      uint8_t* selector_dev, vdb_fr* result_dev) {
+  VDB_REQUIRE_INIT();
+  VDB_ARG(op >= 0 && op < FP_OP_COUNT, "unknown fixed-point operation");
+  VDB_ARG(a_dev && stream_dev && lookup_dev && result_dev && n > 0 && n <= 0xffffffffull, "null pointer or empty input");
+  FpEntry* fp;
+  TRY(get_fp(P, L, &fp));
+  int* derr = (int*)scratch_get(1, 64);
+  if (!derr) return VDB_ERR_OOM;
+  VDB_HIP(hipMemsetAsync(derr, 0, sizeof(int), ctx().stream));
+  Streams st{as_u256(stream_dev), selector_dev, as_u256(lookup_dev), derr, nullptr, nullptr, nullptr, 0, g_win[0], g_win[1], g_win[2], g_win[3]};
+  TRY(wit_fp_op_dev(fp, op, as_u256(a_dev), as_u256(b_dev), n, st, 0, 0, as_u256(result_dev)));
   return check_err_flag(derr);
 }
 

@@ -1012,7 +1012,7 @@ inline void compute_sizes(FpTables& T) {
   measure([&](Gadgets& g) { g.fp_qsqrt(x); }, T.sz.qsqrt);
 }
 
-// One FixedPointInstructions call by number (vdb_wit_fp_op*; the numbering is the oracle's OPS): what the reference's circuits reach
+// One FixedPointInstructions call by number (vdb_wit_fp_op*; the numbering of include/vdb.h): what the reference's circuits reach
 // through the trait, one operation at a time.  b is ignored by the unary ones.
 enum FpOp {
   FP_QADD = 0, FP_QSUB, FP_QMUL, FP_QDIV, FP_NEG, FP_QABS, FP_IS_NEG, FP_QMIN, FP_QSQRT, FP_QLOG2, FP_QEXP2, FP_QLOG, FP_QEXP, FP_QPOW, FP_BIT_XOR,

@@ -489,6 +489,17 @@ void orc_fp_init(fpchip *f, unsigned P, unsigned L) { /* fixed_point.rs:54-98, 1
   quantize1(P, 0.693147180559945309417232121458176568 /* 2.0f64.ln() */, &f->c_ln2);
   quantize1(P, 1.44269504088896340735992468100189214 /* std::f64::consts::LOG2_E */, &f->c_log2e);
   quantize1(P, 1.0, &f->c_one_q);
+  /* generate_sin_poly (fixed_point.rs:189-211): "lolremez -d 14 -r 0:pi sin(x)", highest power first */
+  static const double sinc[15] = {-1.1008071636607462e-11, 2.4208013888629323e-10, -3.8584805817996712e-10, -2.3786993104309845e-08,
+                                  -2.9795813710683115e-09, 2.7608543130047009e-06, -6.4467066994122565e-09, -0.00019840680551418068,
+                                  -3.839555844512214e-09, 0.0083333350601673614, -5.0943769725466814e-10, -0.16666666657583049,
+                                  -8.5029878414113731e-12, 1.0000000000003146, -1.9323057584419828e-15};
+  for (int i = 0; i < 15; i++) quantize1(P, sinc[i], &f->sin_poly[i]);
+  const double pi = 3.14159265358979323846264338327950288; /* std::f64::consts::PI */
+  quantize1(P, pi, &f->c_pi);
+  quantize1(P, pi * 2.0, &f->c_two_pi);
+  quantize1(P, 1.57079632679489661923132169163975144 /* FRAC_PI_2 */, &f->c_half_pi);
+  quantize1(P, 2.0, &f->c_two);
 }
 static fpchip *chip_get(unsigned P, unsigned L) {
   for (int i = 0; i < g_nchips; i++)
@@ -694,6 +705,66 @@ static fr_t fp_qmax(G *g, const fr_t *a, const fr_t *b) { /* :918-934 */
   fr_t s = fp_is_neg(g, &amb);
   return g_select(g, b, a, &s);
 }
+/* ---- the rest of FixedPointInstructions: not reached from DistanceChip / VectorDBChip (examples/fixed_point.rs uses qsin) ---- */
+static fr_t fp_sign(G *g, const fr_t *a) { /* :558-569 */
+  fr_t neg_one = g_neg(g, ONE);
+  fr_t is_neg = fp_is_neg(g, a);
+  return g_select(g, &neg_one, ONE, &is_neg);
+}
+static fr_t fp_clip(G *g, const fr_t *a) { /* :571-586 */
+  fr_t sign = fp_is_neg(g, a);
+  fr_t a_abs = fp_qabs(g, a);
+  u256 m, one = {{1, 0, 0, 0}};
+  u256_shl(&m, &one, 2 * g->f->P); /* max_value = 2^(2P) */
+  fr_t div, rem;
+  r_div_mod(g, &a_abs, &m, 254, &div, &rem);
+  return fp_cond_neg(g, &rem, &sign);
+}
+static fr_t fp_qmod(G *g, const fr_t *a, const fr_t *b) { /* :606-629; b must be positive (assert_is_const(b_sign, 0): no cells) */
+  unsigned P = g->f->P;
+  fr_t a_sign = fp_is_neg(g, a);
+  (void)fp_is_neg(g, b);
+  fr_t a_abs = fp_qabs(g, a);
+  fr_t q, res_abs;
+  r_div_mod_var(g, &a_abs, b, 4 * P, 2 * P, &q, &res_abs);
+  fr_t comp = g_sub(g, b, &res_abs);
+  return g_select(g, &comp, &res_abs, &a_sign);
+}
+static fr_t fp_qsin(G *g, const fr_t *a) { /* :817-841 */
+  fr_t a_abs = fp_qabs(g, a);
+  fr_t a_sign = fp_is_neg(g, a);
+  fr_t a_mod = fp_qmod(g, &a_abs, &g->f->c_two_pi);
+  fr_t a_mpi = g_sub(g, &a_mod, &g->f->c_pi);
+  fr_t is_neg_a_mpi = fp_is_neg(g, &a_mpi);
+  fr_t sin_a_mod = fp_polynomial(g, &a_mod, g->f->sin_poly, 15);
+  fr_t sin_a_mpi_rev = fp_polynomial(g, &a_mpi, g->f->sin_poly, 15);
+  fr_t sin_a_mpi = g_neg(g, &sin_a_mpi_rev);
+  fr_t sin_a_abs = g_select(g, &sin_a_mod, &sin_a_mpi, &is_neg_a_mpi);
+  return fp_cond_neg(g, &sin_a_abs, &a_sign);
+}
+static fr_t fp_qcos(G *g, const fr_t *a) { /* :843-852 */
+  fr_t half_pi = load_constant(g, &g->f->c_half_pi);
+  fr_t t = g_add(g, a, &half_pi);
+  return fp_qsin(g, &t);
+}
+static fr_t fp_qtan(G *g, const fr_t *a) { /* :383-393 */
+  fr_t s = fp_qsin(g, a);
+  fr_t c = fp_qcos(g, a);
+  return fp_qdiv(g, &s, &c);
+}
+static fr_t fp_sinh_cosh(G *g, const fr_t *a, int cosh) { /* :888-916 */
+  fr_t ea = fp_qexp(g, a);
+  fr_t na = g_neg(g, a);
+  fr_t ena = fp_qexp(g, &na);
+  fr_t nume = cosh ? g_add(g, &ea, &ena) : g_sub(g, &ea, &ena);
+  fr_t two = load_constant(g, &g->f->c_two);
+  return fp_qdiv(g, &nume, &two);
+}
+static fr_t fp_qtanh(G *g, const fr_t *a) { /* :407-417 */
+  fr_t s = fp_sinh_cosh(g, a, 0);
+  fr_t c = fp_sinh_cosh(g, a, 1);
+  return fp_qdiv(g, &s, &c);
+}
 static fr_t fp_inner_product(G *g, const fr_t *a, const fr_t *b, size_t n) { /* :854-874 */
   fr_t res = g_add(g, ZERO, ZERO);
   for (size_t i = 0; i < n; i++) {
@@ -725,6 +796,15 @@ void orc_fp_op(octx *c, unsigned P, unsigned L, int op, const fr_t *a, const fr_
     case ORC_OP_BIT_XOR: *out = fp_bit_xor(g, a, b); break;
     case ORC_OP_COND_NEG: *out = fp_cond_neg(g, a, b); break;
     case ORC_OP_SIGNED_DIV_SCALE: fp_signed_div_scale(g, a, out, &r2); break;
+    case ORC_OP_SIGN: *out = fp_sign(g, a); break;
+    case ORC_OP_CLIP: *out = fp_clip(g, a); break;
+    case ORC_OP_QMOD: *out = fp_qmod(g, a, b); break;
+    case ORC_OP_QSIN: *out = fp_qsin(g, a); break;
+    case ORC_OP_QCOS: *out = fp_qcos(g, a); break;
+    case ORC_OP_QTAN: *out = fp_qtan(g, a); break;
+    case ORC_OP_QSINH: *out = fp_sinh_cosh(g, a, 0); break;
+    case ORC_OP_QCOSH: *out = fp_sinh_cosh(g, a, 1); break;
+    case ORC_OP_QTANH: *out = fp_qtanh(g, a); break;
     default: c->err = 2;
   }
 }

@@ -59,6 +59,7 @@ typedef struct {
   fr_t one, zero;
   fr_t exp2_poly[13], log_poly[15];
   fr_t c_half, c_ln2, c_log2e, c_one_q;
+  fr_t sin_poly[15], c_pi, c_two_pi, c_half_pi, c_two; /* fixed_point.rs:189-211, 817-916 */
 } fpchip;
 
 void orc_fp_init(fpchip *f, unsigned P, unsigned L);
@@ -69,7 +70,8 @@ void orc_fp_dequantize(unsigned P, const fr_t *x, double *out, size_t n); /* fix
 enum {
   ORC_OP_QADD = 0, ORC_OP_QSUB, ORC_OP_QMUL, ORC_OP_QDIV, ORC_OP_NEG, ORC_OP_QABS, ORC_OP_IS_NEG,
   ORC_OP_QMIN, ORC_OP_QSQRT, ORC_OP_QLOG2, ORC_OP_QEXP2, ORC_OP_QLOG, ORC_OP_QEXP, ORC_OP_QPOW,
-  ORC_OP_BIT_XOR, ORC_OP_COND_NEG, ORC_OP_SIGNED_DIV_SCALE, ORC_OP_QMAX
+  ORC_OP_BIT_XOR, ORC_OP_COND_NEG, ORC_OP_SIGNED_DIV_SCALE, ORC_OP_QMAX, ORC_OP_SIGN, ORC_OP_CLIP, ORC_OP_QMOD, ORC_OP_QSIN, ORC_OP_QCOS,
+  ORC_OP_QTAN, ORC_OP_QSINH, ORC_OP_QCOSH, ORC_OP_QTANH
 };
 void orc_fp_op(octx *c, unsigned P, unsigned L, int op, const fr_t *a, const fr_t *b, fr_t *out);
 

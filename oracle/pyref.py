@@ -122,6 +122,47 @@ class FixedPoint:
     def qmin(self, a, b):  # :936-952
         return a if self.is_neg((a - b) % R) else b
 
+    def qmax(self, a, b):  # :918-934
+        return b if self.is_neg((a - b) % R) else a
+
+    # the rest of FixedPointInstructions (examples/fixed_point.rs reaches qsin)
+    SIN_POLY = (-1.1008071636607462e-11, 2.4208013888629323e-10, -3.8584805817996712e-10, -2.3786993104309845e-08, -2.9795813710683115e-09,
+                2.7608543130047009e-06, -6.4467066994122565e-09, -0.00019840680551418068, -3.839555844512214e-09, 0.0083333350601673614,
+                -5.0943769725466814e-10, -0.16666666657583049, -8.5029878414113731e-12, 1.0000000000003146, -1.9323057584419828e-15)
+
+    def sign(self, a):  # :558-569: the field elements 1 / -1, not quantized ones
+        return R - 1 if self.is_neg(a) else 1
+
+    def clip(self, a):  # :571-586: |a| mod 2^(2P), the sign restored
+        m = self.qabs(a) % (1 << (2 * self.P))
+        return (R - m) % R if self.is_neg(a) else m
+
+    def qmod(self, a, b):  # :606-629, b positive
+        r = self.qabs(a) % b
+        return (b - r) % R if self.is_neg(a) else r
+
+    def qsin(self, a):  # :817-841
+        coef = [self.quantize(c) for c in self.SIN_POLY]
+        a_mod = self.qmod(self.qabs(a), self.quantize(math.pi * 2.0))
+        a_mpi = (a_mod - self.quantize(math.pi)) % R
+        s = self.polynomial(a_mod, coef) if self.is_neg(a_mpi) else (R - self.polynomial(a_mpi, coef)) % R
+        return (R - s) % R if self.is_neg(a) else s
+
+    def qcos(self, a):  # :843-852
+        return self.qsin((a + self.quantize(math.pi / 2)) % R)
+
+    def qtan(self, a):  # :383-393
+        return self.qdiv(self.qsin(a), self.qcos(a))
+
+    def qsinh(self, a):  # :888-901
+        return self.qdiv((self.qexp(a) - self.qexp((R - a) % R)) % R, self.quantize(2.0))
+
+    def qcosh(self, a):  # :903-916
+        return self.qdiv((self.qexp(a) + self.qexp((R - a) % R)) % R, self.quantize(2.0))
+
+    def qtanh(self, a):  # :407-417
+        return self.qdiv(self.qsinh(a), self.qcosh(a))
+
     def inner_product(self, a, b):  # :854-874
         res = 0
         for x, y in zip(a, b):

@@ -229,3 +229,36 @@ def test_break_points_and_layout(O):
         pos += rows - 1 if ci < len(bp) else rows
     lk = O.layout_lookup(c.lookup(), k, 8)
     assert lk.shape[0] == math.ceil(c.n_lookup / max_rows)
+
+
+def test_the_rest_of_fixed_point_instructions_vs_python_and_f64(O, PY):
+    """sign, clip, qmod, qsin, qcos, qtan, qsinh, qcosh, qtanh (fixed_point.rs:558-629, 817-916, 383-417; examples/fixed_point.rs reaches
+    qsin): the C restatement against the independent Python one, results against f64 (the example prints the error, it holds no tolerance:
+    1e-6 relative as everywhere), every gate row of the emitted cells satisfied"""
+    import math
+    fp = PY.FixedPoint(48)
+    rng = np.random.default_rng(77)
+    f64 = dict(qsin=math.sin, qcos=math.cos, qtan=math.tan, qsinh=math.sinh, qcosh=math.cosh, qtanh=math.tanh)
+    xs = [float(v) for v in rng.uniform(-12.0, 12.0, 10)] + [0.25 * math.pi, 1.0, -1.0, 3.0, -3.5, 6.2, 0.001]
+    c = O.Ctx(store=True, keygen=True)
+    for x in xs:
+        q = O.quantize([x])[0]
+        i = O.fr_to_ints(q)[0]
+        for name in ("sign", "clip", "qsin", "qcos", "qtan", "qsinh", "qcosh", "qtanh"):
+            got = O.fr_to_ints(c.op(name, q))[0]
+            assert got == getattr(fp, name)(i), (name, x)
+            if name in f64:
+                want = f64[name](x)
+                assert abs(float(O.dequantize(O.fr_from_ints([got]))[0]) - want) <= 1e-6 * max(abs(want), 1.0), (name, x)
+        assert O.fr_to_ints(c.op("clip", q))[0] == i                      # inside the range clip is the identity
+        assert O.fr_to_ints(c.op("sign", q))[0] == (O.R_MOD - 1 if x < 0 else 1)
+        for m in (2.0, 0.75, 2 * math.pi):
+            qm = O.quantize([m])[0]
+            got = O.fr_to_ints(c.op("qmod", q, qm))[0]
+            assert got == fp.qmod(i, O.fr_to_ints(qm)[0])
+            assert abs(float(O.dequantize(O.fr_from_ints([got]))[0]) - (x % m)) <= 1e-6 * m, (x, m)       # Python's % is the floored one too
+    big = (1 << 96) + 12345                                              # outside the chip's range: clip brings it back modulo 2^(2P)
+    assert O.fr_to_ints(c.op("clip", O.fr_from_ints([big])[0]))[0] == 12345 == fp.clip(big)
+    neg_big = O.R_MOD - big                                              # ... and keeps the sign
+    assert O.fr_to_ints(c.op("clip", O.fr_from_ints([neg_big])[0]))[0] == O.R_MOD - 12345 == fp.clip(neg_big)
+    assert c.err == 0 and c.check_gates(13) == 0

@@ -303,7 +303,7 @@ def wit_distance(metric, a, b, P=48, L=13, selectors=False):
 
 
 FP_OPS = dict(qadd=0, qsub=1, qmul=2, qdiv=3, neg=4, qabs=5, is_neg=6, qmin=7, qsqrt=8, qlog2=9, qexp2=10, qlog=11, qexp=12, qpow=13, bit_xor=14,
-              cond_neg=15, signed_div_scale=16, qmax=17)
+              cond_neg=15, signed_div_scale=16, qmax=17, sign=18, clip=19, qmod=20, qsin=21, qcos=22, qtan=23, qsinh=24, qcosh=25, qtanh=26)
 
 
 def wit_fp_op(op, a, b=None, P=48, L=13, selectors=False):

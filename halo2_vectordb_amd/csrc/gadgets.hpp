@@ -40,6 +40,7 @@ struct FpTables {
   u256 scale;            // 2^P
   u256 exp2_poly[13], log_poly[15];  // fixed_point.rs:138-187, quantized
   u256 c_half, c_ln2, c_log2e, c_one_q;
+  u256 sin_poly[15], c_pi, c_two_pi, c_half_pi, c_two;   // fixed_point.rs:189-211 and the constants of qsin / qcos / qsinh
   u256 small[260];       // i
   u256 small_inv[260];   // 1/i (i >= 1)
   const u256* limb_tab;  // Montgomery form of 0 .. 2^L - 1 (device pointer)
@@ -978,6 +979,63 @@ struct Gadgets {
     u256 half = load_constant(T.c_half);
     return fp_qpow(x, half);
   }
+  // ---- the rest of FixedPointInstructions: not reached from DistanceChip / VectorDBChip (examples/fixed_point.rs calls qsin); plain
+  // compositions of the generators above, which bring their own value-only paths
+  HD u256 fp_sign(const u256& a) {  // :558-569: the field elements 1 / -1
+    u256 neg_one = g_neg(mont_one<Fr>());
+    u256 n = fp_is_neg(a);
+    return g_select(neg_one, mont_one<Fr>(), n);
+  }
+  HD u256 fp_clip(const u256& a) {  // :571-586: |a| mod max_value = 2^(2P), the sign restored
+    u256 sgn = fp_is_neg(a);
+    u256 aa = fp_qabs(a);
+    u256 div, rem;
+    r_div_mod_pow2(aa, 2 * T.P, 254, div, rem);
+    return fp_cond_neg(rem, sgn);
+  }
+  HD u256 fp_qmod(const u256& a, const u256& b) {  // :606-629; b positive (assert_is_const(b_sign, 0) pushes no cell)
+    u256 sa = fp_is_neg(a);
+    (void)fp_is_neg(b);
+    u256 aa = fp_qabs(a);
+    u256 q, r;
+    r_div_mod_var(aa, b, 4 * T.P, 2 * T.P, q, r);
+    u256 comp = g_sub(b, r);
+    return g_select(comp, r, sa);
+  }
+  HD u256 fp_qsin(const u256& a) {  // :817-841
+    u256 aa = fp_qabs(a);
+    u256 sa = fp_is_neg(a);
+    u256 a_mod = fp_qmod(aa, T.c_two_pi);
+    u256 a_mpi = g_sub(a_mod, T.c_pi);
+    u256 lower = fp_is_neg(a_mpi);
+    u256 s_mod = fp_polynomial<15>(a_mod, T.sin_poly, T.sz.poly15);
+    u256 s_rev = fp_polynomial<15>(a_mpi, T.sin_poly, T.sz.poly15);
+    u256 s_mpi = g_neg(s_rev);   // -sin(a - pi) for pi <= a < 2 pi
+    u256 s_abs = g_select(s_mod, s_mpi, lower);
+    return fp_cond_neg(s_abs, sa);
+  }
+  HD u256 fp_qcos(const u256& a) {  // :843-852
+    u256 hp = load_constant(T.c_half_pi);
+    return fp_qsin(g_add(a, hp));
+  }
+  HD u256 fp_qtan(const u256& a) {  // :383-393
+    u256 s = fp_qsin(a);
+    u256 co = fp_qcos(a);
+    return fp_qdiv(s, co);
+  }
+  HD u256 fp_sinh_cosh(const u256& a, bool cosh) {  // :888-916
+    u256 ea = fp_qexp(a);
+    u256 na = g_neg(a);
+    u256 ena = fp_qexp(na);
+    u256 nume = cosh ? g_add(ea, ena) : g_sub(ea, ena);
+    u256 two = load_constant(T.c_two);
+    return fp_qdiv(nume, two);
+  }
+  HD u256 fp_qtanh(const u256& a) {  // :407-417
+    u256 s = fp_sinh_cosh(a, false);
+    u256 co = fp_sinh_cosh(a, true);
+    return fp_qdiv(s, co);
+  }
 };
 
 // Host-side sizing: runs the generators in counting mode and fills T.sz bottom-up.
@@ -1016,7 +1074,7 @@ inline void compute_sizes(FpTables& T) {
 // through the trait, one operation at a time.  b is ignored by the unary ones.
 enum FpOp {
   FP_QADD = 0, FP_QSUB, FP_QMUL, FP_QDIV, FP_NEG, FP_QABS, FP_IS_NEG, FP_QMIN, FP_QSQRT, FP_QLOG2, FP_QEXP2, FP_QLOG, FP_QEXP, FP_QPOW, FP_BIT_XOR,
-  FP_COND_NEG, FP_SIGNED_DIV_SCALE, FP_QMAX, FP_OP_COUNT
+  FP_COND_NEG, FP_SIGNED_DIV_SCALE, FP_QMAX, FP_SIGN, FP_CLIP, FP_QMOD, FP_QSIN, FP_QCOS, FP_QTAN, FP_QSINH, FP_QCOSH, FP_QTANH, FP_OP_COUNT
 };
 HD inline u256 fp_op_apply(Gadgets& g, int op, const u256& a, const u256& b) {
   switch (op) {
@@ -1038,6 +1096,15 @@ HD inline u256 fp_op_apply(Gadgets& g, int op, const u256& a, const u256& b) {
     case FP_COND_NEG: return g.fp_cond_neg(a, b);
     case FP_SIGNED_DIV_SCALE: return g.fp_signed_div_scale(a);
     case FP_QMAX: return g.fp_qmax(a, b);
+    case FP_SIGN: return g.fp_sign(a);
+    case FP_CLIP: return g.fp_clip(a);
+    case FP_QMOD: return g.fp_qmod(a, b);
+    case FP_QSIN: return g.fp_qsin(a);
+    case FP_QCOS: return g.fp_qcos(a);
+    case FP_QTAN: return g.fp_qtan(a);
+    case FP_QSINH: return g.fp_sinh_cosh(a, false);
+    case FP_QCOSH: return g.fp_sinh_cosh(a, true);
+    case FP_QTANH: return g.fp_qtanh(a);
   }
   return u256_zero();
 }

@@ -132,6 +132,17 @@ static int get_fp(uint32_t P, uint32_t L, FpEntry** out) {
   T.c_ln2 = quantize_host(P, 0.693147180559945309417232121458176568);
   T.c_log2e = quantize_host(P, 1.44269504088896340735992468100189214);
   T.c_one_q = quantize_host(P, 1.0);
+  // generate_sin_poly (fixed_point.rs:189-211: "lolremez -d 14 -r 0:pi sin(x)", highest power first) and the constants of qsin, qcos, qsinh
+  static const double sinc[15] = {-1.1008071636607462e-11, 2.4208013888629323e-10, -3.8584805817996712e-10, -2.3786993104309845e-08,
+                                  -2.9795813710683115e-09, 2.7608543130047009e-06, -6.4467066994122565e-09, -0.00019840680551418068,
+                                  -3.839555844512214e-09, 0.0083333350601673614, -5.0943769725466814e-10, -0.16666666657583049,
+                                  -8.5029878414113731e-12, 1.0000000000003146, -1.9323057584419828e-15};
+  for (int i = 0; i < 15; i++) T.sin_poly[i] = quantize_host(P, sinc[i]);
+  const double pi = 3.14159265358979323846264338327950288;
+  T.c_pi = quantize_host(P, pi);
+  T.c_two_pi = quantize_host(P, pi * 2.0);
+  T.c_half_pi = quantize_host(P, 1.57079632679489661923132169163975144);
+  T.c_two = quantize_host(P, 2.0);
   for (uint32_t i = 0; i < 260; i++) {
     T.small[i] = host_fr_from_u64(i);
     T.small_inv[i] = i ? mont_inv<Fr>(T.small[i]) : u256_zero();

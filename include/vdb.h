@@ -145,7 +145,8 @@ int vdb_wit_distance_dev(int metric, uint32_t precision_bits, uint32_t lookup_bi
  * that apply an operation to many values): n independent calls op(a_i [, b_i]); instance i's cells are cells/n consecutive cells of the
  * stream (its lookup cells likewise), in the order the gadget pushes them.  op: 0 qadd, 1 qsub, 2 qmul, 3 qdiv, 4 neg, 5 qabs, 6 is_neg,
  * 7 qmin, 8 qsqrt, 9 qlog2, 10 qexp2, 11 qlog, 12 qexp, 13 qpow, 14 bit_xor, 15 cond_neg (b: the flag), 16 signed_div_scale (result:
- * the quotient), 17 qmax.  b may be null for the unary ones.  VDB_ERR_DOMAIN where the reference panics (a division by zero).  The _dev
+ * the quotient), 17 qmax, 18 sign (the field elements 1 / -1), 19 clip, 20 qmod (b positive), 21 qsin, 22 qcos, 23 qtan, 24 qsinh,
+ * 25 qcosh, 26 qtanh.  b may be null for the unary ones.  VDB_ERR_DOMAIN where the reference panics (a division by zero).  The _dev
  * form honours vdb_wit_set_window. */
 int vdb_wit_fp_op_size(int op, uint32_t precision_bits, uint32_t lookup_bits, size_t n, uint64_t *cells, uint64_t *lookups);
 int vdb_wit_fp_op(int op, uint32_t precision_bits, uint32_t lookup_bits, const vdb_fr *a, const vdb_fr *b, size_t n, vdb_fr *stream_out,

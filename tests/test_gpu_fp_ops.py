@@ -19,10 +19,11 @@ def api():
     return a
 
 
-UNARY = ("neg", "qabs", "is_neg", "qsqrt", "qlog2", "qexp2", "qlog", "qexp", "signed_div_scale")
-BINARY = ("qadd", "qsub", "qmul", "qdiv", "qmin", "qmax", "qpow", "bit_xor", "cond_neg")
+UNARY = ("neg", "qabs", "is_neg", "qsqrt", "qlog2", "qexp2", "qlog", "qexp", "signed_div_scale", "sign", "clip", "qsin", "qcos", "qtan", "qsinh", "qcosh", "qtanh")
+BINARY = ("qadd", "qsub", "qmul", "qdiv", "qmin", "qmax", "qpow", "bit_xor", "cond_neg", "qmod")
 F64 = dict(qadd=lambda x, y: x + y, qsub=lambda x, y: x - y, qmul=lambda x, y: x * y, qdiv=lambda x, y: x / y, neg=lambda x: -x, qabs=abs,
-           qmin=min, qmax=max, qsqrt=math.sqrt, qlog2=math.log2, qexp2=lambda x: 2.0 ** x, qlog=math.log, qexp=math.exp, qpow=lambda x, y: x ** y)
+           qmin=min, qmax=max, qsqrt=math.sqrt, qlog2=math.log2, qexp2=lambda x: 2.0 ** x, qlog=math.log, qexp=math.exp, qpow=lambda x, y: x ** y,
+           qsin=math.sin, qcos=math.cos, qtan=math.tan, qsinh=math.sinh, qcosh=math.cosh, qtanh=math.tanh, clip=lambda x: x, qmod=lambda x, y: x % y)
 
 
 def _operands(rng, op, n):
@@ -35,6 +36,14 @@ def _operands(rng, op, n):
         return x, None
     if op == "qpow":
         return rng.uniform(0.1, 6.0, n), rng.uniform(-2.0, 2.0, n)
+    if op in ("qsin", "qcos", "qsinh", "qcosh", "qtanh"):
+        return np.concatenate([rng.uniform(-9.0, 9.0, n - 3), [0.25 * math.pi, 1.0, -3.5]]), None
+    if op == "qtan":                             # away from the poles
+        x = rng.uniform(-9.0, 9.0, n)
+        x[np.abs(np.cos(x)) < 0.05] = 0.3
+        return x, None
+    if op == "qmod":
+        return rng.uniform(-50.0, 50.0, n), rng.uniform(0.1, 7.0, n)
     if op == "bit_xor":
         return rng.integers(0, 2, n).astype(np.float64), rng.integers(0, 2, n).astype(np.float64)
     x = np.concatenate([rng.uniform(-300.0, 300.0, n - 4), [0.0, 1.0, -1.0, 2.0 ** -40]])

@@ -100,6 +100,44 @@ class FixedPointChip {
     check(vdb_fp_dequantize(PRECISION_BITS, &x, &out, 1));
     return out;
   }
+  // FixedPointInstructions (src/gadget/fixed_point.rs:213-460), one call each: the cells go into the context in the order the Rust
+  // gadget pushes them (vdb_wit_fp_op; op numbers: include/vdb.h)
+  AssignedValue op(Context& ctx, int code, const AssignedValue& a, const AssignedValue* b = nullptr) const {
+    uint64_t cells = 0, lookups = 0;
+    const uint32_t L = (uint32_t)lookup_bits;
+    check(vdb_wit_fp_op_size(code, PRECISION_BITS, L, 1, &cells, &lookups));
+    auto [stream, lookup] = ctx.grow(cells, lookups);
+    AssignedValue out;
+    check(vdb_wit_fp_op(code, PRECISION_BITS, L, &a.value, b ? &b->value : nullptr, 1, stream, lookup, nullptr, &out.value));
+    return out;
+  }
+  AssignedValue qadd(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 0, a, &b); }
+  AssignedValue qsub(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 1, a, &b); }
+  AssignedValue qmul(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 2, a, &b); }
+  AssignedValue qdiv(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 3, a, &b); }
+  AssignedValue neg(Context& ctx, const AssignedValue& a) const { return op(ctx, 4, a); }
+  AssignedValue qabs(Context& ctx, const AssignedValue& a) const { return op(ctx, 5, a); }
+  AssignedValue is_neg(Context& ctx, const AssignedValue& a) const { return op(ctx, 6, a); }
+  AssignedValue qmin(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 7, a, &b); }
+  AssignedValue qsqrt(Context& ctx, const AssignedValue& a) const { return op(ctx, 8, a); }
+  AssignedValue qlog2(Context& ctx, const AssignedValue& a) const { return op(ctx, 9, a); }
+  AssignedValue qexp2(Context& ctx, const AssignedValue& a) const { return op(ctx, 10, a); }
+  AssignedValue qlog(Context& ctx, const AssignedValue& a) const { return op(ctx, 11, a); }
+  AssignedValue qexp(Context& ctx, const AssignedValue& a) const { return op(ctx, 12, a); }
+  AssignedValue qpow(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 13, a, &b); }
+  AssignedValue bit_xor(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 14, a, &b); }
+  AssignedValue cond_neg(Context& ctx, const AssignedValue& a, const AssignedValue& flag) const { return op(ctx, 15, a, &flag); }
+  AssignedValue signed_div_scale(Context& ctx, const AssignedValue& a) const { return op(ctx, 16, a); }
+  AssignedValue qmax(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 17, a, &b); }
+  AssignedValue sign(Context& ctx, const AssignedValue& a) const { return op(ctx, 18, a); }
+  AssignedValue clip(Context& ctx, const AssignedValue& a) const { return op(ctx, 19, a); }
+  AssignedValue qmod(Context& ctx, const AssignedValue& a, const AssignedValue& b) const { return op(ctx, 20, a, &b); }
+  AssignedValue qsin(Context& ctx, const AssignedValue& a) const { return op(ctx, 21, a); }
+  AssignedValue qcos(Context& ctx, const AssignedValue& a) const { return op(ctx, 22, a); }
+  AssignedValue qtan(Context& ctx, const AssignedValue& a) const { return op(ctx, 23, a); }
+  AssignedValue qsinh(Context& ctx, const AssignedValue& a) const { return op(ctx, 24, a); }
+  AssignedValue qcosh(Context& ctx, const AssignedValue& a) const { return op(ctx, 25, a); }
+  AssignedValue qtanh(Context& ctx, const AssignedValue& a) const { return op(ctx, 26, a); }
   // FixedPointVectorInstructions
   std::vector<F> quantize_vector(const std::vector<double>& v) const {
     std::vector<F> out(v.size());

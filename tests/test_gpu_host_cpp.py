@@ -91,3 +91,39 @@ def test_example_mock_is_the_mock_arm_in_compiled_code(O):
     assert bad.returncode == 4, (bad.stdout, bad.stderr)
     rep = bad.stdout.splitlines()[1].split()
     assert int(rep[1]) >= 1 and 1000 <= int(rep[9]) <= 1003
+
+
+def test_example_fixed_point_in_compiled_code(O):
+    """host/example_fixed_point.cpp = examples/fixed_point.rs:38-112 (FixedPointChip<32>: load_witness(x), qexp2, qlog2 when x > 0, qsin,
+    all public) through the C++ mirror of FixedPointInstructions: the context's cell counts are the oracle's for the same calls, the
+    values the oracle's to the printed precision, and the errors against f64 are what fixed-point at 32 fractional bits allows — at the
+    inputs the example's own comments list (examples/fixed_point.rs:121-128)"""
+    import math
+    exe = os.path.join(ROOT, "halo2_vectordb_amd", "host", "example_fixed_point")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "halo2_vectordb_amd", "csrc"), "../host/example_fixed_point"])
+    P, L = 32, 12
+    for x in (-12.0, -1.88724767676867, 0.0, 1.0, 1.128, 2.0, 4.0, 0.25 * math.pi):
+        out = subprocess.run([exe, str(L), repr(x)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (x, out.stdout, out.stderr)
+        lines = out.stdout.splitlines()
+        c = O.Ctx(store=True, keygen=True)
+        q = O.quantize(np.array([x]), P)
+        c.assign_witnesses(q)
+        want = [("exp2", c.op("qexp2", q[0], P=P, L=L), 2.0 ** x)]
+        if x > 0:
+            want.append(("log2", c.op("qlog2", q[0], P=P, L=L), math.log2(x)))
+        want.append(("sin", c.op("qsin", q[0], P=P, L=L), math.sin(x)))
+        head = lines[0].split()
+        assert (int(head[1]), int(head[3]), int(head[5])) == (len(c), c.n_lookup, 1 + len(want)), (x, lines[0])
+        assert len(lines) == 1 + len(want)
+        for line, (name, value, native) in zip(lines[1:], want):
+            got = line.split()
+            assert got[0] == name
+            zk = float(O.dequantize(value.reshape(1, 4), P)[0])
+            if abs(zk) < 1e12:                                # (sin(0) is -1 ulp: dequantization's quirk, printed as it is)
+                assert abs(float(got[1]) - zk) <= 1e-9 * max(1.0, abs(zk)), (x, line)
+                # (the example prints the error and asserts nothing; at its 32 fractional bits the sine's 14 Horner steps keep ~1e-5 and the
+                #  logarithm's alternating coefficients ~2e-3: the algorithm's accuracy, the same in the oracle)
+                assert abs(zk - native) <= 5e-3 * max(1.0, abs(native)), (x, name, zk, native)
+            assert abs(float(got[2]) - native) <= 1e-9 * max(1.0, abs(native))

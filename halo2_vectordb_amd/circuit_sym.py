@@ -30,6 +30,9 @@ EXP2_COEF = [3.6240421303547230336183979205877e-11, 4.12843274678331302455491699
 LOG_COEF = [-3.319586265362338e-08, 1.4957235315170112e-06, -3.1350053389526744e-05, 0.00040554177582512901, -0.0036218342998850703,
             0.023663846121538389, -0.11691877183255484, 0.44524062371564499, -1.3195777548208449, 3.0518128028712077, -5.4904626000399528,
             7.6298580090181591, -8.1653313719804235, 7.1389971101896279, -3.1937385492842112]                                      # fixed_point.rs:162-187
+SIN_COEF = [-1.1008071636607462e-11, 2.4208013888629323e-10, -3.8584805817996712e-10, -2.3786993104309845e-08, -2.9795813710683115e-09,
+            2.7608543130047009e-06, -6.4467066994122565e-09, -0.00019840680551418068, -3.839555844512214e-09, 0.0083333350601673614,
+            -5.0943769725466814e-10, -0.16666666657583049, -8.5029878414113731e-12, 1.0000000000003146, -1.9323057584419828e-15]  # fixed_point.rs:189-211
 
 
 class C:
@@ -368,6 +371,30 @@ class Sym:
         half = self.load_constant(quantize(0.5, self.P))
         return self.qexp(self.qmul(half, self.qlog(x)))
 
+    # the rest of FixedPointInstructions that examples/fixed_point.rs reaches
+    def qmod(self, a, b):                                    # :606-629 (b: a positive constant or cell)
+        P = self.P
+        sa, sb = self.is_neg(a), self.is_neg(b)
+        self.tie_const(sb, 0)                                # gate().assert_is_const(b_sign, 0)
+        aa = self.qabs(a)
+        _, r = self.r_div_mod_var(aa, b, 4 * P, 2 * P)
+        return self.g_select(self.g_sub(b, r), r, sa)
+
+    def qsin(self, a):                                       # :817-841
+        P = self.P
+        a_abs, a_sign = self.qabs(a), self.is_neg(a)
+        a_mod = self.qmod(a_abs, C(quantize(math.pi * 2.0, P)))
+        a_mpi = self.g_sub(a_mod, C(quantize(math.pi, P)))
+        lower = self.is_neg(a_mpi)
+        coef = [quantize(c, P) for c in SIN_COEF]
+        s_mod = self.polynomial(a_mod, coef)
+        s_mpi = self.g_neg(self.polynomial(a_mpi, coef))
+        return self.cond_neg(self.g_select(s_mod, s_mpi, lower), a_sign)
+
+    def fp_op(self, name, a):
+        return dict(qexp2=self.qexp2, qlog2=self.qlog2, qsin=self.qsin, qexp=self.qexp, qlog=self.qlog, qsqrt=self.qsqrt, qabs=self.qabs,
+                    is_neg=self.is_neg)[name](a)
+
     def inner_product(self, a, b):                           # :854-874
         res = self.g_add(C(0), C(0))
         for x, y in zip(a, b):
@@ -512,6 +539,15 @@ def trace_distances(metrics, dim, P, L):
     a, b = s.assign_witnesses(dim), s.assign_witnesses(dim)
     outs = [s.distance(m, a, b) for m in metrics]
     return _whole(s, 2 * dim), outs
+
+
+def trace_fixed_point(ops, P, L):
+    """examples/fixed_point.rs:55-111: x = ctx.load_witness(..), then one FixedPointInstructions call after the other on x; -> the map and the
+    cells the example makes public: x, then every result"""
+    s = Sym(P, L)
+    (x,) = s.assign_witnesses(1)
+    outs = [x] + [s.fp_op(name, x) for name in ops]
+    return _whole(s, 1), outs
 
 
 def trace_nearest(metric, n, dim, P, L):

@@ -788,3 +788,51 @@ class DistancesHotPath(KmeansHotPath):
             self.d_res.free()
             self.d_res = None
 
+
+
+class FixedPointHotPath(DistancesHotPath):
+    """examples/fixed_point.rs:38-112 through the hot path: FixedPointChip<32> on ONE value — x = ctx.load_witness(quantization(x)), then
+    qexp2(x), qlog2(x) when x > 0, qsin(x), with x and every result public.  Stream: [x | the cells of each call in turn]
+    (vdb_wit_fp_op_dev, one instance each).  `ops`: other FixedPointInstructions names instead of the example's."""
+
+    def __init__(self, x=1.128, ops=None, k=13, P=32, L=12, tau=None, blind_seed=None):
+        self.x = float(x)
+        self.ops = tuple(ops) if ops is not None else ("qexp2",) + (("qlog2",) if self.x > 0.0 else ()) + ("qsin",)
+        for name in self.ops:
+            if name not in api.FP_OPS:
+                raise ValueError("unknown FixedPointChip operation: " + str(name))
+        KmeansHotPath.__init__(self, n=1, dim=1, K=1, I=1, k=k, P=P, L=L, metric="euclidean", tau=tau, vectors=np.array([[self.x]]), blind_seed=blind_seed)
+        self.metrics = ()
+        self.public = True
+        self.shard_witness = False
+
+    def _input_vectors(self):
+        return np.array([[self.x]], dtype=np.float64), None
+
+    def _circuit_size(self):
+        self.parts = []
+        cells_total = lk_total = 0
+        for name in self.ops:
+            cells, lk = ctypes.c_uint64(), ctypes.c_uint64()
+            check(self.lib.vdb_wit_fp_op_size(api.FP_OPS[name], self.P, self.L, 1, ctypes.byref(cells), ctypes.byref(lk)))
+            self.parts.append((api.FP_OPS[name], cells_total, lk_total))
+            cells_total, lk_total = cells_total + cells.value, lk_total + lk.value
+        return 1, cells_total, lk_total
+
+    def _alloc_outputs(self):
+        self.d_res = api.DeviceBuffer((1 + len(self.ops)) * 32)        # [x | results]: the public statement in make_public order
+
+    def _witness(self, sel=None):
+        lib = self.lib
+        check(lib.vdb_memcpy_d2d(self.d_stream.ptr, self.d_vec.ptr, ctypes.c_size_t(32)))
+        check(lib.vdb_memcpy_d2d(self.d_res.ptr, self.d_vec.ptr, ctypes.c_size_t(32)))
+        for i, (op, off, lk_off) in enumerate(self.parts):
+            at = 1 + off
+            check(lib.vdb_wit_fp_op_dev(op, self.P, self.L, self.d_vec.ptr, None, 1, self.d_stream.at(at * 32), self.d_lookup.at(lk_off * 32),
+                                        ctypes.c_void_p(sel.ptr.value + at) if sel is not None else None, self.d_res.at((1 + i) * 32)))
+
+    def public_values_dev(self):
+        return self.d_res.ptr, 1 + len(self.ops)           # examples/fixed_point.rs:64, :79, :94, :110: make_public.push after each
+
+    def results(self):
+        return self.d_res.download((1 + len(self.ops), 4))[1:]

@@ -306,9 +306,15 @@ class ProverRounds:
     def circuit_map(self, d_flags):
         """The circuit's constraint map (circuit_sym.CopyMap) for the gadget this hot path runs: the symbolic trace of the
         fixed-point gadgets, or of the Poseidon sponge for the Merkle circuit."""
-        from .pipeline import DistancesHotPath, MerkleHotPath, NearestHotPath, QueryHotPath
+        from .pipeline import DistancesHotPath, FixedPointHotPath, MerkleHotPath, NearestHotPath, QueryHotPath
         hp = self.hp
         on_device = getattr(self, "map_on_device", True)
+        if isinstance(hp, FixedPointHotPath):
+            # one value, a handful of FixedPointChip calls (examples/fixed_point.rs): x and every result public
+            from . import circuit_sym as CS
+            cm, outs = CS.trace_fixed_point(hp.ops, hp.P, hp.L)
+            self.public_cells = [int(c) for c in outs]
+            return cm
         if isinstance(hp, DistancesHotPath):
             # two vectors, a handful of distances: the whole trace on the host (examples/distances.rs, examples/euclid.rs)
             from . import circuit_sym as CS

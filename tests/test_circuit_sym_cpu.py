@@ -148,3 +148,21 @@ def test_an_altered_witness_is_caught_by_the_map(O):
     bad = vals.copy()
     bad[users[0]] = (bad[users[0]] + 1) % CS.R
     assert cm.check_witness(bad, lk)["copies_unequal"] >= 1
+
+
+@pytest.mark.parametrize("x", [1.128, -1.88724767676867, 0.7853981633974483, 4.0])
+def test_fixed_point_example_map_on_the_oracles_witness(O, x):
+    """examples/fixed_point.rs:55-111 at its PRECISION_BITS = 32: load_witness(x), qexp2, qlog2 for a positive x, qsin; x and every result
+    public — the symbolic map (qmod with its asserted sign, the sine's two polynomials) on the oracle's cells"""
+    P, L = 32, 12
+    ops = ("qexp2",) + (("qlog2",) if x > 0 else ()) + ("qsin",)
+    cm, outs = CS.trace_fixed_point(ops, P, L)
+    q = O.quantize(np.array([x]), P)
+    c = O.Ctx(store=True, keygen=True)
+    c.assign_witnesses(q)
+    res = [c.op(name, q[0], P=P, L=L) for name in ops]
+    assert len(c) == cm.n_cells and c.n_lookup == len(cm.lookup_src) and c.err == 0
+    vals = to_ints(O, c.advice())
+    ok, bad = clean(cm.check_witness(vals, to_ints(O, c.lookup()), flags=c.selectors()))
+    assert ok, bad
+    assert [vals[o] for o in outs] == [to_ints(O, q)[0]] + [to_ints(O, r)[0] for r in res]

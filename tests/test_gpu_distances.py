@@ -144,3 +144,49 @@ def test_poseidon_example_proves_with_inputs_and_hash_public(api, O):
         if pr is not None:
             pr.free()
         hp.free()
+
+
+@pytest.mark.parametrize("x", [1.128, -1.88724767676867])
+def test_fixed_point_example_proves_with_x_and_its_results_public(api, O, x):
+    """examples/fixed_point.rs:38-112 (FixedPointChip<32>; LOOKUP_BITS 12, k 13 as its commented-out set_var lines say): load_witness(x),
+    qexp2, qlog2 when x > 0, qsin — the cells against the oracle's, the device MockProver on the whole map (qmod's asserted sign
+    included), a proof whose instances are x and the results, the verifier; the proof bytes against the CPU prover's"""
+    import math
+    from halo2_vectordb_amd.pipeline import FixedPointHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from halo2_vectordb_amd import circuit_sym as CS
+    from oracle import pairing as PR
+    from oracle import prover as PV
+    from test_gpu_cpu_prover import _compare
+    P, L, k = 32, 12, 13
+    hp = FixedPointHotPath(x=x, k=k, P=P, L=L, tau=TAU).setup()
+    pr = None
+    try:
+        assert hp.ops == (("qexp2", "qlog2", "qsin") if x > 0 else ("qexp2", "qsin"))
+        q = O.quantize(np.array([x]), P)
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        c.assign_witnesses(q)
+        res = [c.op(name, q[0], P=P, L=L) for name in hp.ops]
+        assert hp.n_cells == len(c) and hp.n_lookup == c.n_lookup
+        _same_stream(hp, c, O)
+        assert np.array_equal(hp.results(), np.stack(res))
+        f64 = dict(qexp2=lambda v: 2.0 ** v, qlog2=math.log2, qsin=math.sin)
+        for name, got in zip(hp.ops, api.dequantize(hp.results(), P)):
+            assert abs(float(got) - f64[name](x)) <= 5e-3, (name, float(got))        # 32 fractional bits (the example prints its errors)
+        pr = ProverRounds(hp).keygen()
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        assert len(pr.instance_cells) == 1 + len(hp.ops)
+        cm, outs = CS.trace_fixed_point(hp.ops, P, L)
+        cs = PV.Circuit(k, L, c.break_points(), c.selectors(), c.n_lookup, cm.copy_of, cm.const_idx, cm.consts, cm.lookup_src, [int(o) for o in outs])
+        _pk, proofs = _compare(O, PV, hp, pr, cs, c.advice(), c.lookup(), seeds=(5,))
+        out = proofs[0]
+        assert out["instances"] == O.fr_to_ints(np.concatenate([q, np.stack(res)]))
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
+        other = list(out["instances"])
+        other[-1] = (other[-1] + 1) % O.R_MOD                                          # another sine than the circuit computed
+        assert not _verify(O, api, out["proof"], {**vk, "instances": other})
+    finally:
+        if pr is not None:
+            pr.free()
+        hp.free()

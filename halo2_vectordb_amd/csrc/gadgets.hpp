@@ -1076,35 +1076,85 @@ enum FpOp {
   FP_QADD = 0, FP_QSUB, FP_QMUL, FP_QDIV, FP_NEG, FP_QABS, FP_IS_NEG, FP_QMIN, FP_QSQRT, FP_QLOG2, FP_QEXP2, FP_QLOG, FP_QEXP, FP_QPOW, FP_BIT_XOR,
   FP_COND_NEG, FP_SIGNED_DIV_SCALE, FP_QMAX, FP_SIGN, FP_CLIP, FP_QMOD, FP_QSIN, FP_QCOS, FP_QTAN, FP_QSINH, FP_QCOSH, FP_QTANH, FP_OP_COUNT
 };
+// (every case is a function of its own, never inlined: one kernel body holding all 27 generators took the compiler minutes)
+#define VDB_FP_THUNK1(name, expr) \
+  __host__ __device__ __noinline__ inline u256 fp_thunk_##name(Gadgets& g, const u256& a) { return expr; }
+#define VDB_FP_THUNK2(name, expr) \
+  __host__ __device__ __noinline__ inline u256 fp_thunk_##name(Gadgets& g, const u256& a, const u256& b) { return expr; }
+VDB_FP_THUNK2(qadd, g.g_add(a, b))   // qadd / qsub are the gate's add / sub (fixed_point.rs:475-509)
+VDB_FP_THUNK2(qsub, g.g_sub(a, b))
+VDB_FP_THUNK2(qmul, g.fp_qmul(a, b))
+VDB_FP_THUNK2(qdiv, g.fp_qdiv(a, b))
+VDB_FP_THUNK1(neg, g.g_neg(a))
+VDB_FP_THUNK1(qabs, g.fp_qabs(a))
+VDB_FP_THUNK1(is_neg, g.fp_is_neg(a))
+VDB_FP_THUNK2(qmin, g.fp_qmin(a, b))
+VDB_FP_THUNK1(qsqrt, g.fp_qsqrt(a))
+VDB_FP_THUNK1(qlog2, g.fp_qlog2(a))
+VDB_FP_THUNK1(qexp2, g.fp_qexp2(a))
+VDB_FP_THUNK1(qlog, g.fp_qlog(a))
+VDB_FP_THUNK1(qexp, g.fp_qexp(a))
+VDB_FP_THUNK2(qpow, g.fp_qpow(a, b))
+VDB_FP_THUNK2(bit_xor, g.fp_bit_xor(a, b))
+VDB_FP_THUNK2(cond_neg, g.fp_cond_neg(a, b))
+VDB_FP_THUNK1(sds, g.fp_signed_div_scale(a))
+VDB_FP_THUNK2(qmax, g.fp_qmax(a, b))
+VDB_FP_THUNK1(sign, g.fp_sign(a))
+VDB_FP_THUNK1(clip, g.fp_clip(a))
+VDB_FP_THUNK2(qmod, g.fp_qmod(a, b))
+VDB_FP_THUNK1(qsin, g.fp_qsin(a))
+#undef VDB_FP_THUNK1
+#undef VDB_FP_THUNK2
 HD inline u256 fp_op_apply(Gadgets& g, int op, const u256& a, const u256& b) {
   switch (op) {
-    case FP_QADD: return g.g_add(a, b);                    // qadd / qsub are the gate's add / sub (fixed_point.rs:475-509)
-    case FP_QSUB: return g.g_sub(a, b);
-    case FP_QMUL: return g.fp_qmul(a, b);
-    case FP_QDIV: return g.fp_qdiv(a, b);
-    case FP_NEG: return g.g_neg(a);
-    case FP_QABS: return g.fp_qabs(a);
-    case FP_IS_NEG: return g.fp_is_neg(a);
-    case FP_QMIN: return g.fp_qmin(a, b);
-    case FP_QSQRT: return g.fp_qsqrt(a);
-    case FP_QLOG2: return g.fp_qlog2(a);
-    case FP_QEXP2: return g.fp_qexp2(a);
-    case FP_QLOG: return g.fp_qlog(a);
-    case FP_QEXP: return g.fp_qexp(a);
-    case FP_QPOW: return g.fp_qpow(a, b);
-    case FP_BIT_XOR: return g.fp_bit_xor(a, b);
-    case FP_COND_NEG: return g.fp_cond_neg(a, b);
-    case FP_SIGNED_DIV_SCALE: return g.fp_signed_div_scale(a);
-    case FP_QMAX: return g.fp_qmax(a, b);
-    case FP_SIGN: return g.fp_sign(a);
-    case FP_CLIP: return g.fp_clip(a);
-    case FP_QMOD: return g.fp_qmod(a, b);
-    case FP_QSIN: return g.fp_qsin(a);
-    case FP_QCOS: return g.fp_qcos(a);
-    case FP_QTAN: return g.fp_qtan(a);
-    case FP_QSINH: return g.fp_sinh_cosh(a, false);
-    case FP_QCOSH: return g.fp_sinh_cosh(a, true);
-    case FP_QTANH: return g.fp_qtanh(a);
+    case FP_QADD: return fp_thunk_qadd(g, a, b);
+    case FP_QSUB: return fp_thunk_qsub(g, a, b);
+    case FP_QMUL: return fp_thunk_qmul(g, a, b);
+    case FP_QDIV: return fp_thunk_qdiv(g, a, b);
+    case FP_NEG: return fp_thunk_neg(g, a);
+    case FP_QABS: return fp_thunk_qabs(g, a);
+    case FP_IS_NEG: return fp_thunk_is_neg(g, a);
+    case FP_QMIN: return fp_thunk_qmin(g, a, b);
+    case FP_QSQRT: return fp_thunk_qsqrt(g, a);
+    case FP_QLOG2: return fp_thunk_qlog2(g, a);
+    case FP_QEXP2: return fp_thunk_qexp2(g, a);
+    case FP_QLOG: return fp_thunk_qlog(g, a);
+    case FP_QEXP: return fp_thunk_qexp(g, a);
+    case FP_QPOW: return fp_thunk_qpow(g, a, b);
+    case FP_BIT_XOR: return fp_thunk_bit_xor(g, a, b);
+    case FP_COND_NEG: return fp_thunk_cond_neg(g, a, b);
+    case FP_SIGNED_DIV_SCALE: return fp_thunk_sds(g, a);
+    case FP_QMAX: return fp_thunk_qmax(g, a, b);
+    case FP_SIGN: return fp_thunk_sign(g, a);
+    case FP_CLIP: return fp_thunk_clip(g, a);
+    case FP_QMOD: return fp_thunk_qmod(g, a, b);
+    case FP_QSIN: return fp_thunk_qsin(g, a);
+    case FP_QCOS: {  // :843-852
+      u256 hp = g.load_constant(g.T.c_half_pi);
+      u256 t = fp_thunk_qadd(g, a, hp);
+      return fp_thunk_qsin(g, t);
+    }
+    case FP_QTAN: {  // :383-393
+      u256 s = fp_thunk_qsin(g, a);
+      u256 hp = g.load_constant(g.T.c_half_pi);
+      u256 t = fp_thunk_qadd(g, a, hp);
+      u256 co = fp_thunk_qsin(g, t);
+      return fp_thunk_qdiv(g, s, co);
+    }
+    case FP_QSINH:
+    case FP_QCOSH:
+    case FP_QTANH: {  // :888-916, :407-417
+      u256 num[2];
+      for (int pass = (op == FP_QCOSH ? 1 : 0); pass <= (op == FP_QSINH ? 0 : 1); pass++) {
+        u256 ea = fp_thunk_qexp(g, a);
+        u256 na = fp_thunk_neg(g, a);
+        u256 ena = fp_thunk_qexp(g, na);
+        u256 nume = pass ? fp_thunk_qadd(g, ea, ena) : fp_thunk_qsub(g, ea, ena);
+        u256 two = g.load_constant(g.T.c_two);
+        num[pass] = fp_thunk_qdiv(g, nume, two);
+      }
+      return op == FP_QSINH ? num[0] : (op == FP_QCOSH ? num[1] : fp_thunk_qdiv(g, num[0], num[1]));
+    }
   }
   return u256_zero();
 }

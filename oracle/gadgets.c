@@ -459,7 +459,7 @@ void orc_fp_dequantize(unsigned P, const fr_t *x, double *out, size_t n) { /* fi
   }
 }
 
-static fpchip *g_chips[16];
+static fpchip *g_chips[1024]; /* one per (P, L) a process ever asks for: at most 32 x 28 */
 static int g_nchips = 0;
 void orc_fp_init(fpchip *f, unsigned P, unsigned L) { /* fixed_point.rs:54-98, 138-187 */
   orc_init();
@@ -504,7 +504,7 @@ void orc_fp_init(fpchip *f, unsigned P, unsigned L) { /* fixed_point.rs:54-98, 1
 static fpchip *chip_get(unsigned P, unsigned L) {
   for (int i = 0; i < g_nchips; i++)
     if (g_chips[i]->P == P && g_chips[i]->L == L) return g_chips[i];
-  if (g_nchips == 16) abort();
+  if (g_nchips == 1024) abort();
   fpchip *f = (fpchip *)malloc(sizeof(fpchip));
   orc_fp_init(f, P, L);
   g_chips[g_nchips++] = f;

@@ -27,7 +27,7 @@ def _run(world, circuit, out, port, extra=()):
     return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("circuit,worlds", [("kmeans", (2, 3, 5)), ("merkle", (2, 4)), ("query", (2, 3)), ("c2", (2,)), ("distances", (2,))])
+@pytest.mark.parametrize("circuit,worlds", [("kmeans", (2, 3, 4)), ("merkle", (2, 4)), ("query", (2, 3)), ("c2", (2,)), ("distances", (2,))])
 def test_sharded_proof_is_the_single_rank_proof(tmp_path, circuit, worlds):
     one = _run(1, circuit, str(tmp_path / "p1.bin"), 0)
     assert one["every_rank_wrote_the_same_bytes"] and one["quotient_identity_at_x_holds"] and one["mock_prover_violations"] == 0

@@ -391,9 +391,38 @@ class Sym:
         s_mpi = self.g_neg(self.polynomial(a_mpi, coef))
         return self.cond_neg(self.g_select(s_mod, s_mpi, lower), a_sign)
 
+    def sign(self, a):                                       # :558-569
+        neg_one = self.g_neg(C(1))
+        return self.g_select(neg_one, C(1), self.is_neg(a))
+
+    def clip(self, a):                                       # :571-586
+        sgn, aa = self.is_neg(a), self.qabs(a)
+        _, rem = self.r_div_mod(aa, 2 * self.P, 254)
+        return self.cond_neg(rem, sgn)
+
+    def qcos(self, a):                                       # :843-852
+        hp = self.load_constant(quantize(1.57079632679489661923132169163975144, self.P))
+        return self.qsin(self.g_add(a, hp))
+
+    def qtan(self, a):                                       # :383-393
+        s = self.qsin(a)
+        return self.qdiv(s, self.qcos(a))
+
+    def _sinh_cosh(self, a, cosh):                           # :888-916
+        ea = self.qexp(a)
+        ena = self.qexp(self.g_neg(a))
+        nume = self.g_add(ea, ena) if cosh else self.g_sub(ea, ena)
+        return self.qdiv(nume, self.load_constant(quantize(2.0, self.P)))
+
+    def qtanh(self, a):                                      # :407-417
+        s = self._sinh_cosh(a, False)
+        return self.qdiv(s, self._sinh_cosh(a, True))
+
     def fp_op(self, name, a):
+        """one unary FixedPointInstructions call (the numbering of vdb_wit_fp_op names the same set)"""
         return dict(qexp2=self.qexp2, qlog2=self.qlog2, qsin=self.qsin, qexp=self.qexp, qlog=self.qlog, qsqrt=self.qsqrt, qabs=self.qabs,
-                    is_neg=self.is_neg)[name](a)
+                    is_neg=self.is_neg, neg=self.g_neg, signed_div_scale=self.signed_div_scale, sign=self.sign, clip=self.clip, qcos=self.qcos,
+                    qtan=self.qtan, qsinh=lambda x: self._sinh_cosh(x, False), qcosh=lambda x: self._sinh_cosh(x, True), qtanh=self.qtanh)[name](a)
 
     def inner_product(self, a, b):                           # :854-874
         res = self.g_add(C(0), C(0))

@@ -166,3 +166,21 @@ def test_fixed_point_example_map_on_the_oracles_witness(O, x):
     ok, bad = clean(cm.check_witness(vals, to_ints(O, c.lookup()), flags=c.selectors()))
     assert ok, bad
     assert [vals[o] for o in outs] == [to_ints(O, q)[0]] + [to_ints(O, r)[0] for r in res]
+
+
+@pytest.mark.parametrize("name", ["neg", "qabs", "is_neg", "qsqrt", "qlog2", "qexp2", "qlog", "qexp", "sign", "clip", "qsin", "qcos", "qtan", "qsinh", "qcosh", "qtanh"])
+def test_every_unary_fixed_point_operation_map_on_the_oracles_witness(O, name):
+    """the symbolic map of one FixedPointInstructions call on a loaded witness (what FixedPointHotPath(ops=...) proves), on the oracle's
+    cells, for a positive and — where the operation takes one — a negative operand"""
+    P, L = 48, 12
+    cm, outs = CS.trace_fixed_point((name,), P, L)
+    for x in ((1.375, 0.6) if name in ("qsqrt", "qlog2", "qlog") else (1.375, -2.25)):
+        q = O.quantize(np.array([x]), P)
+        c = O.Ctx(store=True, keygen=True)
+        c.assign_witnesses(q)
+        res = c.op(name, q[0], P=P, L=L)
+        assert len(c) == cm.n_cells and c.n_lookup == len(cm.lookup_src) and c.err == 0
+        vals = to_ints(O, c.advice())
+        ok, bad = clean(cm.check_witness(vals, to_ints(O, c.lookup()), flags=c.selectors()))
+        assert ok, (name, x, bad)
+        assert vals[outs[1]] == to_ints(O, res)[0]

@@ -190,3 +190,35 @@ def test_fixed_point_example_proves_with_x_and_its_results_public(api, O, x):
         if pr is not None:
             pr.free()
         hp.free()
+
+
+@pytest.mark.parametrize("ops,x", [(("qcos", "qtanh"), 0.9), (("sign", "clip", "qsqrt", "qtan"), 2.75), (("neg", "qsinh", "qcosh", "qexp"), -1.5)])
+def test_other_fixed_point_operations_prove(api, O, ops, x):
+    """FixedPointHotPath with other operations than the example's three: the device MockProver on the traced map, a proof with x and the
+    results public, the verifier — for the operations of the trait that nothing else in the suite proves"""
+    from halo2_vectordb_amd.pipeline import FixedPointHotPath
+    from halo2_vectordb_amd.rounds import ProverRounds
+    from oracle import pairing as PR
+    P, L, k = 48, 12, 13
+    hp = FixedPointHotPath(x=x, ops=ops, k=k, P=P, L=L, tau=TAU).setup()
+    pr = None
+    try:
+        q = O.quantize(np.array([x]), P)
+        c = O.Ctx(store=True, keygen=True, plan_k=k)
+        c.assign_witnesses(q)
+        res = [c.op(name, q[0], P=P, L=L) for name in ops]
+        _same_stream(hp, c, O)
+        assert np.array_equal(hp.results(), np.stack(res))
+        pr = ProverRounds(hp).keygen()
+        assert pr.keygen_report.violations() == 0, pr.keygen_report.as_dict()
+        out = pr.prove(None)
+        assert out["instances"] == O.fr_to_ints(np.concatenate([q, np.stack(res)]))
+        vk = dict(meta=_meta(pr), opened=out["opened"], fixed={name: pr.fixed[name].commits for name in FIXED}, tau_h=PR.pt_mul(PR.G2, TAU))
+        assert _verify(O, api, out["proof"], {**vk, "instances": out["instances"]})
+        other = list(out["instances"])
+        other[1] = (other[1] + 1) % O.R_MOD
+        assert not _verify(O, api, out["proof"], {**vk, "instances": other})
+    finally:
+        if pr is not None:
+            pr.free()
+        hp.free()

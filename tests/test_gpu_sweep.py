@@ -374,3 +374,34 @@ def test_device_mock_prover_counts_what_a_host_recount_counts(api, O):
     finally:
         for b in bufs.values():
             b.free()
+
+
+def test_rank_windows_of_the_single_operation_entry_point(api, O):
+    """vdb_wit_fp_op_dev under random rank windows: the cells inside, nothing outside, every result on every rank"""
+    from halo2_vectordb_amd._lib import check
+    lib = api.init()
+    rng = np.random.default_rng(5150)
+    P, L, n = 48, 11, 37
+    for name in ("qmul", "qdiv", "qsqrt", "qsin", "qtanh", "qmod"):
+        x = rng.uniform(0.2, 6.0, n)
+        y = rng.uniform(0.3, 5.0, n)
+        qa, qb = O.quantize(x, P), O.quantize(y, P)
+        binary = name in ("qmul", "qdiv", "qmod")
+        c = O.Ctx(store=True)
+        want = np.stack([c.op(name, qa[i], qb[i] if binary else None, P=P, L=L) for i in range(n)])
+        adv, lk = c.advice(), c.lookup()
+        bufs = [api.DeviceBuffer(qa.nbytes), api.DeviceBuffer(qb.nbytes), api.DeviceBuffer(want.nbytes)]
+        try:
+            bufs[0].upload(qa)
+            bufs[1].upload(qb)
+            lo, hi = sorted(int(v) for v in rng.integers(0, len(adv) + 1, 2))
+            llo, lhi = sorted(int(v) for v in rng.integers(0, len(lk) + 1, 2))
+            run = lambda d_adv, d_lk: check(lib.vdb_wit_fp_op_dev(api.FP_OPS[name], P, L, bufs[0].ptr, bufs[1].ptr if binary else None, n, d_adv.ptr, d_lk.ptr,
+                                                                  None, bufs[2].ptr))
+            for window in ((lo, hi, llo, lhi), (0, len(adv), 0, len(lk))):
+                g_adv, g_lk = _windowed(api, lib, check, adv, lk, window, run)
+                _check_window(adv, lk, g_adv, g_lk, window, (name, window))
+                assert np.array_equal(bufs[2].download(want.shape), want), name
+        finally:
+            for b in bufs:
+                b.free()

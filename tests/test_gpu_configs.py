@@ -362,7 +362,7 @@ def test_a_failing_rank_of_the_sharded_proof_does_not_cost_the_bench_line(tmp_pa
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", VDB_BENCH_TEST_FAIL_RANK="1", VDB_BENCH_PROOF_TIMEOUT="12")
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", VDB_BENCH_TEST_FAIL_RANK="1", VDB_BENCH_PROOF_TIMEOUT="5")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -818,3 +818,44 @@ def test_quotient_terms_coset_by_coset_are_the_natural_order_ones(api, O):
                 b.free()
         d_a.free()
         d_s.free()
+
+
+def test_lookup_permute_sweep_of_shapes_and_value_patterns(api, O):
+    """the lookup argument's permuted columns on inputs no witness produces: every column height 2^6 .. 2^12 with table widths from 2 bits
+    up, one value only, two values, every table entry exactly once (as far as the rows reach), the largest entry alone, values that
+    appear once among long runs — against the oracle's construction, with the two properties the argument needs"""
+    rng = np.random.default_rng(8086)
+    for case in range(18):
+        k = int(rng.integers(6, 13))
+        n = 1 << k
+        usable = n - 6
+        bits = int(rng.integers(2, min(k, 12)))
+        table = _range_table(O, n, bits)
+        tab_ints = O.fr_to_ints(table[:usable])
+        m = 1 << bits
+        cols = []
+        for pattern in range(int(rng.integers(1, 5))):
+            kind = (case + pattern) % 6
+            if kind == 0:
+                v = np.full(n, int(rng.integers(0, m)))
+            elif kind == 1:
+                v = rng.choice([0, m - 1], size=n)
+            elif kind == 2:
+                v = np.arange(n) % m
+            elif kind == 3:
+                v = np.full(n, m - 1)
+            elif kind == 4:
+                v = np.zeros(n, dtype=np.int64)
+                v[rng.integers(0, usable, 5)] = rng.integers(0, m, 5)
+            else:
+                v = rng.integers(0, m, size=n)
+            cols.append(O.fr_from_ints([int(x) for x in v]))
+        ins = np.stack(cols)
+        got_a, got_s = api.lookup_permute(ins, table, usable, bits)
+        for c in range(len(cols)):
+            want_a, want_s = O.lookup_permute(O.fr_to_ints(ins[c, :usable]), tab_ints)
+            assert O.fr_to_ints(got_a[c, :usable]) == want_a, (case, c, k, bits)
+            assert O.fr_to_ints(got_s[c, :usable]) == want_s, (case, c, k, bits)
+            assert not got_a[c, usable:].any() and not got_s[c, usable:].any()
+            assert sorted(want_s) == sorted(tab_ints)
+            assert all(want_a[i] == want_s[i] or (i and want_a[i] == want_a[i - 1]) for i in range(usable))

@@ -859,3 +859,32 @@ def test_lookup_permute_sweep_of_shapes_and_value_patterns(api, O):
             assert not got_a[c, usable:].any() and not got_s[c, usable:].any()
             assert sorted(want_s) == sorted(tab_ints)
             assert all(want_a[i] == want_s[i] or (i and want_a[i] == want_a[i - 1]) for i in range(usable))
+
+
+def test_polynomial_bricks_sweep_over_odd_lengths(api, O):
+    """grand products, evaluation, division by (X - x) and the Horner combination at lengths and batch widths that are no power of two
+    and no multiple of a workgroup (1 .. 5000 coefficients, 1 .. 9 polynomials), at random points and at 0, 1, -1 and a root of unity —
+    against the oracle / the Python-integer restatement"""
+    rng = np.random.default_rng(24601)
+    R = O.R_MOD
+    for case in range(16):
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 1023, 1025, 2049, 4097])) if case % 2 else int(rng.integers(1, 5000))
+        n_cols = int(rng.integers(1, 10))
+        polys = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+        pts = [O.random_fr(rng, 1)[0], O.fr_from_ints([0])[0], O.fr_from_ints([1])[0], O.fr_from_ints([R - 1])[0], O.root_of_unity(int(rng.integers(1, 12)))]
+        x = pts[case % len(pts)]
+        xi = O.fr_to_ints(x.reshape(1, 4))[0]
+        ev = api.eval_polys(polys, x)
+        assert np.array_equal(ev, O.eval_polys(polys, x)), (case, n, n_cols)
+        q, rem = api.kate_div(polys, x)
+        assert np.array_equal(rem, ev)
+        c = int(rng.integers(0, n_cols))
+        want_q, want_r = _kate_div_ints(O.fr_to_ints(polys[c]), xi, R)
+        assert O.fr_to_ints(q[c]) == want_q and O.fr_to_ints(rem[c].reshape(1, 4))[0] == want_r, (case, n)
+        v = O.random_fr(rng, 1)[0]
+        acc = np.zeros((n, 4), dtype=np.uint64)
+        for j in range(n_cols):
+            acc = O.fr_add(O.fr_mul(acc, np.tile(v, (n, 1))), polys[j])
+        assert np.array_equal(api.poly_lincomb(polys, v), acc), (case, n, n_cols)
+        den = O.random_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+        assert np.array_equal(api.grand_product(polys, den), O.grand_product(polys, den)), (case, n, n_cols)

@@ -191,3 +191,18 @@ def test_transform_sweep_every_size_and_odd_batches(api, O):
         assert np.array_equal(got_c, want_c), k
         if k + ext <= 19:
             assert np.array_equal(api.coeff_to_extended(got_c, ext), want_e), (k, ext)
+
+
+def test_poseidon_sweep_of_message_lengths_and_tree_sizes(api, O):
+    """the sponge at every message length 0 .. 21 (an empty absorb, lengths on both sides of every multiple of the rate) with batch sizes
+    that fill no wavefront, and merkle_commitment's root for every number of leaves 1 .. 20 (padding to the next power of two at every
+    position) at odd and even vector widths — against the oracle"""
+    rng = np.random.default_rng(5432)
+    for ln in range(0, 22):
+        n = int(rng.integers(1, 131))
+        msgs = O.random_fr(rng, n * max(ln, 1)).reshape(n, max(ln, 1), 4)[:, :ln]
+        assert np.array_equal(api.poseidon_hash_many(msgs), O.poseidon_hash_many(msgs)), (ln, n)
+    for n in range(1, 21):
+        dim = int(rng.integers(1, 12))
+        v = O.random_fr(rng, n * dim).reshape(n, dim, 4)
+        assert np.array_equal(api.poseidon_merkle_root(v), O.poseidon_merkle_root(v)), (n, dim)

@@ -40,6 +40,27 @@ def test_sharded_proof_is_the_single_rank_proof(tmp_path, circuit, worlds):
         assert rep["sha256"] == one["sha256"] and rep["n_instances"] == one["n_instances"]
 
 
+def test_sharded_proofs_of_random_kmeans_shapes(tmp_path):
+    """seeded random k-means circuits (vectors, width, clusters, iterations, column height, lookup width, cosine or manhattan) on three and
+    four ranks: where the column blocks, the sets of the permutation argument and the advice / lookup junction fall is different every
+    time — the bytes are the one-rank proof's"""
+    rng = np.random.default_rng(2718)
+    for case in range(3):
+        n, dim = int(rng.integers(5, 12)), int(rng.integers(2, 7))
+        K, I = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+        k = int(rng.integers(10, 13))
+        L = int(rng.integers(8, k))
+        metric = ("cosine", "manhattan")[case % 2]
+        circuit = f"kmeans:{n},{dim},{K},{I},{k},{L},{metric}"
+        one = _run(1, circuit, str(tmp_path / f"r{case}_1.bin"), 29560 + 3 * case)
+        want = open(tmp_path / f"r{case}_1.bin", "rb").read()
+        assert one["quotient_identity_at_x_holds"] and len(want) > 0
+        world = 3 + case % 2
+        rep = _run(world, circuit, str(tmp_path / f"r{case}_{world}.bin"), 29561 + 3 * case)
+        assert rep["world"] == world and rep["every_rank_wrote_the_same_bytes"] and rep["quotient_identity_at_x_holds"], (circuit, rep)
+        assert open(tmp_path / f"r{case}_{world}.bin", "rb").read() == want, (circuit, world)
+
+
 def test_sharded_streamed_proof_and_the_verifier(tmp_path, O):
     """two ranks, cosets held 7 columns at a time and blocks of 12 columns (the streamed rounds): the same bytes again, and the
     stand-alone verifier of tests/test_gpu_rounds.py accepts them against the gathered fixed commitments"""

@@ -59,7 +59,10 @@ def main():
     from halo2_vectordb_amd.pipeline import KmeansHotPath, MerkleHotPath, NearestHotPath, QueryHotPath
     from halo2_vectordb_amd.rounds import ProverRounds, quotient_identity_holds
     shard = (rank, world)
-    if args.circuit == "kmeans":
+    if args.circuit.startswith("kmeans:"):    # a shape of the caller's: kmeans:n,dim,K,I,k,L,metric (the tests' seeded random shapes)
+        n_, dim_, K_, I_, k_, L_, metric_ = args.circuit.split(":", 1)[1].split(",")
+        hp = KmeansHotPath(n=int(n_), dim=int(dim_), K=int(K_), I=int(I_), k=int(k_), L=int(L_), metric=metric_, tau=TAU, col_shard=shard)
+    elif args.circuit == "kmeans":
         hp = KmeansHotPath(n=8, dim=4, K=2, I=2, k=12, L=11, metric="cosine", tau=TAU, col_shard=shard)
     elif args.circuit == "nearest":
         hp = NearestHotPath(n=6, dim=4, k=12, L=11, tau=TAU, col_shard=shard)
